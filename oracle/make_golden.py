@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.pt by running the REAL reference (imported from /root/reference).
+
+TEST INFRASTRUCTURE.  Runs only in the build container (the reference cannot travel to the GPU
+box); the outputs are small data fixtures (inputs are re-derived from seeds, weights from
+``oracle.weights.fill_state_dict``).  Usage:  python oracle/make_golden.py
+
+Stand-ins injected before the import (ordinary ModuleNotFoundError otherwise):
+  * ``torchvision.models`` -> oracle/resnet_topology.py (published ResNet topology, restated)
+  * ``thop``               -> empty stub (only imported by utils/nn.py:7, never called on this path)
+"""
+import os
+import sys
+import types
+from pathlib import Path
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference/PMoE")
+sys.path.insert(0, str(REPO))
+
+from oracle import resnet_topology, weights          # noqa: E402
+from oracle.pmoe_oracle import Cfg, stage2_cfg       # noqa: E402
+
+
+def import_reference():
+    tv = types.ModuleType("torchvision")
+    tv.models = resnet_topology
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = resnet_topology
+    thop = types.ModuleType("thop")
+    thop.profile = thop.clever_format = lambda *a, **k: None
+    sys.modules["thop"] = thop
+    sys.path.insert(0, str(REF))
+    sys.path.insert(0, str(REF / "trainer"))
+    from model import moe as ref_moe               # noqa
+    from model.blocks import basics as ref_basics  # noqa
+    import loss as ref_loss                        # noqa
+    return ref_moe, ref_basics, ref_loss
+
+
+GRAD_SLICES = [
+    "moe.0.backbone.conv1.layer1.eca1.conv.weight",
+    "moe.0.backbone.conv1.layer1.conv1.0.weight",
+    "moe.0.backbone.conv1.layer1.conv1.1.weight",
+    "moe.0.backbone.conv1.layer2.eca2.conv.weight",
+    "moe.0.backbone.conv1.layer2.conv2.0.weight",
+    "moe.0.backbone.bn1.bias",
+    "moe.1.backbone.layer1.0.conv1.weight",
+    "moe.1.backbone.layer2.0.downsample.0.weight",
+    "moe.1.backbone.layer2.0.downsample.1.weight",
+    "moe.0.backbone.layer4.1.conv2.weight",
+    "moe.0.backbone.layer4.1.bn2.weight",
+    "moe.0.speed_encoder.0.weight",
+    "moe.0.command_encoder.0.weight",
+    "moe.0.speed_pred.0.weight",
+    "moe.1.action_features.0.weight",
+    "moe.0.action_pred.weight",
+    "moe.0.action_pred.bias",
+    "moe.1.alpha.weight",
+]
+
+
+def run_case(ref_moe, ref_loss, name, model_type, n_experts, batch, size, train=True, steps=0):
+    torch.manual_seed(0)
+    cfg = stage2_cfg(model_type, n_experts, dropout=0.0)
+    model = ref_moe.get_model(cfg)
+    weights.fill_state_dict(model, seed=0)
+    model.train(train)
+    inp = weights.make_inputs(batch, size, size, seed=1234)
+    out = {"meta": dict(name=name, type=model_type, n_experts=n_experts, batch=batch, size=size,
+                        train=train, weight_seed=0, input_seed=1234),
+           "state_dict_keys": list(model.state_dict().keys()),
+           "state_dict_shapes": [tuple(v.shape) for v in model.state_dict().values()]}
+    if train:
+        dist, speeds = model(inp["images"], inp["speed"], inp["command"])
+        loss = ref_loss.moe_loss(dist, speeds, inp["control"], inp["target_speed"].clone(), cfg.loss_coefs)
+        loss.backward()
+        out["loss"] = loss.detach().clone()
+        named = dict(model.named_parameters())
+        out["grad_norms"] = {k: p.grad.norm().item() for k, p in named.items()}
+        out["grad_sums"] = {k: p.grad.double().sum().item() for k, p in named.items()}
+        sl = {}
+        for k in GRAD_SLICES:
+            if k in named:
+                sl[k] = named[k].grad.flatten()[:64].clone()
+        if model_type == "moe_alt":
+            for k in ("moe.0.alpha.0.weight", "moe.0.alpha.2.weight", "moe.0.alpha.2.bias"):
+                sl[k] = named[k].grad.flatten()[:64].clone()
+        out["grad_slices"] = sl
+        sd = model.state_dict()
+        out["bn_after_1"] = {k: sd[k].clone() for k in sd
+                             if k.startswith("moe.0.backbone") and
+                             (k.endswith("running_mean") or k.endswith("running_var")
+                              or k.endswith("num_batches_tracked"))
+                             and ("conv1.layer1" in k or "bn1" in k.split(".")[3:4] or "layer4.1.bn2" in k
+                                  or "layer2.0.downsample" in k)}
+    else:
+        with torch.no_grad():
+            dist, speeds = model(inp["images"], inp["speed"], inp["command"])
+    out["probs"] = dist.mixture_distribution.probs.detach().clone()
+    out["mean"] = dist.component_distribution.base_dist.loc.detach().clone()
+    out["std"] = dist.component_distribution.base_dist.scale.detach().clone()
+    out["speeds"] = speeds.detach().clone()
+    out["log_prob"] = dist.log_prob(inp["control"]).detach().clone()
+    # per-expert 1536-d feature slice (first 8 of each 512 block) via the reference's own modules
+    with torch.no_grad():
+        model.eval()
+        e0 = model.moe[0]
+        x = inp["images"].view(batch, -1, size, size)
+        out["feat_eval_e0"] = e0.backbone(x)[:, :16].clone()
+        model.train(train)
+
+    if steps:
+        # H1: the reference's own step recipe (train_2.py:149-165): fwd, moe_loss, zero_grad, backward,
+        # clip_grad_norm_(1.0), grad-norm, Adam(amsgrad) step.
+        torch.manual_seed(0)
+        model = ref_moe.get_model(cfg)
+        weights.fill_state_dict(model, seed=0)
+        model.train()
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()),
+                               lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)
+        traj = []
+        for _ in range(steps):
+            dist, speeds = model(inp["images"], inp["speed"], inp["command"])
+            loss = ref_loss.moe_loss(dist, speeds, inp["control"], inp["target_speed"].clone(), cfg.loss_coefs)
+            opt.zero_grad()
+            loss.backward()
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            traj.append(dict(loss=loss.item(), grad_norm=float(gn)))
+        named = dict(model.named_parameters())
+        out["h1"] = dict(traj=traj, param_sums={k: named[k].double().sum().item() for k in GRAD_SLICES if k in named},
+                         param_l2={k: named[k].norm().item() for k in GRAD_SLICES if k in named})
+    return out
+
+
+def micro_cases(ref_basics, ref_loss):
+    """Layer-level fixtures (G5): ECA kernel sizes, make_mlp layouts, ECA forward, moe_loss values."""
+    out = {}
+    out["eca_k"] = {c: ref_basics.EfficientBlock(c).conv.kernel_size[0] for c in (12, 64, 92, 138, 512)}
+    layouts = {}
+    for bn in (False, True):
+        for p in (0.0, 0.3):
+            for dims in ([6, 512, 512], [1536, 512, 512, 1]):
+                m = ref_basics.make_mlp(dims, "relu", False, bn, p)
+                layouts[(bn, p, tuple(dims))] = list(m.state_dict().keys())
+    out["mlp_layouts"] = layouts
+    g = torch.Generator().manual_seed(7)
+    eca = ref_basics.EfficientBlock(64)
+    with torch.no_grad():
+        eca.conv.weight.copy_(torch.tensor([[[0.3, -0.7, 0.5]]]))
+    x = torch.randn(2, 64, 5, 7, generator=g)
+    out["eca_x_seed"] = 7
+    out["eca_y"] = eca(x).detach()
+    # moe_loss on explicit mixture parameters
+    import torch.distributions as D
+    probs = torch.softmax(torch.randn(5, 4, generator=g), -1)
+    mean = torch.randn(5, 4, 2, generator=g)
+    std = torch.rand(5, 4, 2, generator=g) + 0.3
+    speeds = torch.randn(5, 4, 1, generator=g)
+    act = torch.rand(5, 2, generator=g) * 2 - 1
+    tgt = torch.rand(5, 1, generator=g)
+    dist = D.MixtureSameFamily(D.Categorical(probs), D.Independent(D.Normal(mean, std), 1))
+    out["loss_case"] = dict(probs=probs, mean=mean, std=std, speeds=speeds, act=act, tgt=tgt,
+                            loss=ref_loss.moe_loss(dist, speeds, act, tgt.clone(), [0.7, 0.3]).detach())
+    return out
+
+
+def main():
+    ref_moe, ref_basics, ref_loss = import_reference()
+    gold = REPO / "tests" / "golden"
+    gold.mkdir(parents=True, exist_ok=True)
+    cases = [
+        ("g1_moe_e4_b2_128", "moe", 4, 2, 128, True, 5),
+        ("g2_moe_e4_b1_224_eval", "moe", 4, 1, 224, False, 0),
+        ("g3_moe_e8_b2_128", "moe", 8, 2, 128, True, 0),
+        ("g4_moealt_e4_b2_64", "moe_alt", 4, 2, 64, True, 0),
+        ("g5_moe_e3_b3_96", "moe", 3, 3, 96, True, 0),
+    ]
+    for name, t, e, b, s, train, steps in cases:
+        res = run_case(ref_moe, ref_loss, name, t, e, b, s, train, steps)
+        torch.save(res, gold / f"{name}.pt")
+        print(name, "loss" in res and float(res["loss"]), res["probs"][0].tolist())
+    torch.save(micro_cases(ref_basics, ref_loss), gold / "micro.pt")
+    print("wrote", sorted(p.name for p in gold.glob("*.pt")))
+
+
+if __name__ == "__main__":
+    main()

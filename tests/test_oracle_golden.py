@@ -1,0 +1,108 @@
+"""The CPU oracle (oracle/pmoe_oracle.py) against golden vectors produced by the imported
+reference (oracle/make_golden.py).  This is what pins the oracle; tolerance is fp32 round-off of
+two CPU implementations of the same graph (bit-equal in practice)."""
+import pytest
+import torch
+
+from oracle import pmoe_oracle as O
+from oracle import weights as W
+
+
+def _load(golden_dir, name):
+    return torch.load(golden_dir / f"{name}.pt", weights_only=False)
+
+
+def _run(g):
+    m = g["meta"]
+    cfg = O.stage2_cfg(m["type"], m["n_experts"], dropout=0.0)
+    model = O.get_model(cfg)
+    W.fill_state_dict(model, seed=m["weight_seed"])
+    model.train(m["train"])
+    inp = W.make_inputs(m["batch"], m["size"], m["size"], seed=m["input_seed"])
+    return cfg, model, inp
+
+
+CASES = ["g1_moe_e4_b2_128", "g3_moe_e8_b2_128", "g4_moealt_e4_b2_64", "g5_moe_e3_b3_96"]
+
+
+@pytest.mark.parametrize("name", CASES + ["g2_moe_e4_b1_224_eval"])
+def test_state_dict_layout_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg, model, _ = _run(g)
+    sd = model.state_dict()
+    assert list(sd.keys()) == g["state_dict_keys"]
+    assert [tuple(v.shape) for v in sd.values()] == g["state_dict_shapes"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_forward_backward_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg, model, inp = _run(g)
+    dist, speeds = model(inp["images"], inp["speed"], inp["command"])
+    loss = O.moe_loss(dist, speeds, inp["control"], inp["target_speed"], cfg.loss_coefs)
+    loss.backward()
+    tol = dict(rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dist.mixture_distribution.probs, g["probs"], **tol)
+    torch.testing.assert_close(dist.component_distribution.base_dist.loc, g["mean"], **tol)
+    torch.testing.assert_close(dist.component_distribution.base_dist.scale, g["std"], **tol)
+    torch.testing.assert_close(speeds, g["speeds"], **tol)
+    torch.testing.assert_close(loss.detach(), g["loss"], **tol)
+    torch.testing.assert_close(dist.log_prob(inp["control"]).detach(), g["log_prob"], **tol)
+    named = dict(model.named_parameters())
+    for k, n in g["grad_norms"].items():
+        assert named[k].grad.norm().item() == pytest.approx(n, rel=1e-4, abs=1e-7), k
+    for k, sl in g["grad_slices"].items():
+        torch.testing.assert_close(named[k].grad.flatten()[:64], sl, rtol=1e-4, atol=1e-6)
+    sd = model.state_dict()
+    for k, v in g["bn_after_1"].items():
+        torch.testing.assert_close(sd[k], v, rtol=1e-5, atol=1e-6)
+    # explicit mixture log-likelihood formula == torch.distributions
+    ll = O.mixture_nll_explicit(dist.mixture_distribution.probs, g["mean"], g["std"], inp["control"])
+    torch.testing.assert_close(ll.detach(), g["log_prob"], rtol=1e-5, atol=1e-5)
+
+
+def test_eval_forward_matches_reference(golden_dir):
+    g = _load(golden_dir, "g2_moe_e4_b1_224_eval")
+    cfg, model, inp = _run(g)
+    with torch.no_grad():
+        dist, speeds = model(inp["images"], inp["speed"], inp["command"])
+    torch.testing.assert_close(dist.mixture_distribution.probs, g["probs"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dist.component_distribution.base_dist.loc, g["mean"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(speeds, g["speeds"], rtol=1e-5, atol=1e-6)
+    assert model.sample(inp["images"], inp["speed"], inp["command"]).shape == (1, 2)
+
+
+def test_h1_step_trajectory_matches_reference(golden_dir):
+    """Caller row H1 (train_2.py:149-165): 5 steps of fwd / moe_loss / backward / clip 1.0 / Adam(amsgrad)."""
+    g = _load(golden_dir, "g1_moe_e4_b2_128")
+    cfg, model, inp = _run(g)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
+    for ref in g["h1"]["traj"]:
+        dist, speeds = model(inp["images"], inp["speed"], inp["command"])
+        loss = O.moe_loss(dist, speeds, inp["control"], inp["target_speed"], cfg.loss_coefs)
+        opt.zero_grad()
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        assert loss.item() == pytest.approx(ref["loss"], rel=2e-4)
+        assert float(gn) == pytest.approx(ref["grad_norm"], rel=2e-3)
+    named = dict(model.named_parameters())
+    for k, v in g["h1"]["param_l2"].items():
+        assert named[k].norm().item() == pytest.approx(v, rel=1e-5)
+
+
+def test_micro_cases(golden_dir):
+    g = _load(golden_dir, "micro")
+    for c, k in g["eca_k"].items():
+        assert O.eca_kernel_size(c) == k
+    for (bn, p, dims), keys in g["mlp_layouts"].items():
+        assert list(O.make_mlp(list(dims), "relu", False, bn, p).state_dict().keys()) == keys
+    eca = O.EfficientBlock(64)
+    with torch.no_grad():
+        eca.conv.weight.copy_(torch.tensor([[[0.3, -0.7, 0.5]]]))
+    x = torch.randn(2, 64, 5, 7, generator=torch.Generator().manual_seed(g["eca_x_seed"]))
+    torch.testing.assert_close(eca(x), g["eca_y"], rtol=1e-6, atol=1e-6)
+    lc = g["loss_case"]
+    import torch.distributions as D
+    dist = D.MixtureSameFamily(D.Categorical(lc["probs"]), D.Independent(D.Normal(lc["mean"], lc["std"]), 1))
+    torch.testing.assert_close(O.moe_loss(dist, lc["speeds"], lc["act"], lc["tgt"], [0.7, 0.3]), lc["loss"])
