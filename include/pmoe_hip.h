@@ -1,0 +1,196 @@
+/* libpmoe_hip.so -- C ABI of the MI355X (gfx950) kernels behind PMoE's stage-2 policy networks.
+ *
+ * The reference (mhnazeri/PMoE) has no native layer at all: its hot path reaches cuDNN/cuBLAS/ATen
+ * through torch.nn.  Each entry point below therefore names the torch.nn / torch.nn.functional call
+ * site in the reference whose arithmetic it replaces (paths relative to /root/reference/PMoE).
+ * `pmoe_amd/hip.py` is the ctypes binding the Python host uses; INTEGRATION.md shows how a
+ * maintainer of the reference would bind it.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, ints, floats; no torch / STL types; nothing is allocated or
+ *     freed here (the caller owns every buffer, scratch included); launches go to `stream`
+ *     (a hipStream_t passed as void*), never the null stream implicitly, and never synchronise.
+ *   - return value: 0 = launched; >0 = hipError_t; PMOE_ERR_* (<0) = rejected arguments.
+ *   - activations are NHWC ("channels last"), element type `dtype` (PMOE_DT_BF16 | PMOE_DT_F32),
+ *     with the E experts folded into the image index: image n belongs to expert n / ipe.
+ *     Every channel count is padded by the caller to a multiple of 16 (zero filled).
+ *   - re-entrant, no global mutable state besides one-time kernel attribute setup.
+ */
+#ifndef PMOE_HIP_H
+#define PMOE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMOE_DT_BF16 0
+#define PMOE_DT_F32 1
+
+#define PMOE_ERR_ARG (-1)
+#define PMOE_ERR_UNSUPPORTED (-2)
+
+#define PMOE_ACT_NONE 0
+#define PMOE_ACT_RELU 1
+#define PMOE_ACT_ELU 2
+
+#define PMOE_RES_NONE 0
+#define PMOE_RES_ADD 1     /* out = acc + res                                   (residual / grad sum) */
+#define PMOE_RES_DRELU 2   /* out = acc * relu'(res), res = saved layer output  (MLP backward)        */
+#define PMOE_RES_DELU 3    /* out = acc * elu'(res),  res = saved layer output                        */
+
+int pmoe_version(void);
+const char* pmoe_error_string(int code);
+/* sizeof() of the descriptor structs as compiled (which: 0 = pmoe_conv_desc, 1 = pmoe_wgrad_desc);
+ * lets a foreign-language binding verify its struct layout without launching anything */
+int pmoe_abi_sizeof(int which);
+
+/* ---- convolution / grouped GEMM -------------------------------------------------------------
+ * Replaces nn.Conv2d in model/blocks/basics.py:93-100,113-120 (stem), the torchvision ResNet body
+ * built at model/blocks/backbone.py:57-70, and nn.Linear in model/blocks/basics.py:31 /
+ * model/moe.py:71-72 (a Linear over the per-expert batch is a 1x1 conv on 1x1 images).
+ * Also their data gradients: stride-1 dgrad = the same conv with flipped/transposed weights,
+ * stride-2 dgrad = `dilate` (transposed conv: the source is read as if zero-upsampled by 2). */
+typedef struct pmoe_conv_desc {
+    const void* in;       /* [Nin][H][W][in_ld]; reduces over channels [in_coff, in_coff+cin)      */
+    const void* w;        /* packed [E][coutp][ks*ks][cin] (pmoe_pack_conv_weights)                */
+    void* out;            /* [N][Ho][Wo][out_ld]; writes channels [out_coff, out_coff+cout)        */
+    const void* res;      /* optional, geometry of out with res_ld/res_coff (see PMOE_RES_*)       */
+    const float* bias;    /* optional [E][coutp] f32                                               */
+    float* stats;         /* optional [pmoe_conv2d_stat_rows()][2][coutp] f32 BN partial sums      */
+    int32_t n, h, w_, cin;
+    int32_t ho, wo, cout, coutp;
+    int32_t in_ld, in_coff, out_ld, out_coff, res_ld, res_coff;
+    int32_t ipe;          /* images per expert                                                     */
+    int32_t in_shared;    /* 1: `in` holds ipe images read by every expert                         */
+    int32_t ks, stride, pad, dilate;
+    int32_t act, res_mode;
+    float drop_p;         /* >0: inverted dropout on the output (nn.Dropout, basics.py:39)         */
+    uint64_t seed;
+    int32_t dtype;
+} pmoe_conv_desc;
+
+int pmoe_conv2d_igemm(const pmoe_conv_desc* d, void* stream);
+/* number of [2][coutp] partial-sum rows the launch writes to d->stats (rows of expert e are
+ * contiguous: [e*rows/E, (e+1)*rows/E) ); <0 = error */
+int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
+
+/* Weight gradient of the same layers (autograd of nn.Conv2d / nn.Linear at the call sites above).
+ * Accumulates into dw_ws [E][ks*ks][coutp][cinp] f32 with atomics: zero it first. */
+typedef struct pmoe_wgrad_desc {
+    const void* x;        /* layer input  [Nin][H][W][x_ld]  */
+    const void* dy;       /* output grad  [N][Ho][Wo][dy_ld] */
+    float* dw_ws;
+    int32_t n, h, w_, cin, cinp;
+    int32_t ho, wo, cout, coutp;
+    int32_t x_ld, x_coff, dy_ld, dy_coff;
+    int32_t ipe, x_shared;
+    int32_t ks, stride, pad;
+    int32_t dtype;
+} pmoe_wgrad_desc;
+int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
+
+/* Master weights live in the reference's own layout (one f32 OIHW / [out][in] tensor per expert,
+ * state_dict keys of SURVEY.md section 8b); these repack all E experts of a layer in one launch.
+ * src_ptrs: device array of E pointers to f32 [cout][cin][ks][ks].
+ * fwd : [E][coutp][ks*ks][cinp]                       (conv / linear forward, wgrad layout)
+ * dgrd: [E][cinp2][ks*ks][coutp2] with taps reversed   (operand of the data-gradient launch)
+ * either destination may be null. */
+int pmoe_pack_conv_weights(const void* const* src_ptrs, void* fwd, void* dgrd, int32_t E, int32_t cout,
+                           int32_t cin, int32_t ks, int32_t coutp, int32_t cinp, int32_t cinp2, int32_t coutp2,
+                           int32_t dtype, void* stream);
+/* dw_ws [E][ks*ks][coutp][cinp] f32 -> grads [E][cout][cin][ks][ks] f32 (contiguous arena slice) */
+int pmoe_unpack_conv_wgrad(const float* dw_ws, float* grads, int32_t E, int32_t cout, int32_t cin, int32_t ks,
+                           int32_t coutp, int32_t cinp, void* stream);
+/* bias pack: E pointers to f32 [cout] -> f32 [E][coutp] */
+int pmoe_pack_bias(const void* const* src_ptrs, float* dst, int32_t E, int32_t cout, int32_t coutp, void* stream);
+
+/* ---- BatchNorm2d, training mode (nn.BatchNorm2d at basics.py:101,121; torchvision bn1/bn2/downsample.1)
+ * rows = N*H*W activations of C channels; expert e owns rows [e*rows_per_expert, ...).            */
+/* per-(expert,channel) partial sums: part [E][nparts][2][C] f32 */
+int pmoe_colstats(const void* x, int64_t rows_per_expert, int32_t E, int32_t C, int32_t ld, int32_t coff,
+                  float* part, int32_t nparts, int32_t dtype, void* stream);
+/* deterministic tree step: part_in [E][nin][W] -> part_out [E][nout][W] (W = 2*C floats) */
+int pmoe_reduce_partials(const float* part_in, float* part_out, int32_t E, int32_t nin, int32_t nout, int32_t width,
+                         void* stream);
+/* finalize: mean/var from partials; writes scale = gamma*invstd, shift = beta - mean*scale, mean, invstd
+ * ([E][C] f32 each); updates running_mean / running_var in place (momentum, unbiased var) through
+ * per-expert pointer tables when they are non-null.  training=0: stats come from the running buffers. */
+int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const void* const* gamma_ptrs,
+                     const void* const* beta_ptrs, void* const* rmean_ptrs, void* const* rvar_ptrs, float momentum,
+                     float eps, int32_t training, float* scale, float* shift, float* mean, float* invstd, int32_t E,
+                     int32_t C, void* stream);
+/* y = [relu]( x*scale + shift [+ res] ) */
+int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,
+                  int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream);
+/* backward reduce: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat -> part [E][nparts][2][C] */
+int pmoe_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                       int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, float* part, int32_t nparts,
+                       int32_t dtype, void* stream);
+/* dgamma/dbeta [E][C] (written to the grad arena) + the two per-channel means used by bwd_apply */
+int pmoe_bn_bwd_finalize(const float* part, int32_t nparts, int64_t count, float* dgamma, float* dbeta, float* c1,
+                         float* c2, int32_t E, int32_t C, void* stream);
+/* dx = gamma*invstd * (g - c1 - xhat*c2); optionally also stores g (the masked grad) to gmask_out */
+int pmoe_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                      const float* scale, const float* c1, const float* c2, void* dx, void* gmask_out,
+                      int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream);
+
+/* ---- pooling (nn.MaxPool2d(3,2,1) and AdaptiveAvgPool2d(1) of the torchvision ResNet; the GAP of
+ * EfficientBlock, basics.py:70) */
+int pmoe_maxpool3s2_fwd(const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C,
+                        int32_t dtype, void* stream);
+int pmoe_maxpool3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                        int32_t dtype, void* stream);
+/* partial per-(image,channel) sums over HW: part [N][nparts][C] f32; optional second operand b:
+ * sums of a*b (used for the ECA scale gradient) */
+int pmoe_gap_partial(const void* a, const void* b, float* part, int32_t N, int64_t HW, int32_t C, int32_t nparts,
+                     int32_t b_shared_ipe, int32_t dtype, void* stream);
+/* mean over HW from partials, written as T into out[n*out_ld + out_coff + c] (feature concat slot) */
+int pmoe_gap_finish(const float* part, void* out, int32_t N, int32_t C, int32_t nparts, int64_t HW, int32_t out_ld,
+                    int32_t out_coff, int32_t dtype, void* stream);
+/* dx[n][hw][c] = g[n*g_ld + g_coff + c] / HW */
+int pmoe_gap_bwd(const void* g, void* dx, int32_t N, int64_t HW, int32_t C, int32_t g_ld, int32_t g_coff,
+                 int32_t dtype, void* stream);
+
+/* ---- ECA channel attention (EfficientBlock.forward, basics.py:69-76) -------------------------
+ * gate[n][c] = sigmoid(sum_j w[e][j] * mean_hw(x)[n][c + j - k/2]) from GAP partials (creal = number
+ * of real channels the conv1d sees, rest is padding) */
+int pmoe_eca_gate(const float* gap_part, int32_t nparts, int64_t HW, const void* const* w_ptrs, int32_t k,
+                  float* gate, float* gapmean, int32_t N, int32_t ipe, int32_t in_ipe, int32_t C, int32_t creal,
+                  void* stream);
+/* y[n] = x[n or n%ipe] * gate[n]   (x_shared_ipe>0: x holds ipe images shared by all experts) */
+int pmoe_eca_scale(const void* x, const float* gate, void* y, int32_t N, int64_t HW, int32_t C, int32_t x_shared_ipe,
+                   int32_t dtype, void* stream);
+/* from dgate-sums (sum_hw dy*x, partials) -> dpre, dgap [N][C] and dw [E][k] (written to the arena) */
+int pmoe_eca_bwd_small(const float* dot_part, int32_t nparts, const float* gate, const float* gapmean,
+                       const void* const* w_ptrs, int32_t k, float* dgap, float* dw, int32_t N, int32_t ipe,
+                       int32_t C, int32_t creal, void* stream);
+/* dx = dy*gate + dgap/HW */
+int pmoe_eca_bwd_apply(const void* dy, const float* gate, const float* dgap, void* dx, int32_t N, int64_t HW,
+                       int32_t C, int32_t dtype, void* stream);
+
+/* ---- layout: images f32 [B][Cin][H][W] (images.view(B,-1,H,W), moe.py:90-92) -> T [B][H][W][Cp] */
+int pmoe_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cp,
+                      int32_t dtype, void* stream);
+/* small f32 [B][K] host-side inputs (speed, command) -> T [B][Kp] zero padded */
+int pmoe_pad_rows(const float* src, void* dst, int32_t B, int32_t K, int32_t Kp, int32_t dtype, void* stream);
+
+/* ---- gate softmax + Gaussian-mixture head (moe.py:98-100,150-153) and moe_loss (trainer/loss.py:121-132)
+ * head [E*B][head_ld] T: cols 0..1 mean, 2..3 raw std, 4 raw alpha; spd [E*B][spd_ld] T col 0.
+ * probs [B][E], mean/std [B][E][2], speeds [B][E][1] f32.  alpha_relu: BaseExpert (1) vs BaseExpertAlt (0).
+ * One 64-lane wave handles 64/G samples, G = pow2 >= E lanes per sample, xor-shuffle reductions over E. */
+int pmoe_gate_mixture_fwd(const void* head, int32_t head_ld, const void* spd, int32_t spd_ld, float* probs,
+                          float* mean, float* std_, float* speeds, int32_t B, int32_t E, int32_t alpha_relu,
+                          int32_t dtype, void* stream);
+int pmoe_gate_mixture_bwd(const void* head, int32_t head_ld, const float* probs, const float* dprobs,
+                          const float* dmean, const float* dstd, const float* dspeeds, void* dhead, void* dspd,
+                          int32_t spd_ld, int32_t B, int32_t E, int32_t alpha_relu, int32_t dtype, void* stream);
+/* loss = c0 * mean_b(-logsumexp_e(log p + sum_d logN)) + c1 * mean((speeds-target)^2)/E; also the
+ * gradients of loss wrt probs/mean/std/speeds (scaled by gscale) for the backward pass. */
+int pmoe_moe_loss(const float* probs, const float* mean, const float* std_, const float* speeds,
+                  const float* actions, const float* target_speed, float c0, float c1, float* loss, float* loglik,
+                  float* dprobs, float* dmean, float* dstd, float* dspeeds, int32_t B, int32_t E, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

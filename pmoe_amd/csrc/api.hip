@@ -1,0 +1,81 @@
+// C-ABI entry points for the MFMA conv / grouped-GEMM kernels, plus version and error strings.
+#include "common.h"
+#include "kernels.h"
+
+static ConvArgs to_args(const pmoe_conv_desc* d) {
+    ConvArgs a;
+    a.in = d->in; a.w = d->w; a.out = d->out; a.res = d->res; a.bias = d->bias; a.stats = d->stats;
+    a.N = d->n; a.H = d->h; a.W = d->w_; a.Cin = d->cin;
+    a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout; a.CoutP = d->coutp;
+    a.in_ld = d->in_ld; a.in_coff = d->in_coff; a.out_ld = d->out_ld; a.out_coff = d->out_coff;
+    a.res_ld = d->res_ld; a.res_coff = d->res_coff;
+    a.ipe = d->ipe; a.in_shared = d->in_shared;
+    a.ks = d->ks; a.stride = d->stride; a.pad = d->pad; a.dilate = d->dilate;
+    a.act = d->act; a.res_mode = d->res ? d->res_mode : PMOE_RES_NONE;
+    a.drop_p = d->drop_p; a.seed = d->seed;
+    a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = 0;
+    return a;
+}
+
+static int check_conv(const pmoe_conv_desc* d) {
+    if (!d || !d->in || !d->w || !d->out) return PMOE_ERR_ARG;
+    if (d->n <= 0 || d->h <= 0 || d->w_ <= 0 || d->ho <= 0 || d->wo <= 0 || d->ipe <= 0) return PMOE_ERR_ARG;
+    const int ve = d->dtype == PMOE_DT_BF16 ? 8 : 4;
+    if (d->in_ld % ve || d->in_coff % ve || d->out_ld % ve || d->out_coff % ve) return PMOE_ERR_ARG;
+    if (d->res && (d->res_ld % ve || d->res_coff % ve)) return PMOE_ERR_ARG;
+    if (d->cout > d->coutp || d->in_coff + d->cin > d->in_ld || d->out_coff + d->cout > d->out_ld) return PMOE_ERR_ARG;
+    if (d->drop_p < 0.f || d->drop_p >= 1.f) return PMOE_ERR_ARG;
+    // geometry: forward conv / transposed (dilate) relation between (h,w) and (ho,wo)
+    if (!d->dilate) {
+        if (d->ho != (d->h + 2 * d->pad - d->ks) / d->stride + 1) return PMOE_ERR_ARG;
+        if (d->wo != (d->w_ + 2 * d->pad - d->ks) / d->stride + 1) return PMOE_ERR_ARG;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int pmoe_version(void) { return 100; }
+
+int pmoe_abi_sizeof(int which) {
+    return which == 0 ? (int)sizeof(pmoe_conv_desc) : which == 1 ? (int)sizeof(pmoe_wgrad_desc) : PMOE_ERR_ARG;
+}
+
+const char* pmoe_error_string(int code) {
+    if (code == 0) return "ok";
+    if (code == PMOE_ERR_ARG) return "pmoe: invalid argument (shape / alignment / pointer)";
+    if (code == PMOE_ERR_UNSUPPORTED) return "pmoe: unsupported configuration (no tile fits LDS)";
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "pmoe: unknown error";
+}
+
+int pmoe_conv2d_igemm(const pmoe_conv_desc* d, void* stream) {
+    int rc = check_conv(d);
+    if (rc) return rc;
+    return conv_igemm_launch(to_args(d), d->dtype, (hipStream_t)stream);
+}
+
+int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d) {
+    if (!d || d->ipe <= 0) return PMOE_ERR_ARG;
+    return conv_igemm_mblocks(to_args(d), d->dtype);
+}
+
+int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream) {
+    if (!d || !d->x || !d->dy || !d->dw_ws || d->ipe <= 0) return PMOE_ERR_ARG;
+    const int ve = d->dtype == PMOE_DT_BF16 ? 8 : 4;
+    if (d->x_ld % ve || d->x_coff % ve || d->dy_ld % ve || d->dy_coff % ve) return PMOE_ERR_ARG;
+    if (d->x_coff + d->cin > d->x_ld || d->dy_coff + d->cout > d->dy_ld) return PMOE_ERR_ARG;
+    if (d->ho != (d->h + 2 * d->pad - d->ks) / d->stride + 1) return PMOE_ERR_ARG;
+    if (d->wo != (d->w_ + 2 * d->pad - d->ks) / d->stride + 1) return PMOE_ERR_ARG;
+    WgradArgs a;
+    a.x = d->x; a.dy = d->dy; a.dw = d->dw_ws;
+    a.N = d->n; a.H = d->h; a.W = d->w_; a.Cin = d->cin; a.CinP = d->cinp;
+    a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout; a.CoutP = d->coutp;
+    a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.dy_ld = d->dy_ld; a.dy_coff = d->dy_coff;
+    a.ipe = d->ipe; a.x_shared = d->x_shared;
+    a.ks = d->ks; a.stride = d->stride; a.pad = d->pad;
+    a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = a.mb_per_wg = 0;
+    return conv_wgrad_launch(a, d->dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

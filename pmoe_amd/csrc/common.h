@@ -1,0 +1,82 @@
+// Shared device helpers for the PMoE gfx950 kernels.  CDNA4 only: wave = 64 lanes, MFMA 32x32,
+// 160 KiB LDS per CU.  No CUDA/compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#include "../../include/pmoe_hip.h"   // dtype / error / activation codes shared with the C ABI
+
+template <typename T> struct VecOf;                       // 16-byte vector of T
+template <> struct VecOf<bf16> { static constexpr int N = 8; };
+template <> struct VecOf<float> { static constexpr int N = 4; };
+
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+__device__ __forceinline__ float to_f32(float x) { return x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+
+// unpack a 16-byte vector of T into floats / pack floats back
+template <typename T> __device__ __forceinline__ void unpack16(const v4i& v, float* f);
+template <> __device__ __forceinline__ void unpack16<bf16>(const v4i& v, float* f) {
+    bf16x8 b = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)b[i];
+}
+template <> __device__ __forceinline__ void unpack16<float>(const v4i& v, float* f) {
+    f32x4 b = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = b[i];
+}
+template <typename T> __device__ __forceinline__ v4i pack16(const float* f);
+template <> __device__ __forceinline__ v4i pack16<bf16>(const float* f) {
+    bf16x8 b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = (bf16)f[i];
+    return __builtin_bit_cast(v4i, b);
+}
+template <> __device__ __forceinline__ v4i pack16<float>(const float* f) {
+    f32x4 b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = f[i];
+    return __builtin_bit_cast(v4i, b);
+}
+
+__device__ __forceinline__ v4i ldg16(const void* p) { return *reinterpret_cast<const v4i*>(p); }
+__device__ __forceinline__ void stg16(void* p, v4i v) { *reinterpret_cast<v4i*>(p) = v; }
+
+// 32-bit mix for the dropout mask (counter based: seed + element index -> uniform [0,1))
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// XCD-aware block remap (bijective for any grid size): blocks that are neighbours in the logical
+// tile order land on one XCD (= share its 4 MiB L2) under the observed round-robin dealing.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u, x = bid & 7u, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+static inline int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return ((1 << l) == v) ? l : -1;
+}
+
+#define HIP_RET(expr)                       \
+    do {                                    \
+        hipError_t _e = (expr);             \
+        if (_e != hipSuccess) return (int)_e; \
+    } while (0)

@@ -1,0 +1,70 @@
+// Halo-patch staging shared by the implicit-GEMM conv kernel and the weight-gradient kernel.
+#pragma once
+#include "common.h"
+
+// LDS chunk swizzles (16-byte chunk index j of a pixel row is stored at j ^ swz(pixel)):
+//  mode 0 (ds_read_b128 operand reads, 32 different pixels per half-wave): conflict free when a
+//         16-lane group's pixels are distinct mod 16.
+//  mode 1 (ds_read_b64_tr_b16 reads of 4 consecutive pixels x 64 B): toggles the 64-byte half of
+//         the row with bit 1 of the pixel so the 4 rows of a transposed block hit 4 bank ranges.
+template <int LOG_RB, int MODE> __device__ __forceinline__ int swz_chunk(int x) {
+    if (MODE == 0) return (x >> (8 - LOG_RB)) & ((1 << (LOG_RB - 4)) - 1);
+    return ((x >> 1) & 1) << (LOG_RB - 5);
+}
+
+struct PatchGeom {
+    int n0, n_end, e_first_img;   // first image of the tile, one-past-last image of the expert, e*ipe
+    int Y0, X0;                   // source coordinate of patch pixel (0,0)
+    int PH, PW, NPIX;
+    int H, W, ld, coff, cmax;      // cmax: channels [0,cmax) past coff exist, the rest reads as 0
+    int dilate, shared;
+};
+
+// Stage channels [c0, c0 + RB/sizeof(T)) of the halo patch into LDS.  thread -> (16-byte chunk,
+// pixel slot); the pixel -> (image,row,col) decode advances incrementally (no divisions in the loop).
+template <typename T, int LOG_RB, int NTHR, int MODE>
+__device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const PatchGeom& g, int c0, int tid) {
+    constexpr int RB = 1 << LOG_RB, CPR = RB / 16, LOG_CPR = LOG_RB - 4;
+    constexpr int PSTEP = NTHR / CPR;
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int pj = tid & (CPR - 1);
+    int pp = tid >> LOG_CPR;
+    int ix = pp % g.PW;
+    const int row = pp / g.PW;
+    int iy = row % g.PH, pn = row / g.PH;
+    while (pp < g.NPIX) {
+        v4i v[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            dst[u] = -1;
+            if (pp < g.NPIX) {
+                const int n = g.n0 + pn;
+                int Y = g.Y0 + iy, X = g.X0 + ix;
+                bool ok = n < g.n_end && (c0 + pj * VE) < g.cmax;
+                if (g.dilate) {
+                    ok = ok && Y >= 0 && X >= 0 && !((Y | X) & 1);
+                    Y >>= 1; X >>= 1;
+                    ok = ok && Y < g.H && X < g.W;
+                } else {
+                    ok = ok && (unsigned)Y < (unsigned)g.H && (unsigned)X < (unsigned)g.W;
+                }
+                v[u] = v4i{0, 0, 0, 0};
+                if (ok) {
+                    const int nin = g.shared ? (n - g.e_first_img) : n;
+                    v[u] = ldg16(in + (((size_t)nin * g.H + Y) * g.W + X) * g.ld + g.coff + c0 + pj * VE);
+                }
+                dst[u] = pp * RB + ((pj ^ swz_chunk<LOG_RB, MODE>(pp)) << 4);
+                pp += PSTEP;
+                ix += PSTEP;
+                while (ix >= g.PW) {
+                    ix -= g.PW;
+                    if (++iy == g.PH) { iy = 0; ++pn; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<v4i*>(patch + dst[u]) = v[u];
+    }
+}

@@ -1,0 +1,346 @@
+// Grouped (per-expert) NHWC convolution as an implicit GEMM on MFMA, gfx950.
+//
+// One workgroup owns an output patch of TN x TH x TW pixels (BM = 64*WM of them) x BN = 64*WN
+// output channels.  Per input-channel chunk the (TH-1)*S+KS by (TW-1)*S+KS input halo patch is
+// staged ONCE in LDS (XOR-swizzled 16-byte chunks, zero filled outside the image) and every
+// filter tap reads its MFMA operand from it at a shifted pixel address, so an input byte crosses
+// L2->LDS once per chunk instead of once per tap.  Weight tiles [BN][chunk] stream per (chunk,tap)
+// through a 2-deep LDS ring, prefetched into registers under the MFMAs of the previous tap.
+// MFMA roles: A = weights (rows = cout), B = pixels (cols = pixel); D[cout][pixel] is staged
+// through LDS in f32 and written back as whole 16-byte channel vectors per pixel (coalesced),
+// where bias / activation / residual / dropout / per-channel BatchNorm partial sums are fused.
+//
+// The same kernel serves: forward conv 3x3/1x1 stride 1/2, stride-1 data-gradient (flipped,
+// transposed weights), stride-2 data-gradient (`dilate`: the source is read as if zero-upsampled
+// by 2, i.e. a transposed conv), and the expert MLP heads (1x1 conv on 1x1 images = grouped GEMM
+// over experts with TN samples per tile).
+#include "conv_common.h"
+#include "kernels.h"
+
+template <int LOG_RB> __device__ __forceinline__ int swz(int x) { return swz_chunk<LOG_RB, 0>(x); }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ void run(const v4i& a, const v4i& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // 16 bytes = 4 f32 per lane-half: MFMA j consumes element j of both operands (k = 4h + j).
+    static __device__ __forceinline__ void run(const v4i& a, const v4i& b, f32x16& c) {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], c, 0, 0, 0);
+    }
+};
+
+template <typename T, int LOG_RB, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs a) {
+    constexpr int RB = 1 << LOG_RB, CPR = RB / 16, LOG_CPR = LOG_RB - 4;
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int VE = 16 / (int)sizeof(T);
+    constexpr int CK = RB / (int)sizeof(T);
+    constexpr int KSUB = RB / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const unsigned mb = xcd_remap(blockIdx.x, gridDim.x);
+    int t = (int)mb;
+    const int px = t % a.tiles_x; t /= a.tiles_x;
+    const int py = t % a.tiles_y; t /= a.tiles_y;
+    const int ng = t % a.n_groups;
+    const int e = t / a.n_groups;
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int S = a.stride, KS = a.ks, TAPS = KS * KS;
+    const int PW = (TW - 1) * S + KS, PH = (TH - 1) * S + KS;
+    const int NPIX = a.TN * PH * PW;
+    const int n0 = e * a.ipe + ng * a.TN, n_end = (e + 1) * a.ipe;
+    const int oy0 = py * TH, ox0 = px * TW;
+    const int Y0 = oy0 * S - a.pad, X0 = ox0 * S - a.pad;
+    const int cout0 = blockIdx.y * BN;
+
+    char* patch = smem;
+    char* wbuf = smem + ((NPIX * RB + 255) & ~255);
+
+    int ppb[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int p = wm * 64 + mt * 32 + l31;
+        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+        ppb[mt] = (pn * PH + my * S) * PW + mx * S;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    const T* wbase = (const T*)a.w + ((size_t)e * a.CoutP + cout0) * TAPS * a.Cin;
+    constexpr int WV = (BN * CPR + NTHR - 1) / NTHR;
+    v4i wreg[WV];
+    auto w_issue = [&](int c0, int tap) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * NTHR;
+            if (v < BN * CPR) {
+                const int n = v >> LOG_CPR, j = v & (CPR - 1);
+                wreg[i] = ldg16(wbase + ((size_t)n * TAPS + tap) * a.Cin + c0 + j * VE);
+            }
+        }
+    };
+    auto w_commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * NTHR;
+            if (v < BN * CPR) {
+                const int n = v >> LOG_CPR, j = v & (CPR - 1);
+                *reinterpret_cast<v4i*>(wbuf + buf * (BN * RB) + n * RB + ((j ^ swz<LOG_RB>(n)) << 4)) = wreg[i];
+            }
+        }
+    };
+
+    PatchGeom geo;
+    geo.n0 = n0; geo.n_end = n_end; geo.e_first_img = e * a.ipe;
+    geo.Y0 = Y0; geo.X0 = X0; geo.PH = PH; geo.PW = PW; geo.NPIX = NPIX;
+    geo.H = a.H; geo.W = a.W; geo.ld = a.in_ld; geo.coff = a.in_coff; geo.cmax = a.Cin;
+    geo.dilate = a.dilate; geo.shared = a.in_shared;
+    const T* in = (const T*)a.in;
+    auto load_patch = [&](int c0) { load_halo_patch<T, LOG_RB, NTHR, 0>(patch, in, geo, c0, tid); };
+
+    const int nchunks = a.Cin / CK;
+    int cur = 0;
+    w_issue(0, 0);
+    w_commit(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK;
+        load_patch(c0);
+        __syncthreads();
+        for (int r = 0; r < KS; ++r) {
+            for (int q = 0; q < KS; ++q) {
+                const int tap = r * KS + q;
+                const bool last = (ch == nchunks - 1) && (tap == TAPS - 1);
+                int ntap = tap + 1, nc0 = c0;
+                if (ntap == TAPS) { ntap = 0; nc0 += CK; }
+                if (!last) w_issue(nc0, ntap);
+                const char* wb = wbuf + cur * (BN * RB);
+                const int tapoff = r * PW + q;
+                int pp[2], fp[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    pp[mt] = ppb[mt] + tapoff;
+                    fp[mt] = swz<LOG_RB>(pp[mt]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KSUB; ++ks) {
+                    v4i af[2], bfr[2];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int row = wn * 64 + nt * 32 + l31;
+                        af[nt] = *reinterpret_cast<const v4i*>(wb + row * RB + (((ks * 2 + h) ^ swz<LOG_RB>(row)) << 4));
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        bfr[mt] = *reinterpret_cast<const v4i*>(patch + pp[mt] * RB + (((ks * 2 + h) ^ fp[mt]) << 4));
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) Mma<T>::run(af[nt], bfr[mt], acc[nt][mt]);
+                }
+                if (!last) w_commit(cur ^ 1);
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    }
+
+    // ---- epilogue: D[cout][pixel] -> LDS f32 [BM][BN] (16B units XOR-swizzled by pixel) ----
+    constexpr int UPR = BN / 4;
+    float* stg = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int p = wm * 64 + mt * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u = wn * 16 + nt * 8 + 2 * g + h;
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[nt][mt][4 * g + i];
+                *reinterpret_cast<f32x4*>(stg + p * BN + ((u ^ (p & (UPR - 1))) << 2)) = v;
+            }
+        }
+    __syncthreads();
+
+    constexpr int CPO = BN / VE;
+    constexpr int PROWS = NTHR / CPO;
+    const int cc = tid % CPO, pr = tid / CPO;
+    const int cout = cout0 + cc * VE;
+    const bool cvalid = cout < a.Cout;
+    float bias[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) bias[i] = (a.bias && cvalid) ? a.bias[(size_t)e * a.CoutP + cout + i] : 0.f;
+    float s1[VE], s2[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) s1[i] = s2[i] = 0.f;
+    const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    T* out = (T*)a.out;
+    const T* res = (const T*)a.res;
+    for (int p = pr; p < BM; p += PROWS) {
+        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+        const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
+        const bool ok = cvalid && n < n_end && oy < a.Ho && ox < a.Wo;
+        float v[VE];
+#pragma unroll
+        for (int k = 0; k < VE / 4; ++k) {
+            const int u = cc * (VE / 4) + k;
+            const f32x4 tt = *reinterpret_cast<const f32x4*>(stg + p * BN + ((u ^ (p & (UPR - 1))) << 2));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * k + i] = tt[i];
+        }
+        if (ok) {
+            const size_t opix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+            for (int i = 0; i < VE; ++i) v[i] += bias[i];
+            if (a.res_mode) {
+                float rv[VE];
+                unpack16<T>(ldg16(res + opix * a.res_ld + a.res_coff + cout), rv);
+                if (a.res_mode == PMOE_RES_ADD) {
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) v[i] += rv[i];
+                } else if (a.res_mode == PMOE_RES_DRELU) {          // saved output y: relu'(y) (with dropout scale)
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) v[i] = rv[i] > 0.f ? v[i] * keep_scale : 0.f;
+                } else if (a.res_mode == PMOE_RES_DELU) {           // saved output y = elu(z) * mask * keep_scale
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) {
+                        const float y = rv[i] * (1.f / keep_scale);
+                        const float d = y > 0.f ? 1.f : y + 1.f;
+                        v[i] = (a.drop_p > 0.f && rv[i] == 0.f) ? 0.f : v[i] * d * keep_scale;
+                    }
+                }
+            }
+            if (a.act == PMOE_ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] = fmaxf(v[i], 0.f);
+            } else if (a.act == PMOE_ACT_ELU) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] = v[i] > 0.f ? v[i] : expm1f(v[i]);
+            }
+            if (a.drop_p > 0.f && a.res_mode < PMOE_RES_DRELU) {
+                const unsigned long long base = (unsigned long long)opix * (unsigned)a.Cout + cout;
+#pragma unroll
+                for (int i = 0; i < VE; ++i)
+                    v[i] = hash_uniform(a.seed, base + i) >= a.drop_p ? v[i] * keep_scale : 0.f;
+            }
+            const v4i pk = pack16<T>(v);
+            if (a.stats) {
+                float rr[VE];
+                unpack16<T>(pk, rr);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
+            }
+            stg16(out + opix * a.out_ld + a.out_coff + cout, pk);
+        }
+    }
+    if (a.stats) {
+        // BatchNorm partial sums of this tile: lanes sharing a channel vector combine by xor-shuffle,
+        // waves through LDS; one [2][CoutP] row per m-block, reduced later in fixed order.
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);              // [waves][2][BN]
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+#pragma unroll
+            for (int off = CPO; off < 64; off <<= 1) {
+                s1[i] += __shfl_xor(s1[i], off);
+                s2[i] += __shfl_xor(s2[i], off);
+            }
+        }
+        if (CPO >= 64 || lane < CPO) {
+            // CPO > 64 cannot occur (BN<=128, VE>=4 -> CPO<=32)
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                red[(wave * 2 + 0) * BN + cc * VE + i] = s1[i];
+                red[(wave * 2 + 1) * BN + cc * VE + i] = s2[i];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM * WN; ++w) s += red[(w * 2 + which) * BN + c];
+            if (cout0 + c < a.CoutP) a.stats[((size_t)mb * 2 + which) * a.CoutP + cout0 + c] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int LOG_RB, int WM, int WN>
+static int launch_cfg(const ConvArgs& a, int mblocks, size_t smem, hipStream_t st) {
+    auto k = conv_igemm_kernel<T, LOG_RB, WM, WN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    dim3 grid(mblocks, a.CoutP / (WN * 64), 1), block(WM * WN * 64, 1, 1);
+    hipLaunchKernelGGL(k, grid, block, smem, st, a);
+    return (int)hipGetLastError();
+}
+
+template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* out_mblocks) {
+    const int esz = (int)sizeof(T);
+    if (a.Cin <= 0 || a.CoutP % 64 || a.Cout % (16 / esz) || a.Cin % (32 / esz)) return PMOE_ERR_ARG;
+    if ((a.ks != 1 && a.ks != 3) || (a.stride != 1 && a.stride != 2) || (a.dilate && a.stride != 1)) return PMOE_ERR_ARG;
+    if (a.N % a.ipe) return PMOE_ERR_ARG;
+    const int E = a.N / a.ipe;
+    const bool wide = (a.CoutP % 128 == 0);
+    const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+    auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    // candidate chunk widths (bytes per pixel row in LDS), widest first
+    for (int log_rb = 7; log_rb >= 5; --log_rb) {
+        const int rb = 1 << log_rb, ck = rb / esz;
+        if (a.Cin % ck) continue;
+        int lTW = p2(a.Wo); if (lTW > 5) lTW = 5;
+        int lBM = p2(BM);
+        int lTH = p2(a.Ho); if (lTH > lBM - lTW) lTH = lBM - lTW;
+        const int TN = BM >> (lTW + lTH);
+        const int TW = 1 << lTW, TH = 1 << lTH;
+        const int PW = (TW - 1) * a.stride + a.ks, PH = (TH - 1) * a.stride + a.ks;
+        size_t smem = (((size_t)TN * PH * PW * rb + 255) & ~(size_t)255) + 2 * (size_t)BN * rb;
+        const size_t stg = (size_t)BM * BN * 4;
+        if (smem < stg) smem = stg;
+        if (smem > 150 * 1024) continue;
+        a.lTW = lTW; a.lTH = lTH; a.TN = TN;
+        a.n_groups = (a.ipe + TN - 1) / TN;
+        a.tiles_y = (a.Ho + TH - 1) / TH;
+        a.tiles_x = (a.Wo + TW - 1) / TW;
+        const int mblocks = E * a.n_groups * a.tiles_y * a.tiles_x;
+        if (out_mblocks) { *out_mblocks = mblocks; return 0; }
+        if (log_rb == 7) return wide ? launch_cfg<T, 7, 2, 2>(a, mblocks, smem, st) : launch_cfg<T, 7, 4, 1>(a, mblocks, smem, st);
+        if (log_rb == 6) return wide ? launch_cfg<T, 6, 2, 2>(a, mblocks, smem, st) : launch_cfg<T, 6, 4, 1>(a, mblocks, smem, st);
+        return wide ? launch_cfg<T, 5, 2, 2>(a, mblocks, smem, st) : launch_cfg<T, 5, 4, 1>(a, mblocks, smem, st);
+    }
+    return PMOE_ERR_UNSUPPORTED;
+}
+
+int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
+    if (dtype == PMOE_DT_BF16) return launch_dtype<bf16>(a, st, nullptr);
+    if (dtype == PMOE_DT_F32) return launch_dtype<float>(a, st, nullptr);
+    return PMOE_ERR_ARG;
+}
+
+int conv_igemm_mblocks(const ConvArgs& a, int dtype) {
+    int mb = 0;
+    int rc = (dtype == PMOE_DT_BF16) ? launch_dtype<bf16>(a, nullptr, &mb) : launch_dtype<float>(a, nullptr, &mb);
+    return rc ? rc : mb;
+}

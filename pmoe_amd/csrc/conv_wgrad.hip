@@ -1,0 +1,222 @@
+// Grouped (per-expert) convolution weight gradient on MFMA, gfx950.
+//
+//   dW[e][tap][cout][cin] += sum over the expert's output pixels of dY[pixel][cout] * X[pixel shifted by tap][cin]
+//
+// The reduction (GEMM K) dimension is the pixel index, which is the SLOW axis of both NHWC
+// operands.  A workgroup stages a dY tile [pixels][CK couts] and the matching X halo patch
+// [pixels+halo][CK cins] in LDS exactly as the forward kernel does and reads both MFMA operands
+// TRANSPOSED: bf16 with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group), f32 with
+// scalar ds_read_b32 (the f32 MFMA takes one element per lane).  One dY fragment is reused for all
+// ks*ks taps, so each tap costs one transposed X read per MFMA.  Every wave keeps its
+// [32 cout][32 cin] x taps accumulators in registers across ALL the m-blocks the workgroup walks
+// (K-split over gridDim.x), and flushes once with f32 atomics whose lanes run along cin
+// (2 x 128-byte segments per wave-instruction: the full-rate shape).
+#include "conv_common.h"
+#include "kernels.h"
+
+template <typename T> struct WgradCfg;
+template <> struct WgradCfg<bf16> { static constexpr int WCO = 2, WCI = 2, WK = 1; };   // 64 x 64 channels / WG
+template <> struct WgradCfg<float> { static constexpr int WCO = 1, WCI = 1, WK = 4; };  // 32 x 32, pixels split 4 ways
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+}
+
+template <typename T, int TAPS>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int LOG_RB = 7, RB = 128;
+    constexpr int VE = 16 / (int)sizeof(T);
+    constexpr int CKW = RB / (int)sizeof(T);            // channels per operand tile: 64 bf16 / 32 f32
+    constexpr int WCI = WgradCfg<T>::WCI, WK = WgradCfg<T>::WK;
+    constexpr int KS = TAPS == 9 ? 3 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int co_sub = (WK == 1) ? wave / WCI : 0;
+    const int ci_sub = (WK == 1) ? wave % WCI : 0;
+    const int k_sub = (WK == 1) ? 0 : wave;
+
+    const int e = blockIdx.z;
+    const int n_ci_blk = (a.Cin + CKW - 1) / CKW;
+    const int cob = blockIdx.y / n_ci_blk, cib = blockIdx.y % n_ci_blk;
+    const int co0 = cob * CKW, ci0 = cib * CKW;
+
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int S = a.stride;
+    const int PW = (TW - 1) * S + KS, PH = (TH - 1) * S + KS;
+    const int NPIX = a.TN * PH * PW;
+    const int BMP = a.TN << (lTW + lTH);
+    const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
+
+    char* dyt = smem;                                   // [BMP][128 B]
+    char* patch = smem + BMP * RB;                      // [NPIX][128 B]
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+
+    const T* x = (const T*)a.x;
+    const T* dy = (const T*)a.dy;
+    const int mb_begin = blockIdx.x * a.mb_per_wg;
+    int mb_end = mb_begin + a.mb_per_wg;
+    if (mb_end > mbpe) mb_end = mbpe;
+
+    for (int mbi = mb_begin; mbi < mb_end; ++mbi) {
+        int t = mbi;
+        const int px = t % a.tiles_x; t /= a.tiles_x;
+        const int py = t % a.tiles_y; t /= a.tiles_y;
+        const int ng = t;
+        const int n0 = e * a.ipe + ng * a.TN, n_end = (e + 1) * a.ipe;
+        const int oy0 = py * TH, ox0 = px * TW;
+
+        __syncthreads();                                // previous tile's operand reads are done
+        // dY tile: thread -> (chunk j, pixel slot), 32 pixels per sweep
+        {
+            const int j = tid & 7;
+            for (int p = tid >> 3; p < BMP; p += 32) {
+                const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+                const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
+                v4i v = v4i{0, 0, 0, 0};
+                if (n < n_end && oy < a.Ho && ox < a.Wo && co0 + j * VE < a.Cout)
+                    v = ldg16(dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.dy_ld + a.dy_coff + co0 + j * VE);
+                *reinterpret_cast<v4i*>(dyt + p * RB + ((j ^ swz_chunk<LOG_RB, 1>(p)) << 4)) = v;
+            }
+        }
+        PatchGeom geo;
+        geo.n0 = n0; geo.n_end = n_end; geo.e_first_img = e * a.ipe;
+        geo.Y0 = oy0 * S - a.pad; geo.X0 = ox0 * S - a.pad; geo.PH = PH; geo.PW = PW; geo.NPIX = NPIX;
+        geo.H = a.H; geo.W = a.W; geo.ld = a.x_ld; geo.coff = a.x_coff; geo.cmax = a.Cin;
+        geo.dilate = 0; geo.shared = a.x_shared;
+        load_halo_patch<T, LOG_RB, 256, 1>(patch, x, geo, ci0, tid);
+        __syncthreads();
+
+        for (int kb = k_sub; kb < (BMP >> 4); kb += WK) {
+            const int p0 = kb << 4;
+            if constexpr (sizeof(T) == 2) {
+                // transposed fragments: lane (g = lane>>4: channel block g&1, k half g>>1;
+                // q = (lane>>2)&3: pixel row it addresses; pc = lane&3: 4-channel column group)
+                const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+                const int cblk = 16 * (g & 1) + 4 * pc;              // channel inside the wave's 32
+                int pA[2], ppB[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int p = p0 + 8 * (g >> 1) + 4 * tt + q;
+                    pA[tt] = p;
+                    const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+                    ppB[tt] = (pn * PH + my * S) * PW + mx * S;
+                }
+                const int ca = co_sub * 32 + cblk, cb = ci_sub * 32 + cblk;
+                bf16x8 fa;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const s16x4 r = tr_read(dyt + pA[tt] * RB + (((ca >> 3) ^ swz_chunk<LOG_RB, 1>(pA[tt])) << 4) + ((ca & 7) << 1));
+                    const bf16x4 rb = __builtin_bit_cast(bf16x4, r);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[4 * tt + i] = rb[i];
+                }
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int tapoff = (tap / KS) * PW + (tap % KS);
+                    bf16x8 fb;
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int pp = ppB[tt] + tapoff;
+                        const s16x4 r = tr_read(patch + pp * RB + (((cb >> 3) ^ swz_chunk<LOG_RB, 1>(pp)) << 4) + ((cb & 7) << 1));
+                        const bf16x4 rb = __builtin_bit_cast(bf16x4, r);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fb[4 * tt + i] = rb[i];
+                    }
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                }
+            } else {
+                // f32: MFMA 32x32x2, lane holds A[i = l31][k = h]; 8 MFMAs cover 16 pixels
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int p = p0 + 2 * m + h;
+                    const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+                    const int ppb = (pn * PH + my * S) * PW + mx * S;
+                    const float av = *reinterpret_cast<const float*>(
+                        dyt + p * RB + (((l31 >> 2) ^ swz_chunk<LOG_RB, 1>(p)) << 4) + ((l31 & 3) << 2));
+#pragma unroll
+                    for (int tap = 0; tap < TAPS; ++tap) {
+                        const int pp = ppb + (tap / KS) * PW + (tap % KS);
+                        const float bv = *reinterpret_cast<const float*>(
+                            patch + pp * RB + (((l31 >> 2) ^ swz_chunk<LOG_RB, 1>(pp)) << 4) + ((l31 & 3) << 2));
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // flush: D[row = cout][col = cin]; lanes run along cin -> contiguous 128-byte atomic segments
+    const int cin = ci0 + ci_sub * 32 + l31;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        float* base = a.dw + (((size_t)e * TAPS + tap) * a.CoutP) * a.CinP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cout = co0 + co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            atomicAdd(base + (size_t)cout * a.CinP + cin, acc[tap][r]);
+        }
+    }
+}
+
+template <typename T, int TAPS> static int launch_wg(const WgradArgs& a, int E, size_t smem, hipStream_t st) {
+    auto k = conv_wgrad_kernel<T, TAPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    constexpr int CKW = 128 / (int)sizeof(T);
+    const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
+    dim3 grid((mbpe + a.mb_per_wg - 1) / a.mb_per_wg, ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW), E), block(256, 1, 1);
+    hipLaunchKernelGGL(k, grid, block, smem, st, a);
+    return (int)hipGetLastError();
+}
+
+template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st) {
+    constexpr int CKW = 128 / (int)sizeof(T);
+    constexpr int VEh = 16 / (int)sizeof(T);
+    if (a.Cin % VEh || a.Cout % VEh || a.CinP % CKW || a.CoutP % CKW || a.CinP < a.Cin || a.CoutP < a.Cout) return PMOE_ERR_ARG;
+    if ((a.ks != 1 && a.ks != 3) || (a.stride != 1 && a.stride != 2) || a.N % a.ipe) return PMOE_ERR_ARG;
+    const int E = a.N / a.ipe;
+    auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    for (int lBM = 8; lBM >= 6; --lBM) {
+        int lTW = p2(a.Wo); if (lTW > 5) lTW = 5;
+        int lTH = p2(a.Ho); if (lTH > lBM - lTW) lTH = lBM - lTW;
+        if (lTW > lBM) { lTW = lBM; lTH = 0; }
+        const int BMP = 1 << lBM;
+        const int TN = BMP >> (lTW + lTH);
+        const int TW = 1 << lTW, TH = 1 << lTH;
+        const int PW = (TW - 1) * a.stride + a.ks, PH = (TH - 1) * a.stride + a.ks;
+        const size_t smem = (size_t)BMP * 128 + (size_t)TN * PH * PW * 128;
+        if (smem > 150 * 1024) continue;
+        a.lTW = lTW; a.lTH = lTH; a.TN = TN;
+        a.n_groups = (a.ipe + TN - 1) / TN;
+        a.tiles_y = (a.Ho + TH - 1) / TH;
+        a.tiles_x = (a.Wo + TW - 1) / TW;
+        const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
+        // K-split: aim for ~4 workgroups per CU over the whole launch
+        const int pairs = ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW) * E;
+        int want = (1024 + pairs - 1) / pairs;
+        if (want < 1) want = 1;
+        if (want > mbpe) want = mbpe;
+        a.mb_per_wg = (mbpe + want - 1) / want;
+        return a.ks == 3 ? launch_wg<T, 9>(a, E, smem, st) : launch_wg<T, 1>(a, E, smem, st);
+    }
+    return PMOE_ERR_UNSUPPORTED;
+}
+
+int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
+    if (dtype == PMOE_DT_BF16) return wgrad_dtype<bf16>(a, st);
+    if (dtype == PMOE_DT_F32) return wgrad_dtype<float>(a, st);
+    return PMOE_ERR_ARG;
+}

@@ -1,0 +1,294 @@
+// Weight (re)packing between the reference's per-expert f32 parameter tensors and the grouped
+// kernel layouts, the gate-softmax / Gaussian-mixture head and the fused moe_loss.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// src[e]: f32 [cout][cin][taps].  fwd: T [E][coutp][taps][cinp].  dgrd: T [E][cinp2][taps][coutp2]
+// with dgrd[e][ci][taps-1-t][co] = src[e][co][ci][t]  (the flipped, transposed operand of dgrad).
+template <typename T>
+__global__ void __launch_bounds__(256) pack_w_kernel(const float* const* __restrict__ src, T* __restrict__ fwd,
+                                                    T* __restrict__ dgrd, int cout, int cin, int taps, int coutp,
+                                                    int cinp, int cinp2, int coutp2) {
+    const int e = blockIdx.y;
+    const float* s = src[e];
+    const long long nf = fwd ? (long long)coutp * taps * cinp : 0;
+    const long long nd = dgrd ? (long long)cinp2 * taps * coutp2 : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nf + nd; i += (long long)gridDim.x * 256) {
+        if (i < nf) {
+            const int ci = (int)(i % cinp);
+            long long t = i / cinp;
+            const int tp = (int)(t % taps);
+            const int co = (int)(t / taps);
+            const float v = (co < cout && ci < cin) ? s[((size_t)co * cin + ci) * taps + tp] : 0.f;
+            fwd[(size_t)e * nf + i] = from_f32<T>(v);
+        } else {
+            const long long k = i - nf;
+            const int co = (int)(k % coutp2);
+            long long t = k / coutp2;
+            const int tp = (int)(t % taps);
+            const int ci = (int)(t / taps);
+            const float v = (co < cout && ci < cin) ? s[((size_t)co * cin + ci) * taps + (taps - 1 - tp)] : 0.f;
+            dgrd[(size_t)e * nd + k] = from_f32<T>(v);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ g, int cout,
+                                                          int cin, int taps, int coutp, int cinp) {
+    const int e = blockIdx.y;
+    const long long n = (long long)cout * cin * taps;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int tp = (int)(i % taps);
+        long long t = i / taps;
+        const int ci = (int)(t % cin);
+        const int co = (int)(t / cin);
+        g[(size_t)e * n + i] = ws[(((size_t)e * taps + tp) * coutp + co) * cinp + ci];
+    }
+}
+
+__global__ void __launch_bounds__(256) pack_bias_kernel(const float* const* __restrict__ src, float* __restrict__ dst,
+                                                       int cout, int coutp) {
+    const int e = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < coutp; i += gridDim.x * 256)
+        dst[e * coutp + i] = i < cout ? src[e][i] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gate softmax + mixture parameters.  G = pow2 >= E lanes per sample; a wave covers 64/G samples and
+// reduces over the expert axis with xor-shuffles (no LDS, no atomics).
+template <typename T>
+__global__ void __launch_bounds__(256) gate_fwd_kernel(const T* __restrict__ head, int head_ld, const T* __restrict__ spd,
+                                                      int spd_ld, float* __restrict__ probs, float* __restrict__ mean,
+                                                      float* __restrict__ sd, float* __restrict__ speeds, int B, int E,
+                                                      int G, int alpha_relu) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int b = gid / G, e = gid % G;
+    const bool live = b < B && e < E;
+    float hv[5] = {0, 0, 0, 0, 0};
+    float sp = 0.f;
+    if (live) {
+        const T* row = head + ((size_t)e * B + b) * head_ld;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) hv[i] = to_f32(row[i]);
+        sp = to_f32(spd[((size_t)e * B + b) * spd_ld]);
+    }
+    float a = alpha_relu ? fmaxf(hv[4], 0.f) : hv[4];
+    if (!live) a = -INFINITY;
+    float m = a;
+    for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const float ex = live ? __expf(a - m) : 0.f;
+    float s = ex;
+    for (int off = 1; off < G; off <<= 1) s += __shfl_xor(s, off);
+    if (live) {
+        const size_t o = (size_t)b * E + e;
+        probs[o] = ex / s;
+        mean[o * 2 + 0] = hv[0];
+        mean[o * 2 + 1] = hv[1];
+        sd[o * 2 + 0] = (hv[2] > 0.f ? hv[2] : expm1f(hv[2])) + 1.f;
+        sd[o * 2 + 1] = (hv[3] > 0.f ? hv[3] : expm1f(hv[3])) + 1.f;
+        speeds[o] = sp;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gate_bwd_kernel(const T* __restrict__ head, int head_ld,
+                                                      const float* __restrict__ probs, const float* __restrict__ dprobs,
+                                                      const float* __restrict__ dmean, const float* __restrict__ dstd,
+                                                      const float* __restrict__ dspeeds, T* __restrict__ dhead,
+                                                      T* __restrict__ dspd, int spd_ld, int B, int E, int G,
+                                                      int alpha_relu) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int b = gid / G, e = gid % G;
+    const bool live = b < B && e < E;
+    float p = 0.f, dp = 0.f;
+    if (live) {
+        p = probs[(size_t)b * E + e];
+        dp = dprobs ? dprobs[(size_t)b * E + e] : 0.f;
+    }
+    float dot = p * dp;
+    for (int off = 1; off < G; off <<= 1) dot += __shfl_xor(dot, off);
+    if (live) {
+        const size_t o = (size_t)b * E + e;
+        const T* row = head + ((size_t)e * B + b) * head_ld;
+        const float r2 = to_f32(row[2]), r3 = to_f32(row[3]), r4 = to_f32(row[4]);
+        float da = p * (dp - dot);
+        if (alpha_relu && !(r4 > 0.f)) da = 0.f;
+        T* drow = dhead + ((size_t)e * B + b) * head_ld;
+        drow[0] = from_f32<T>(dmean ? dmean[o * 2 + 0] : 0.f);
+        drow[1] = from_f32<T>(dmean ? dmean[o * 2 + 1] : 0.f);
+        drow[2] = from_f32<T>(dstd ? dstd[o * 2 + 0] * (r2 > 0.f ? 1.f : __expf(r2)) : 0.f);
+        drow[3] = from_f32<T>(dstd ? dstd[o * 2 + 1] * (r3 > 0.f ? 1.f : __expf(r3)) : 0.f);
+        drow[4] = from_f32<T>(da);
+        for (int i = 5; i < head_ld; ++i) drow[i] = from_f32<T>(0.f);
+        T* srow = dspd + ((size_t)e * B + b) * spd_ld;
+        srow[0] = from_f32<T>(dspeeds ? dspeeds[o] : 0.f);
+        for (int i = 1; i < spd_ld; ++i) srow[i] = from_f32<T>(0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// moe_loss (trainer/loss.py:121-132) with MixtureSameFamily.log_prob written out:
+//   ll_b = logsumexp_e( log_softmax(log clamp(p/sum p))_e + sum_d logN(a_d; mu_ed, sigma_ed) )
+//   loss = c0 * (-mean_b ll_b) + c1 * mean_{b,e}((speed_be - target_b)^2) / E
+// One workgroup; lanes over (sample, expert) as in the gate kernel; gradients are produced in the
+// same pass (they are tiny) so backward is a scale by the incoming grad.
+__global__ void __launch_bounds__(256) moe_loss_kernel(const float* __restrict__ probs, const float* __restrict__ mean,
+                                                      const float* __restrict__ sd, const float* __restrict__ speeds,
+                                                      const float* __restrict__ act, const float* __restrict__ tgt,
+                                                      float c0, float c1, float* __restrict__ loss,
+                                                      float* __restrict__ loglik, float* __restrict__ dprobs,
+                                                      float* __restrict__ dmean, float* __restrict__ dstd,
+                                                      float* __restrict__ dspeeds, int B, int E, int G) {
+    const float EPS = 1.1920929e-07f, HALF_LOG_2PI = 0.9189385332046727f;
+    const int e = threadIdx.x % G;
+    float nll_acc = 0.f, mse_acc = 0.f;
+    const int spb = 256 / G;
+    for (int b0 = 0; b0 < B; b0 += spb) {
+        const int b = b0 + threadIdx.x / G;
+        const bool live = b < B && e < E;
+        float p = 0.f, comp = 0.f, mu[2] = {0, 0}, sg[2] = {1, 1}, a[2] = {0, 0}, spv = 0.f, tg = 0.f;
+        if (live) {
+            const size_t o = (size_t)b * E + e;
+            p = probs[o];
+            for (int d = 0; d < 2; ++d) {
+                mu[d] = mean[o * 2 + d];
+                sg[d] = sd[o * 2 + d];
+                a[d] = act[b * 2 + d];
+                const float z = (a[d] - mu[d]) / sg[d];
+                comp += -0.5f * z * z - __logf(sg[d]) - HALF_LOG_2PI;
+            }
+            spv = speeds[o];
+            tg = tgt[b];
+        }
+        float ps = p;
+        for (int off = 1; off < G; off <<= 1) ps += __shfl_xor(ps, off);
+        const float pn = live ? p / ps : 0.f;
+        const bool clamped = pn < EPS || pn > 1.f - EPS;
+        const float l = live ? __logf(fminf(fmaxf(pn, EPS), 1.f - EPS)) : -INFINITY;
+        float lm = l;
+        for (int off = 1; off < G; off <<= 1) lm = fmaxf(lm, __shfl_xor(lm, off));
+        float ls = live ? __expf(l - lm) : 0.f;
+        for (int off = 1; off < G; off <<= 1) ls += __shfl_xor(ls, off);
+        const float lsm = l - (lm + __logf(ls));                 // log_softmax of the logits
+        const float t = live ? comp + lsm : -INFINITY;
+        float tm = t;
+        for (int off = 1; off < G; off <<= 1) tm = fmaxf(tm, __shfl_xor(tm, off));
+        float ts = live ? __expf(t - tm) : 0.f;
+        for (int off = 1; off < G; off <<= 1) ts += __shfl_xor(ts, off);
+        const float ll = tm + __logf(ts);
+        if (live) {
+            const size_t o = (size_t)b * E + e;
+            const float r = __expf(t - ll);                       // responsibility of expert e
+            const float q = __expf(lsm);
+            const float gs = -c0 / (float)B;                      // d loss / d ll_b
+            if (e == 0) { nll_acc += -ll; if (loglik) loglik[b] = ll; }
+            // d ll / d p_j = (r_j - q_j)/p_j  (normalisation terms cancel because sum r = sum q = 1)
+            dprobs[o] = clamped ? 0.f : gs * (r - q) / (pn * ps);
+            for (int d = 0; d < 2; ++d) {
+                const float diff = a[d] - mu[d], iv = 1.f / (sg[d] * sg[d]);
+                dmean[o * 2 + d] = gs * r * diff * iv;
+                dstd[o * 2 + d] = gs * r * (diff * diff * iv / sg[d] - 1.f / sg[d]);
+            }
+            const float ds = spv - tg;
+            mse_acc += ds * ds;
+            dspeeds[o] = c1 * 2.f * ds / ((float)B * (float)E * (float)E);
+        }
+    }
+    __shared__ float r1[256], r2[256];
+    r1[threadIdx.x] = nll_acc;
+    r2[threadIdx.x] = mse_acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = c0 * r1[0] / (float)B + c1 * r2[0] / ((float)B * (float)E * (float)E);
+}
+
+static inline int pow2ceil(int v) { int g = 1; while (g < v) g <<= 1; return g; }
+
+extern "C" {
+
+int pmoe_pack_conv_weights(const void* const* src_ptrs, void* fwd, void* dgrd, int32_t E, int32_t cout, int32_t cin,
+                           int32_t ks, int32_t coutp, int32_t cinp, int32_t cinp2, int32_t coutp2, int32_t dtype,
+                           void* stream) {
+    if (coutp < cout || cinp < cin || (dgrd && (cinp2 < cin || coutp2 < cout))) return PMOE_ERR_ARG;
+    const int taps = ks * ks;
+    const long long n = (fwd ? (long long)coutp * taps * cinp : 0) + (dgrd ? (long long)cinp2 * taps * coutp2 : 0);
+    long long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (dtype == PMOE_DT_BF16)
+        hipLaunchKernelGGL((pack_w_kernel<bf16>), dim3((int)g, E), dim3(256), 0, (hipStream_t)stream,
+                           (const float* const*)src_ptrs, (bf16*)fwd, (bf16*)dgrd, cout, cin, taps, coutp, cinp, cinp2,
+                           coutp2);
+    else if (dtype == PMOE_DT_F32)
+        hipLaunchKernelGGL((pack_w_kernel<float>), dim3((int)g, E), dim3(256), 0, (hipStream_t)stream,
+                           (const float* const*)src_ptrs, (float*)fwd, (float*)dgrd, cout, cin, taps, coutp, cinp, cinp2,
+                           coutp2);
+    else
+        return PMOE_ERR_ARG;
+    return (int)hipGetLastError();
+}
+
+int pmoe_unpack_conv_wgrad(const float* dw_ws, float* grads, int32_t E, int32_t cout, int32_t cin, int32_t ks,
+                           int32_t coutp, int32_t cinp, void* stream) {
+    const int taps = ks * ks;
+    long long g = ((long long)cout * cin * taps + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((int)g, E), dim3(256), 0, (hipStream_t)stream, dw_ws, grads, cout, cin,
+                       taps, coutp, cinp);
+    return (int)hipGetLastError();
+}
+
+int pmoe_pack_bias(const void* const* src_ptrs, float* dst, int32_t E, int32_t cout, int32_t coutp, void* stream) {
+    hipLaunchKernelGGL(pack_bias_kernel, dim3((coutp + 255) / 256, E), dim3(256), 0, (hipStream_t)stream,
+                       (const float* const*)src_ptrs, dst, cout, coutp);
+    return (int)hipGetLastError();
+}
+
+int pmoe_gate_mixture_fwd(const void* head, int32_t head_ld, const void* spd, int32_t spd_ld, float* probs, float* mean,
+                          float* std_, float* speeds, int32_t B, int32_t E, int32_t alpha_relu, int32_t dtype,
+                          void* stream) {
+    if (E < 1 || E > 64 || head_ld < 5) return PMOE_ERR_ARG;
+    const int G = pow2ceil(E);
+    const int blocks = (B * G + 255) / 256;
+    if (dtype == PMOE_DT_BF16)
+        hipLaunchKernelGGL((gate_fwd_kernel<bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)head,
+                           head_ld, (const bf16*)spd, spd_ld, probs, mean, std_, speeds, B, E, G, alpha_relu);
+    else if (dtype == PMOE_DT_F32)
+        hipLaunchKernelGGL((gate_fwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)head,
+                           head_ld, (const float*)spd, spd_ld, probs, mean, std_, speeds, B, E, G, alpha_relu);
+    else
+        return PMOE_ERR_ARG;
+    return (int)hipGetLastError();
+}
+
+int pmoe_gate_mixture_bwd(const void* head, int32_t head_ld, const float* probs, const float* dprobs, const float* dmean,
+                          const float* dstd, const float* dspeeds, void* dhead, void* dspd, int32_t spd_ld, int32_t B,
+                          int32_t E, int32_t alpha_relu, int32_t dtype, void* stream) {
+    if (E < 1 || E > 64 || head_ld < 5) return PMOE_ERR_ARG;
+    const int G = pow2ceil(E);
+    const int blocks = (B * G + 255) / 256;
+    if (dtype == PMOE_DT_BF16)
+        hipLaunchKernelGGL((gate_bwd_kernel<bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)head,
+                           head_ld, probs, dprobs, dmean, dstd, dspeeds, (bf16*)dhead, (bf16*)dspd, spd_ld, B, E, G,
+                           alpha_relu);
+    else if (dtype == PMOE_DT_F32)
+        hipLaunchKernelGGL((gate_bwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)head,
+                           head_ld, probs, dprobs, dmean, dstd, dspeeds, (float*)dhead, (float*)dspd, spd_ld, B, E, G,
+                           alpha_relu);
+    else
+        return PMOE_ERR_ARG;
+    return (int)hipGetLastError();
+}
+
+int pmoe_moe_loss(const float* probs, const float* mean, const float* std_, const float* speeds, const float* actions,
+                  const float* target_speed, float c0, float c1, float* loss, float* loglik, float* dprobs, float* dmean,
+                  float* dstd, float* dspeeds, int32_t B, int32_t E, void* stream) {
+    if (E < 1 || E > 64) return PMOE_ERR_ARG;
+    hipLaunchKernelGGL(moe_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, probs, mean, std_, speeds, actions,
+                       target_speed, c0, c1, loss, loglik, dprobs, dmean, dstd, dspeeds, B, E, pow2ceil(E));
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// Internal launcher interfaces shared by the .hip translation units and the C-ABI layer (api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pmoe_hip.h"
+
+struct ConvArgs {
+    const void* in;        // [Nin][H][W][in_ld] T ; channels [in_coff, in_coff+Cin) are reduced over
+    const void* w;         // [E][CoutP][ks*ks][Cin] T
+    void* out;             // [N][Ho][Wo][out_ld] T ; channels [out_coff, out_coff+Cout) are written
+    const void* res;       // residual / saved activation, geometry of `out` with its own ld/coff
+    const float* bias;     // [E][CoutP] f32 or null
+    float* stats;          // [mblocks][2][CoutP] f32 partial (sum, sum of squares) or null
+    int N, H, W, Cin;
+    int Ho, Wo, Cout, CoutP;
+    int in_ld, in_coff, out_ld, out_coff, res_ld, res_coff;
+    int ipe;               // images per expert (N = E * ipe)
+    int in_shared;         // 1: the input holds ipe images shared by all experts
+    int ks, stride, pad, dilate;
+    int act, res_mode;
+    float drop_p;
+    unsigned long long seed;
+    // filled by the launcher
+    int lTW, lTH, TN, n_groups, tiles_y, tiles_x;
+};
+
+struct WgradArgs {
+    const void* x;         // conv input  [Nin][H][W][x_ld] T
+    const void* dy;        // output grad [N][Ho][Wo][dy_ld] T
+    float* dw;             // [E][taps][CoutP][CinP] f32, accumulated with atomics (must be zeroed)
+    int N, H, W, Cin, CinP;      // Cin: multiple of the channel chunk; CinP: row length of dw
+    int Ho, Wo, Cout, CoutP;     // Cout: multiple of the channel chunk actually reduced
+    int x_ld, x_coff, dy_ld, dy_coff;
+    int ipe, x_shared;
+    int ks, stride, pad;
+    int lTW, lTH, TN, n_groups, tiles_y, tiles_x, mb_per_wg;
+};
+
+int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st);
+int conv_igemm_mblocks(const ConvArgs& a, int dtype);
+int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);

@@ -1,0 +1,149 @@
+"""ctypes binding of ``libpmoe_hip.so`` (the C ABI declared in ``include/pmoe_hip.h``).
+
+PyTorch is used for device memory and streams only: every wrapper takes torch tensors, checks
+device / dtype / contiguity / shape the way torch would (``ValueError`` / ``RuntimeError``), and
+passes raw ``data_ptr()`` + the CURRENT torch stream.  There is no fallback: if the shared
+library is missing, or a tensor is not on a ROCm device, this module raises.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "libpmoe_hip.so"
+_lib = None
+
+DT_BF16, DT_F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
+RES_NONE, RES_ADD, RES_DRELU, RES_DELU = 0, 1, 2, 3
+
+_TORCH_DT = {torch.bfloat16: DT_BF16, torch.float32: DT_F32}
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p), ("res", C.c_void_p),
+        ("bias", C.c_void_p), ("stats", C.c_void_p),
+        ("n", C.c_int32), ("h", C.c_int32), ("w_", C.c_int32), ("cin", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32), ("cout", C.c_int32), ("coutp", C.c_int32),
+        ("in_ld", C.c_int32), ("in_coff", C.c_int32), ("out_ld", C.c_int32), ("out_coff", C.c_int32),
+        ("res_ld", C.c_int32), ("res_coff", C.c_int32),
+        ("ipe", C.c_int32), ("in_shared", C.c_int32),
+        ("ks", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dilate", C.c_int32),
+        ("act", C.c_int32), ("res_mode", C.c_int32),
+        ("drop_p", C.c_float), ("seed", C.c_uint64), ("dtype", C.c_int32),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("dy", C.c_void_p), ("dw_ws", C.c_void_p),
+        ("n", C.c_int32), ("h", C.c_int32), ("w_", C.c_int32), ("cin", C.c_int32), ("cinp", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32), ("cout", C.c_int32), ("coutp", C.c_int32),
+        ("x_ld", C.c_int32), ("x_coff", C.c_int32), ("dy_ld", C.c_int32), ("dy_coff", C.c_int32),
+        ("ipe", C.c_int32), ("x_shared", C.c_int32),
+        ("ks", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES).  Kept in one table so
+# tests/test_abi.py can check that every symbol of include/pmoe_hip.h is exported and bound.
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SIGNATURES = {
+    "pmoe_version": [],
+    "pmoe_error_string": [C.c_int],
+    "pmoe_abi_sizeof": [C.c_int],
+    "pmoe_conv2d_igemm": [C.POINTER(ConvDesc), _P],
+    "pmoe_conv2d_stat_rows": [C.POINTER(ConvDesc)],
+    "pmoe_conv2d_wgrad": [C.POINTER(WgradDesc), _P],
+    "pmoe_pack_conv_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_unpack_conv_wgrad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_pack_bias": [_P, _P, _I, _I, _I, _P],
+    "pmoe_colstats": [_P, _L, _I, _I, _I, _I, _P, _I, _I, _P],
+    "pmoe_reduce_partials": [_P, _P, _I, _I, _I, _I, _P],
+    "pmoe_bn_finalize": [_P, _I, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I, _I, _P],
+    "pmoe_bn_apply": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "pmoe_bn_bwd_reduce": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _I, _P],
+    "pmoe_bn_bwd_finalize": [_P, _I, _L, _P, _P, _P, _P, _I, _I, _P],
+    "pmoe_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "pmoe_maxpool3s2_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pmoe_maxpool3s2_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pmoe_gap_partial": [_P, _P, _P, _I, _L, _I, _I, _I, _I, _P],
+    "pmoe_gap_finish": [_P, _P, _I, _I, _I, _L, _I, _I, _I, _P],
+    "pmoe_gap_bwd": [_P, _P, _I, _L, _I, _I, _I, _I, _P],
+    "pmoe_eca_gate": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pmoe_eca_scale": [_P, _P, _P, _I, _L, _I, _I, _I, _P],
+    "pmoe_eca_bwd_small": [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "pmoe_eca_bwd_apply": [_P, _P, _P, _P, _I, _L, _I, _I, _P],
+    "pmoe_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_pad_rows": [_P, _P, _I, _I, _I, _I, _P],
+    "pmoe_gate_mixture_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pmoe_gate_mixture_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pmoe_moe_loss": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+}
+_RESTYPES = {"pmoe_error_string": C.c_char_p}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and return the shared library; raise HipUnavailable if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise HipUnavailable(
+            f"{_LIB_PATH} not found: build it with ./build.sh (hipcc --offload-arch=gfx950). "
+            "pmoe_amd has no CPU or PyTorch fallback path.")
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pmoe_error_string(rc)
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dt(t):
+    try:
+        return _TORCH_DT[t.dtype]
+    except KeyError:
+        raise ValueError(f"pmoe_amd kernels take bfloat16 or float32 activations, got {t.dtype}") from None
+
+
+def ptr(t, name="tensor", dtype=None):
+    """Validated device pointer of a dense tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the MI355X (cuda) device, got {t.device}; "
+                           "pmoe_amd has no CPU path")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_table(tensors, device):
+    """Device array of raw pointers (one per expert) as an int64 tensor."""
+    return torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=device)

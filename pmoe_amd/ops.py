@@ -1,0 +1,232 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of include/pmoe_hip.h).
+
+Activations are NHWC tensors ``[N, H, W, C]`` (bf16 or f32) with the experts folded into N
+(image n belongs to expert ``n // ipe``).  These functions only validate and launch; they never
+compute anything with torch ops.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+from .hip import ConvDesc, WgradDesc, check, dt, load, ptr, stream_ptr
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def conv_out_size(h, ks, stride, pad):
+    return (h + 2 * pad - ks) // stride + 1
+
+
+def _nhwc(t, name):
+    if t.dim() != 4:
+        raise ValueError(f"{name}: expected NHWC [N,H,W,C], got shape {tuple(t.shape)}")
+    return t.shape
+
+
+def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=False, in_shared=False,
+           in_coff=0, out_coff=0, res=None, res_coff=0, res_mode=hip.RES_NONE, bias=None, act=hip.ACT_NONE,
+           drop_p=0.0, seed=0, stats=None):
+    """out[..., out_coff:out_coff+cout] = epilogue(conv(x[..., in_coff:in_coff+cin], w)).
+    ``x`` [Nin,H,W,ldx], ``out`` [N,Ho,Wo,ldo] preallocated; also used for dgrad and grouped GEMM."""
+    nin, h, w_, ldx = _nhwc(x, "x")
+    n, ho, wo, ldo = _nhwc(out, "out")
+    if x.dtype != out.dtype or w_packed.dtype != x.dtype:
+        raise ValueError("conv2d: x, w and out must share one dtype")
+    d = ConvDesc()
+    d.in_, d.w, d.out = ptr(x, "x"), ptr(w_packed, "w"), ptr(out, "out")
+    d.res = ptr(res, "res", x.dtype) if res is not None else None
+    d.bias = ptr(bias, "bias", torch.float32) if bias is not None else None
+    d.stats = ptr(stats, "stats", torch.float32) if stats is not None else None
+    d.n, d.h, d.w_, d.cin = n, h, w_, cin
+    d.ho, d.wo, d.cout, d.coutp = ho, wo, cout, coutp
+    d.in_ld, d.in_coff, d.out_ld, d.out_coff = ldx, in_coff, ldo, out_coff
+    d.res_ld = res.shape[-1] if res is not None else 0
+    d.res_coff = res_coff
+    d.ipe, d.in_shared = ipe, int(in_shared)
+    d.ks, d.stride, d.pad, d.dilate = ks, stride, pad, int(dilate)
+    d.act, d.res_mode = act, res_mode if res is not None else hip.RES_NONE
+    d.drop_p, d.seed, d.dtype = float(drop_p), int(seed), dt(x)
+    if in_shared and nin != ipe:
+        raise ValueError("conv2d: shared input must hold exactly ipe images")
+    if not in_shared and nin != n:
+        raise ValueError("conv2d: input/output image counts differ")
+    if w_packed.numel() < (n // ipe) * coutp * ks * ks * cin:
+        raise ValueError("conv2d: packed weight tensor too small")
+    check(load().pmoe_conv2d_igemm(C.byref(d), stream_ptr()), "pmoe_conv2d_igemm")
+    return out
+
+
+def conv2d_stat_rows(n, h, w_, ho, wo, cin, cout, coutp, ipe, ks, stride, pad, dtype):
+    d = ConvDesc()
+    d.n, d.h, d.w_, d.cin, d.ho, d.wo, d.cout, d.coutp = n, h, w_, cin, ho, wo, cout, coutp
+    d.ipe, d.ks, d.stride, d.pad, d.dtype = ipe, ks, stride, pad, hip._TORCH_DT[dtype]
+    rows = load().pmoe_conv2d_stat_rows(C.byref(d))
+    if rows < 0:
+        check(rows, "pmoe_conv2d_stat_rows")
+    return rows
+
+
+def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, x_shared=False, x_coff=0, dy_coff=0):
+    nin, h, w_, ldx = _nhwc(x, "x")
+    n, ho, wo, ldy = _nhwc(dy, "dy")
+    d = WgradDesc()
+    d.x, d.dy, d.dw_ws = ptr(x, "x"), ptr(dy, "dy", x.dtype), ptr(dw_ws, "dw_ws", torch.float32)
+    d.n, d.h, d.w_, d.cin, d.cinp = n, h, w_, cin, cinp
+    d.ho, d.wo, d.cout, d.coutp = ho, wo, cout, coutp
+    d.x_ld, d.x_coff, d.dy_ld, d.dy_coff = ldx, x_coff, ldy, dy_coff
+    d.ipe, d.x_shared = ipe, int(x_shared)
+    d.ks, d.stride, d.pad, d.dtype = ks, stride, pad, dt(x)
+    if dw_ws.numel() < (n // ipe) * ks * ks * coutp * cinp:
+        raise ValueError("conv2d_wgrad: workspace too small")
+    check(load().pmoe_conv2d_wgrad(C.byref(d), stream_ptr()), "pmoe_conv2d_wgrad")
+    return dw_ws
+
+
+def pack_conv_weights(ptr_tab, fwd, dgrd, E, cout, cin, ks, coutp, cinp, cinp2, coutp2, dtype):
+    check(load().pmoe_pack_conv_weights(ptr(ptr_tab, "ptr table", torch.int64), ptr(fwd), ptr(dgrd), E, cout, cin, ks,
+                                        coutp, cinp, cinp2, coutp2, hip._TORCH_DT[dtype], stream_ptr()),
+          "pmoe_pack_conv_weights")
+
+
+def unpack_conv_wgrad(dw_ws, grads, E, cout, cin, ks, coutp, cinp):
+    check(load().pmoe_unpack_conv_wgrad(ptr(dw_ws, "dw_ws", torch.float32), ptr(grads, "grads", torch.float32), E, cout,
+                                        cin, ks, coutp, cinp, stream_ptr()), "pmoe_unpack_conv_wgrad")
+
+
+def pack_bias(ptr_tab, dst, E, cout, coutp):
+    check(load().pmoe_pack_bias(ptr(ptr_tab, "ptr table", torch.int64), ptr(dst, "dst", torch.float32), E, cout, coutp,
+                                stream_ptr()), "pmoe_pack_bias")
+
+
+def colstats(x2d_rows_per_expert, x, E, C_, part, nparts, ld=None, coff=0):
+    check(load().pmoe_colstats(ptr(x, "x"), x2d_rows_per_expert, E, C_, ld if ld is not None else x.shape[-1], coff,
+                               ptr(part, "part", torch.float32), nparts, dt(x), stream_ptr()), "pmoe_colstats")
+
+
+def reduce_partials(part_in, part_out, E, nin, nout, width):
+    check(load().pmoe_reduce_partials(ptr(part_in, "part_in", torch.float32), ptr(part_out, "part_out", torch.float32),
+                                      E, nin, nout, width, stream_ptr()), "pmoe_reduce_partials")
+
+
+def bn_finalize(part, nparts, count, gamma_tab, beta_tab, rmean_tab, rvar_tab, momentum, eps, training, scale, shift,
+                mean, invstd, E, C_):
+    f32 = torch.float32
+    check(load().pmoe_bn_finalize(ptr(part, "part", f32), nparts, count, ptr(gamma_tab), ptr(beta_tab), ptr(rmean_tab),
+                                  ptr(rvar_tab), momentum, eps, int(training), ptr(scale, "scale", f32),
+                                  ptr(shift, "shift", f32), ptr(mean, "mean", f32), ptr(invstd, "invstd", f32), E, C_,
+                                  stream_ptr()), "pmoe_bn_finalize")
+
+
+def bn_apply(x, res, y, scale, shift, rpe, E, C_, relu):
+    check(load().pmoe_bn_apply(ptr(x, "x"), ptr(res, "res", x.dtype), ptr(y, "y", x.dtype), ptr(scale), ptr(shift), rpe,
+                               E, C_, int(relu), dt(x), stream_ptr()), "pmoe_bn_apply")
+
+
+def bn_bwd_reduce(dy, y, x, mean, invstd, rpe, E, C_, relu, part, nparts):
+    check(load().pmoe_bn_bwd_reduce(ptr(dy, "dy"), ptr(y, "y", dy.dtype), ptr(x, "x", dy.dtype), ptr(mean), ptr(invstd),
+                                    rpe, E, C_, int(relu), ptr(part, "part", torch.float32), nparts, dt(dy),
+                                    stream_ptr()), "pmoe_bn_bwd_reduce")
+
+
+def bn_bwd_finalize(part, nparts, count, dgamma, dbeta, c1, c2, E, C_):
+    check(load().pmoe_bn_bwd_finalize(ptr(part), nparts, count, ptr(dgamma), ptr(dbeta), ptr(c1), ptr(c2), E, C_,
+                                      stream_ptr()), "pmoe_bn_bwd_finalize")
+
+
+def bn_bwd_apply(dy, y, x, mean, invstd, scale, c1, c2, dx, gmask, rpe, E, C_, relu):
+    check(load().pmoe_bn_bwd_apply(ptr(dy, "dy"), ptr(y, "y", dy.dtype), ptr(x, "x", dy.dtype), ptr(mean), ptr(invstd),
+                                   ptr(scale), ptr(c1), ptr(c2), ptr(dx, "dx", dy.dtype), ptr(gmask, "gmask", dy.dtype),
+                                   rpe, E, C_, int(relu), dt(dy), stream_ptr()), "pmoe_bn_bwd_apply")
+
+
+def maxpool_fwd(x, y, argmax):
+    n, h, w_, c = _nhwc(x, "x")
+    check(load().pmoe_maxpool3s2_fwd(ptr(x, "x"), ptr(y, "y", x.dtype), ptr(argmax, "argmax", torch.uint8), n, h, w_, c,
+                                     dt(x), stream_ptr()), "pmoe_maxpool3s2_fwd")
+
+
+def maxpool_bwd(dy, argmax, dx):
+    n, h, w_, c = _nhwc(dx, "dx")
+    check(load().pmoe_maxpool3s2_bwd(ptr(dy, "dy"), ptr(argmax, "argmax", torch.uint8), ptr(dx, "dx", dy.dtype), n, h,
+                                     w_, c, dt(dy), stream_ptr()), "pmoe_maxpool3s2_bwd")
+
+
+def gap_partial(a, b, part, nparts, b_shared_ipe=0):
+    n, h, w_, c = _nhwc(a, "a")
+    check(load().pmoe_gap_partial(ptr(a, "a"), ptr(b, "b", a.dtype), ptr(part, "part", torch.float32), n, h * w_, c,
+                                  nparts, b_shared_ipe, dt(a), stream_ptr()), "pmoe_gap_partial")
+
+
+def gap_finish(part, out, n, c, nparts, hw, out_ld, out_coff):
+    check(load().pmoe_gap_finish(ptr(part, "part", torch.float32), ptr(out, "out"), n, c, nparts, hw, out_ld, out_coff,
+                                 dt(out), stream_ptr()), "pmoe_gap_finish")
+
+
+def gap_bwd(g, dx, g_ld, g_coff):
+    n, h, w_, c = _nhwc(dx, "dx")
+    check(load().pmoe_gap_bwd(ptr(g, "g", dx.dtype), ptr(dx, "dx"), n, h * w_, c, g_ld, g_coff, dt(dx), stream_ptr()),
+          "pmoe_gap_bwd")
+
+
+def eca_gate(gap_part, nparts, hw, w_tab, k, gate, gapmean, n, ipe, in_ipe, c, creal):
+    f32 = torch.float32
+    check(load().pmoe_eca_gate(ptr(gap_part, "gap_part", f32), nparts, hw, ptr(w_tab), k, ptr(gate, "gate", f32),
+                               ptr(gapmean, "gapmean", f32), n, ipe, in_ipe, c, creal, stream_ptr()), "pmoe_eca_gate")
+
+
+def eca_scale(x, gate, y, x_shared_ipe=0):
+    n, h, w_, c = _nhwc(y, "y")
+    check(load().pmoe_eca_scale(ptr(x, "x"), ptr(gate, "gate", torch.float32), ptr(y, "y", x.dtype), n, h * w_, c,
+                                x_shared_ipe, dt(x), stream_ptr()), "pmoe_eca_scale")
+
+
+def eca_bwd_small(dot_part, nparts, gate, gapmean, w_tab, k, dgap, dw, n, ipe, c, creal):
+    check(load().pmoe_eca_bwd_small(ptr(dot_part), nparts, ptr(gate), ptr(gapmean), ptr(w_tab), k, ptr(dgap), ptr(dw),
+                                    n, ipe, c, creal, stream_ptr()), "pmoe_eca_bwd_small")
+
+
+def eca_bwd_apply(dy, gate, dgap, dx):
+    n, h, w_, c = _nhwc(dy, "dy")
+    check(load().pmoe_eca_bwd_apply(ptr(dy, "dy"), ptr(gate), ptr(dgap), ptr(dx, "dx", dy.dtype), n, h * w_, c, dt(dy),
+                                    stream_ptr()), "pmoe_eca_bwd_apply")
+
+
+def nchw_to_nhwc(src, dst):
+    b, c, h, w_ = src.shape
+    check(load().pmoe_nchw_to_nhwc(ptr(src, "src", torch.float32), ptr(dst, "dst"), b, c, h, w_, dst.shape[-1], dt(dst),
+                                   stream_ptr()), "pmoe_nchw_to_nhwc")
+
+
+def pad_rows(src, dst):
+    b, k = src.shape
+    check(load().pmoe_pad_rows(ptr(src, "src", torch.float32), ptr(dst, "dst"), b, k, dst.shape[-1], dt(dst),
+                               stream_ptr()), "pmoe_pad_rows")
+
+
+def gate_mixture_fwd(head, spd, probs, mean, std, speeds, B, E, alpha_relu):
+    f32 = torch.float32
+    check(load().pmoe_gate_mixture_fwd(ptr(head, "head"), head.shape[-1], ptr(spd, "spd", head.dtype), spd.shape[-1],
+                                       ptr(probs, "probs", f32), ptr(mean, "mean", f32), ptr(std, "std", f32),
+                                       ptr(speeds, "speeds", f32), B, E, int(alpha_relu), dt(head), stream_ptr()),
+          "pmoe_gate_mixture_fwd")
+
+
+def gate_mixture_bwd(head, probs, dprobs, dmean, dstd, dspeeds, dhead, dspd, B, E, alpha_relu):
+    f32 = torch.float32
+    check(load().pmoe_gate_mixture_bwd(ptr(head, "head"), head.shape[-1], ptr(probs, "probs", f32),
+                                       ptr(dprobs, "dprobs", f32), ptr(dmean, "dmean", f32), ptr(dstd, "dstd", f32),
+                                       ptr(dspeeds, "dspeeds", f32), ptr(dhead, "dhead", head.dtype),
+                                       ptr(dspd, "dspd", head.dtype), dspd.shape[-1], B, E, int(alpha_relu), dt(head),
+                                       stream_ptr()), "pmoe_gate_mixture_bwd")
+
+
+def moe_loss(probs, mean, std, speeds, actions, target, c0, c1, loss, loglik, dprobs, dmean, dstd, dspeeds, B, E):
+    f32 = torch.float32
+    check(load().pmoe_moe_loss(ptr(probs, "probs", f32), ptr(mean, "mean", f32), ptr(std, "std", f32),
+                               ptr(speeds, "speeds", f32), ptr(actions, "actions", f32), ptr(target, "target", f32),
+                               float(c0), float(c1), ptr(loss, "loss", f32), ptr(loglik, "loglik", f32),
+                               ptr(dprobs, "dprobs", f32), ptr(dmean, "dmean", f32), ptr(dstd, "dstd", f32),
+                               ptr(dspeeds, "dspeeds", f32), B, E, stream_ptr()), "pmoe_moe_loss")

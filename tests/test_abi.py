@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports every symbol
+include/pmoe_hip.h declares, with the argument counts the ctypes binding uses (no compute calls)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from pmoe_amd import hip
+
+REPO = Path(__file__).resolve().parents[1]
+HEADER = (REPO / "include" / "pmoe_hip.h").read_text()
+
+
+def _declared():
+    text = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    text = re.sub(r"typedef struct.*?\}\s*\w+;", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"(?:int|const char\*)\s+(pmoe_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        out[m.group(1)] = n
+    return out
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not hip.lib_path().exists():
+        import __graft_entry__
+        __graft_entry__.build()
+    return hip.load()
+
+
+def test_header_declares_the_bound_symbols():
+    decl = _declared()
+    assert set(decl) == set(hip.SIGNATURES), set(decl) ^ set(hip.SIGNATURES)
+    for name, n in decl.items():
+        assert len(hip.SIGNATURES[name]) == n, (name, n, len(hip.SIGNATURES[name]))
+
+
+def test_library_exports_every_symbol(lib):
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.pmoe_version() >= 100
+    assert b"invalid" in lib.pmoe_error_string(-1)
+
+
+def test_struct_layouts_match_c(lib):
+    # sizes computed by hand from include/pmoe_hip.h (LP64): 6 pointers + 22 int32 + float + pad + u64 + int32 + pad
+    assert ctypes.sizeof(hip.ConvDesc) == 160 == lib.pmoe_abi_sizeof(0)
+    assert ctypes.sizeof(hip.WgradDesc) == lib.pmoe_abi_sizeof(1)
+    assert ctypes.sizeof(hip.WgradDesc) == 3 * 8 + 19 * 4 + 4  # padded to 8
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    from pmoe_amd import ops
+    x = torch.zeros(1, 4, 4, 16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.maxpool_fwd(x, torch.zeros(1, 2, 2, 16), torch.zeros(1, 2, 2, 16, dtype=torch.uint8))
