@@ -1,0 +1,706 @@
+"""Grouped execution engine: runs the SAME layer of all E experts as one HIP launch.
+
+The reference loops over experts in Python and calls ~60 cuDNN/cuBLAS kernels per expert
+(``model/moe.py:141``).  Here the experts are folded into the image index (image n of the NHWC
+activation belongs to expert ``n // B``) and every layer -- conv, BatchNorm pass, pool, ECA, MLP
+GEMM -- is issued once for all experts.  Activations stay on the device in NHWC bf16 (or f32)
+between launches; parameters stay in the reference's per-expert f32 tensors (the state_dict
+contract) and are repacked to the grouped kernel layouts by one small launch per layer.
+
+Backward is driven by a tape of closures recorded during forward (no torch autograd inside the
+path); the whole network is ONE ``torch.autograd.Function`` towards the outside, so ``loss.backward()``,
+``clip_grad_norm_`` and optimizers of the reference trainer work unchanged.  Gradients are written
+into one flat f32 arena in backward order, which is also the data-parallel all-reduce buffer
+(bucketed RCCL all-reduce launched while earlier layers are still in backward).
+"""
+import itertools
+
+import torch
+import torch.distributed as dist
+
+from . import hip, ops
+from .model import blocks as B
+from .parallel import BucketedAllReduce
+
+F32 = torch.float32
+
+
+def r16(c):
+    return (c + 15) // 16 * 16
+
+
+def r64(c):
+    return (c + 63) // 64 * 64
+
+
+class Var:
+    """A device activation [N,H,W,ld] (+ channel window) with its gradient slot."""
+    __slots__ = ("t", "coff", "c", "g", "needs_grad", "act", "drop_p", "base")
+
+    def __init__(self, t, c=None, coff=0, needs_grad=False, base=None):
+        self.t, self.coff, self.c = t, coff, (c if c is not None else t.shape[-1])
+        self.g, self.needs_grad, self.act, self.drop_p, self.base = None, needs_grad, hip.ACT_NONE, 0.0, base
+
+    @property
+    def grad(self):
+        return self.base.g if self.base is not None else self.g
+
+    def set_grad(self, g):
+        if self.base is not None:
+            self.base.g = g
+        else:
+            self.g = g
+
+    def window(self, coff, c):
+        v = Var(self.t, c, coff, self.needs_grad, base=self if self.base is None else self.base)
+        return v
+
+
+class GroupedConv:
+    """One conv / linear layer of all experts: packed operands + launch helpers."""
+
+    def __init__(self, eng, name, weights, biases, cin, cout, ks, stride, pad):
+        self.eng, self.name = eng, name
+        self.weights, self.biases = weights, biases
+        self.cin, self.cout, self.ks, self.stride, self.pad = cin, cout, ks, stride, pad
+        self.cinp, self.coutp, self.cout_st = r16(cin), r64(cout), r16(cout)
+        self.dg_rows, self.dg_red = r64(cin), r16(cout)
+        self.taps = ks * ks
+        self.w_fwd = self.w_dg = self.bias_packed = None
+        self.need_dgrad = True
+
+    def alloc(self, dtype, dev):
+        E = self.eng.E
+        self.w_fwd = torch.empty(E, self.coutp, self.taps, self.cinp, dtype=dtype, device=dev)
+        self.w_dg = torch.empty(E, self.dg_rows, self.taps, self.dg_red, dtype=dtype, device=dev) if self.need_dgrad else None
+        if self.biases is not None:
+            self.bias_packed = torch.empty(E, self.coutp, dtype=F32, device=dev)
+
+    def pack(self, wtab, btab):
+        E = self.eng.E
+        ops.pack_conv_weights(wtab, self.w_fwd, self.w_dg, E, self.cout, self.cin, self.ks, self.coutp, self.cinp,
+                              self.dg_rows, self.dg_red, self.w_fwd.dtype)
+        if self.biases is not None:
+            ops.pack_bias(btab, self.bias_packed, E, self.cout, self.coutp)
+
+    @property
+    def trainable(self):
+        return any(p.requires_grad for p in self.weights) or (
+            self.biases is not None and any(p.requires_grad for p in self.biases))
+
+
+class GroupedBN:
+    def __init__(self, name, mods):
+        self.name, self.mods = name, mods
+        self.C = mods[0].num_features
+        self.eps, self.momentum = mods[0].eps, mods[0].momentum
+
+    @property
+    def trainable(self):
+        return any(m.weight.requires_grad or m.bias.requires_grad for m in self.mods)
+
+
+class GroupedECA:
+    def __init__(self, name, mods):
+        self.name, self.mods = name, mods
+        self.k = mods[0].conv.kernel_size
+        self.creal = mods[0].channels
+
+    @property
+    def trainable(self):
+        return any(m.conv.weight.requires_grad for m in self.mods)
+
+
+class ExpertGroupEngine:
+    """Executes ``experts`` (list of pmoe_amd.model.moe.BaseExpert[Alt]) as one grouped network."""
+
+    def __init__(self, experts, alt=False):
+        self.experts = list(experts)
+        self.E = len(self.experts)
+        self.alt = alt
+        self.dp_group = None          # torch.distributed process group for gradient all-reduce (None = WORLD)
+        self.dp_enabled = False       # set by pmoe_amd.parallel-aware callers (bench.py, enable_data_parallel)
+        self.dp_buckets = 6
+        self._built_for = None
+        self._seed_counter = itertools.count(1)
+        self.fuse_conv_stats = True
+        self._collect()
+
+    # ------------------------------------------------------------------ structure
+    def _collect(self):
+        ex = self.experts
+        self.params = []              # ordered list of (kind, layer, [E params]) in FORWARD order
+
+        def conv(name, mods, ks=None):
+            m0 = mods[0]
+            if isinstance(m0, B.Linear):
+                layer = GroupedConv(self, name, [m.weight for m in mods],
+                                    [m.bias for m in mods] if m0.bias is not None else None,
+                                    m0.in_features, m0.out_features, 1, 1, 0)
+            else:
+                layer = GroupedConv(self, name, [m.weight for m in mods], None, m0.in_channels, m0.out_channels,
+                                    m0.kernel_size, m0.stride, m0.padding)
+            self.params.append(("w", layer, layer.weights))
+            if layer.biases is not None:
+                self.params.append(("b", layer, layer.biases))
+            return layer
+
+        def bn(name, mods):
+            layer = GroupedBN(name, mods)
+            self.params.append(("gamma", layer, [m.weight for m in mods]))
+            self.params.append(("beta", layer, [m.bias for m in mods]))
+            return layer
+
+        def eca(name, mods):
+            layer = GroupedECA(name, mods)
+            self.params.append(("eca", layer, [m.conv.weight for m in mods]))
+            return layer
+
+        def mlp(name, seqs):
+            spec = seqs[0].spec
+            for s in seqs:
+                if s.spec != spec:
+                    raise ValueError("experts of one mixture must share MLP configuration")
+            if spec["bn"]:
+                raise NotImplementedError(
+                    "make_mlp(bn=True) (BatchNorm1d heads, docs/experiments.md / stage_3.yaml) is not on the HIP "
+                    "path yet; every stage-2 config uses bn: False")
+            if spec["act"] not in ("relu", "elu"):
+                raise NotImplementedError(f"MLP activation {spec['act']!r} is not on the HIP path (stage-2 uses relu/elu)")
+            lins = [[m for m in s if isinstance(m, B.Linear)] for s in seqs]
+            layers = [conv(f"{name}.{i}", [l[i] for l in lins]) for i in range(len(lins[0]))]
+            return dict(layers=layers, act=hip.ACT_RELU if spec["act"] == "relu" else hip.ACT_ELU,
+                        l_act=spec["l_act"], dropout=spec["dropout"])
+
+        bbs = [e.backbone for e in ex]
+        self.speed_enc = mlp("speed_encoder", [e.speed_encoder for e in ex])
+        self.cmd_enc = mlp("command_encoder", [e.command_encoder for e in ex])
+        self.eca1 = eca("eca1", [b.conv1.layer1.eca1 for b in bbs])
+        self.conv1 = conv("stem.conv1", [b.conv1.layer1.conv1[0] for b in bbs])
+        self.bn_c1 = bn("stem.bn1", [b.conv1.layer1.conv1[1] for b in bbs])
+        self.eca2 = eca("eca2", [b.conv1.layer2.eca2 for b in bbs])
+        self.conv2 = conv("stem.conv2", [b.conv1.layer2.conv2[0] for b in bbs])
+        self.bn_c2 = bn("stem.bn2", [b.conv1.layer2.conv2[1] for b in bbs])
+        self.bn1 = bn("bn1", [b.bn1 for b in bbs])
+        self.blocks = []
+        for li in range(1, 5):
+            seqs = [getattr(b, f"layer{li}") for b in bbs]
+            for bi in range(len(seqs[0])):
+                blks = [s[bi] for s in seqs]
+                d = dict(conv1=conv(f"layer{li}.{bi}.conv1", [k.conv1 for k in blks]),
+                         bn1=bn(f"layer{li}.{bi}.bn1", [k.bn1 for k in blks]),
+                         conv2=conv(f"layer{li}.{bi}.conv2", [k.conv2 for k in blks]),
+                         bn2=bn(f"layer{li}.{bi}.bn2", [k.bn2 for k in blks]), down=None)
+                if blks[0].downsample is not None:
+                    d["down"] = (conv(f"layer{li}.{bi}.down", [k.downsample[0] for k in blks]),
+                                 bn(f"layer{li}.{bi}.downbn", [k.downsample[1] for k in blks]))
+                self.blocks.append(d)
+        self.speed_pred = mlp("speed_pred", [e.speed_pred for e in ex])
+        self.action_feat = mlp("action_features", [e.action_features for e in ex])
+        if self.alt:
+            # BaseExpertAlt (moe.py:108-110): alpha = Sequential(Linear(1536,512), ReLU, Linear(512,1)) on features
+            self.alpha_mlp = dict(layers=[conv("alpha.0", [e.alpha[0] for e in ex]), conv("alpha.2", [e.alpha[2] for e in ex])],
+                                  act=hip.ACT_RELU, l_act=False, dropout=0.0)
+            self.head = conv("action_pred", [e.action_pred for e in ex])
+        else:
+            # action_pred (4 rows) and alpha (1 row) read the same input: one GEMM with 5 output rows
+            self.head = self._fused_head(ex)
+        self.conv1.need_dgrad = True
+        self.all_convs = [p[1] for p in self.params if p[0] == "w"]
+        self.all_bns = [p[1] for p in self.params if p[0] == "gamma"]
+        self.flat_params = [p for _, _, plist in self.params for p in plist]
+
+    def _fused_head(self, ex):
+        class _Cat:  # weights of action_pred (rows 0..3) and alpha (row 4) as one 5-row layer
+            pass
+        layer = GroupedConv(self, "head", None, None, ex[0].action_pred.in_features, 5, 1, 1, 0)
+        layer.parts = [([e.action_pred.weight for e in ex], [e.action_pred.bias for e in ex], 4),
+                       ([e.alpha.weight for e in ex], [e.alpha.bias for e in ex], 1)]
+        layer.weights = layer.parts[0][0] + layer.parts[1][0]
+        layer.biases = layer.parts[0][1] + layer.parts[1][1]
+        for (ws, bs, _), nm in zip(layer.parts, ("action_pred", "alpha")):
+            self.params.append(("w_part", (layer, nm), ws))
+            self.params.append(("b_part", (layer, nm), bs))
+        return layer
+
+    # ------------------------------------------------------------------ buffers
+    def _ensure_built(self, dev, dtype):
+        key = (str(dev), dtype)
+        if self._built_for == key:
+            return
+        for layer in self.all_convs + ([self.head] if not self.alt else []):
+            if layer.w_fwd is None or layer.w_fwd.dtype != dtype or layer.w_fwd.device != dev:
+                layer.alloc(dtype, dev)
+        self._ptr_key = None
+        self._packed_version = None
+        self._built_for = key
+
+    def _refresh_tables(self, dev):
+        """One int64 device table of all parameter/buffer pointers (rebuilt only when storage moved)."""
+        tensors = []
+        index = {}
+
+        def add(key, lst):
+            index[key] = (len(tensors), len(lst))
+            tensors.extend(lst)
+
+        for kind, layer, plist in self.params:
+            add((kind, id(layer) if not isinstance(layer, tuple) else (id(layer[0]), layer[1])), plist)
+        for bnl in self.all_bns:
+            add(("rm", id(bnl)), [m.running_mean for m in bnl.mods])
+            add(("rv", id(bnl)), [m.running_var for m in bnl.mods])
+        ptrs = tuple(t.data_ptr() for t in tensors)
+        if ptrs != self._ptr_key:
+            for t in tensors:
+                if t.device != dev or t.dtype != F32 or not t.is_contiguous():
+                    raise RuntimeError("pmoe_amd: parameters/buffers must be contiguous float32 tensors on the "
+                                       f"same device as the inputs ({dev}); got {t.dtype} on {t.device}")
+            self._ptr_tab = torch.tensor(ptrs, dtype=torch.int64, device=dev)
+            self._ptr_key = ptrs
+            self._ptr_index = index
+            self._packed_version = None
+
+    def _tab(self, kind, layer):
+        k = (kind, id(layer) if not isinstance(layer, tuple) else (id(layer[0]), layer[1]))
+        s, n = self._ptr_index[k]
+        return self._ptr_tab[s:s + n]
+
+    def _pack_all(self):
+        ver = sum(p._version for p in self.flat_params)
+        if ver == self._packed_version:
+            return
+        for layer in self.all_convs:
+            layer.pack(self._tab("w", layer), self._tab("b", layer) if layer.biases is not None else None)
+        if not self.alt:
+            h = self.head
+            E = self.E
+            # two packs into row windows of the fused 5-row head: rows 0..3 action_pred, row 4 alpha
+            for (ws, bs, rows), nm, r0 in ((h.parts[0], "action_pred", 0), (h.parts[1], "alpha", 4)):
+                self._pack_head_part(h, nm, rows, r0)
+        self._packed_version = ver
+
+    def _pack_head_part(self, h, nm, rows, r0):
+        # The pack kernel writes a whole [coutp] panel, so pack each part into scratch and copy its rows.
+        E = self.E
+        scratch_f = torch.empty(E, 64, 1, h.cinp, dtype=h.w_fwd.dtype, device=h.w_fwd.device)
+        scratch_d = torch.empty(E, h.dg_rows, 1, 16, dtype=h.w_fwd.dtype, device=h.w_fwd.device)
+        ops.pack_conv_weights(self._tab("w_part", (h, nm)), scratch_f, scratch_d, E, rows, h.cin, 1, 64, h.cinp,
+                              h.dg_rows, 16, h.w_fwd.dtype)
+        if r0 == 0:
+            h.w_fwd.zero_()
+            h.w_dg.zero_()
+            h.bias_packed.zero_()
+        h.w_fwd[:, r0:r0 + rows] = scratch_f[:, :rows]
+        h.w_dg[:, :, :, r0:r0 + rows] = scratch_d[:, :, :, :rows]
+        sb = torch.empty(E, 64, dtype=F32, device=h.w_fwd.device)
+        ops.pack_bias(self._tab("b_part", (h, nm)), sb, E, rows, 64)
+        h.bias_packed[:, r0:r0 + rows] = sb[:, :rows]
+
+    # ------------------------------------------------------------------ primitive ops (forward + tape)
+    def _new(self, n, h, w, c, dtype=None):
+        return torch.empty(n, h, w, c, dtype=dtype or self.dtype, device=self.dev)
+
+    def _conv(self, x, layer, *, bias=True, act=hip.ACT_NONE, drop_p=0.0, out=None, out_coff=0, in_shared=False,
+              want_stats=False):
+        H, W = x.t.shape[1], x.t.shape[2]
+        Ho = ops.conv_out_size(H, layer.ks, layer.stride, layer.pad)
+        Wo = ops.conv_out_size(W, layer.ks, layer.stride, layer.pad)
+        if out is None:
+            o = Var(self._new(self.N, Ho, Wo, layer.cout_st), layer.cout_st, 0)
+        else:
+            o = out.window(out_coff, layer.cout_st)
+        stats = None
+        if want_stats:
+            rows = ops.conv2d_stat_rows(self.N, H, W, Ho, Wo, layer.cinp, layer.cout_st, layer.coutp, self.B, layer.ks,
+                                        layer.stride, layer.pad, self.dtype)
+            stats = torch.empty(rows, 2, layer.coutp, dtype=F32, device=self.dev)
+        seed = (next(self._seed_counter) * 0x9E3779B1 + self.base_seed) & 0xFFFFFFFFFFFF if drop_p > 0 else 0
+        ops.conv2d(x.t, layer.w_fwd, o.t, cin=layer.cinp, cout=layer.cout_st, coutp=layer.coutp, ipe=self.B,
+                   ks=layer.ks, stride=layer.stride, pad=layer.pad, in_shared=in_shared, in_coff=x.coff,
+                   out_coff=o.coff, bias=layer.bias_packed if bias else None, act=act, drop_p=drop_p, seed=seed,
+                   stats=stats)
+        o.act, o.drop_p = act, drop_p
+        o.needs_grad = x.needs_grad or layer.trainable
+        if out is not None and o.needs_grad:
+            out.needs_grad = True
+        if self.taping and o.needs_grad:
+            self.tape.append(lambda: self._conv_bwd(x, layer, o, in_shared))
+        return (o, stats) if want_stats else o
+
+    def _conv_bwd(self, x, layer, o, in_shared):
+        """dy is the gradient w.r.t. the layer's PRE-activation output (the consumer's dgrad epilogue
+        already applied act'); emits weight/bias gradients and, if needed, the input gradient."""
+        dy = o.grad
+        if dy is None:
+            return
+        E = self.E
+        if layer.trainable:
+            ckw = 64 if self.dtype == torch.bfloat16 else 32
+            cpw = (layer.cinp + ckw - 1) // ckw * ckw
+            cow = (layer.cout_st + ckw - 1) // ckw * ckw
+            ws = self._wgrad_ws(E * layer.taps * cow * cpw)
+            ws.zero_()
+            ops.conv2d_wgrad(x.t, dy, ws, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B,
+                             ks=layer.ks, stride=layer.stride, pad=layer.pad, x_shared=in_shared, x_coff=x.coff,
+                             dy_coff=o.coff)
+            parts = getattr(layer, "parts", None)
+            if parts is None:
+                ops.unpack_conv_wgrad(ws, self._grad_slot("w", layer), E, layer.cout, layer.cin, layer.ks, cow, cpw)
+            else:
+                full = torch.empty(E, layer.cout, layer.cin, dtype=F32, device=self.dev)
+                ops.unpack_conv_wgrad(ws, full, E, layer.cout, layer.cin, 1, cow, cpw)
+                self._grad_slot("w_part", (layer, "action_pred")).view(E, 4, layer.cin).copy_(full[:, 0:4])
+                self._grad_slot("w_part", (layer, "alpha")).view(E, 1, layer.cin).copy_(full[:, 4:5])
+            if layer.biases is not None:
+                rpe = self.B * dy.shape[1] * dy.shape[2]
+                part = torch.empty(E, 1, 2, layer.cout_st, dtype=F32, device=self.dev)
+                ops.colstats(rpe, dy, E, layer.cout_st, part, 1, ld=dy.shape[-1], coff=o.coff)
+                sums = part[:, 0, 0, :layer.cout]
+                if parts is None:
+                    self._grad_slot("b", layer).view(E, layer.cout).copy_(sums)
+                else:
+                    self._grad_slot("b_part", (layer, "action_pred")).view(E, 4).copy_(sums[:, 0:4])
+                    self._grad_slot("b_part", (layer, "alpha")).view(E, 1).copy_(sums[:, 4:5])
+        if x.needs_grad:
+            prev = x.grad
+            res, res_mode = None, hip.RES_NONE
+            if x.act != hip.ACT_NONE:
+                if prev is not None:
+                    raise RuntimeError("activation output consumed twice: unsupported gradient accumulation")
+                res, res_mode = x.t, (hip.RES_DRELU if x.act == hip.ACT_RELU else hip.RES_DELU)
+            elif prev is not None:
+                res, res_mode = prev, hip.RES_ADD       # second consumer: accumulate in the epilogue
+            g = prev if prev is not None else torch.empty_like(x.t)
+            ops.conv2d(dy, layer.w_dg, g, cin=layer.dg_red, cout=layer.cinp, coutp=layer.dg_rows, ipe=self.B,
+                       ks=layer.ks, stride=1, pad=layer.ks - 1 - layer.pad, dilate=(layer.stride == 2),
+                       in_coff=o.coff, out_coff=x.coff, res=res, res_coff=x.coff, res_mode=res_mode,
+                       drop_p=x.drop_p if res_mode in (hip.RES_DRELU, hip.RES_DELU) else 0.0)
+            x.set_grad(g)
+
+    def _bn(self, z, layer, relu, res=None, stats=None):
+        """y = [relu](bn(z) [+ res]); train mode: batch statistics (fused conv partials or a colstats pass)."""
+        E, C_ = self.E, layer.C
+        n, h, w, _ = z.t.shape
+        rpe = self.B * h * w
+        scale, shift, mean, invstd = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(4))
+        if self.training:
+            if stats is not None:
+                rows = stats.shape[0] // E
+                part, nparts = stats, rows
+                if stats.shape[2] != C_:
+                    raise RuntimeError("fused stats width mismatch")
+                if rows > 128:
+                    part = torch.empty(E, 128, 2, C_, dtype=F32, device=self.dev)
+                    ops.reduce_partials(stats, part, E, rows, 128, 2 * C_)
+                    nparts = 128
+            else:
+                nparts = min(128, max(1, rpe // 512))
+                part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
+                ops.colstats(rpe, z.t, E, C_, part, nparts)
+            ops.bn_finalize(part, nparts, rpe, self._tab("gamma", layer), self._tab("beta", layer),
+                            self._tab("rm", layer), self._tab("rv", layer), layer.momentum, layer.eps, True, scale,
+                            shift, mean, invstd, E, C_)
+            self._bn_touched.append(layer)
+        else:
+            ops.bn_finalize(scale, 0, rpe, self._tab("gamma", layer), self._tab("beta", layer), self._tab("rm", layer),
+                            self._tab("rv", layer), layer.momentum, layer.eps, False, scale, shift, mean, invstd, E, C_)
+        y = Var(torch.empty_like(z.t))
+        ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, rpe, E, C_, relu)
+        y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
+        if self.taping and y.needs_grad:
+            train = self.training
+            self.tape.append(lambda: self._bn_bwd(z, layer, y, res, relu, scale, mean, invstd, rpe, train))
+        return y
+
+    def _bn_bwd(self, z, layer, y, res, relu, scale, mean, invstd, rpe, train):
+        dy = y.grad
+        if dy is None:
+            return
+        E, C_ = self.E, layer.C
+        nparts = min(128, max(1, rpe // 512))
+        part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
+        ops.bn_bwd_reduce(dy, y.t, z.t, mean, invstd, rpe, E, C_, relu, part, nparts)
+        c1, c2 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(2))
+        ops.bn_bwd_finalize(part, nparts, rpe, self._grad_slot("gamma", layer).view(E, C_),
+                            self._grad_slot("beta", layer).view(E, C_), c1, c2, E, C_)
+        if not train:          # eval-mode BN is an affine map: no batch-statistics terms
+            c1.zero_()
+            c2.zero_()
+        want_res = res is not None and res.needs_grad
+        dz = torch.empty_like(z.t) if z.needs_grad else None
+        gm = torch.empty_like(z.t) if want_res else None
+        if dz is None and gm is None:
+            return
+        if dz is None:
+            dz = torch.empty_like(z.t)
+        ops.bn_bwd_apply(dy, y.t, z.t, mean, invstd, scale, c1, c2, dz, gm, rpe, E, C_, relu)
+        if z.needs_grad:
+            if z.grad is not None:
+                raise RuntimeError("BN input consumed twice")
+            z.set_grad(dz)
+        if want_res:
+            if res.grad is not None:
+                raise RuntimeError("residual gradient slot already filled")
+            res.set_grad(gm)
+
+    def _maxpool(self, x):
+        n, h, w, c = x.t.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = Var(self._new(n, ho, wo, c))
+        am = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=self.dev)
+        ops.maxpool_fwd(x.t, y.t, am)
+        y.needs_grad = x.needs_grad
+        if self.taping and y.needs_grad:
+            def bwd():
+                if y.grad is None:
+                    return
+                dx = torch.empty_like(x.t)
+                ops.maxpool_bwd(y.grad, am, dx)
+                x.set_grad(dx)
+            self.tape.append(bwd)
+        return y
+
+    def _gap_parts(self, hw):
+        return min(16, max(1, hw // 1024))
+
+    def _eca(self, x, layer, shared):
+        """y[n] = x[n or n % B] * sigmoid(conv1d(GAP(x)))  (EfficientBlock, basics.py:69-76)."""
+        nx, h, w, c = x.t.shape
+        hw = h * w
+        nparts = self._gap_parts(hw)
+        part = torch.empty(nx, nparts, c, dtype=F32, device=self.dev)
+        ops.gap_partial(x.t, None, part, nparts)
+        gate = torch.empty(self.N, c, dtype=F32, device=self.dev)
+        gapmean = torch.empty(self.N, c, dtype=F32, device=self.dev)
+        ops.eca_gate(part, nparts, hw, self._tab("eca", layer), layer.k, gate, gapmean, self.N, self.B,
+                     self.B if shared else 0, c, layer.creal)
+        y = Var(self._new(self.N, h, w, c))
+        ops.eca_scale(x.t, gate, y.t, self.B if shared else 0)
+        y.needs_grad = x.needs_grad or layer.trainable
+        if self.taping and y.needs_grad:
+            def bwd():
+                dy = y.grad
+                if dy is None:
+                    return
+                dot = torch.empty(self.N, nparts, c, dtype=F32, device=self.dev)
+                ops.gap_partial(dy, x.t, dot, nparts, self.B if shared else 0)
+                dgap = torch.empty(self.N, c, dtype=F32, device=self.dev)
+                ops.eca_bwd_small(dot, nparts, gate, gapmean, self._tab("eca", layer), layer.k, dgap,
+                                  self._grad_slot("eca", layer).view(self.E, layer.k), self.N, self.B, c, layer.creal)
+                if x.needs_grad:
+                    dx = torch.empty_like(x.t)
+                    ops.eca_bwd_apply(dy, gate, dgap, dx)
+                    x.set_grad(dx)
+            self.tape.append(bwd)
+        return y
+
+    def _gap_to(self, x, feat, coff):
+        n, h, w, c = x.t.shape
+        hw = h * w
+        nparts = self._gap_parts(hw)
+        part = torch.empty(n, nparts, c, dtype=F32, device=self.dev)
+        ops.gap_partial(x.t, None, part, nparts)
+        ops.gap_finish(part, feat.t, n, c, nparts, hw, feat.t.shape[-1], coff)
+        if x.needs_grad:
+            feat.needs_grad = True
+        if self.taping and x.needs_grad:
+            def bwd():
+                g = feat.grad
+                if g is None:
+                    return
+                dx = torch.empty_like(x.t)
+                ops.gap_bwd(g, dx, g.shape[-1], coff)
+                x.set_grad(dx)
+            self.tape.append(bwd)
+
+    def _mlp(self, x, spec, out=None, out_coff=0, in_shared=False):
+        layers = spec["layers"]
+        drop = spec["dropout"] if self.training else 0.0
+        v = x
+        for i, layer in enumerate(layers):
+            last = i == len(layers) - 1
+            act = spec["act"] if (not last or spec["l_act"]) else hip.ACT_NONE
+            dp = drop if not last else 0.0        # basics.py:33-39: dropout follows hidden activations only
+            v = self._conv(v, layer, act=act, drop_p=dp, out=out if last else None, out_coff=out_coff if last else 0,
+                           in_shared=in_shared and i == 0)
+        return v
+
+    # ------------------------------------------------------------------ gradient arena
+    def _wgrad_ws(self, numel):
+        if self._ws is None or self._ws.numel() < numel:
+            self._ws = torch.empty(numel, dtype=F32, device=self.dev)
+        return self._ws[:numel]
+
+    @staticmethod
+    def _key(kind, layer):
+        return (kind, id(layer) if not isinstance(layer, tuple) else (id(layer[0]), layer[1]))
+
+    def _layout_arena(self):
+        """Gradient arena in BACKWARD order (heads first, stem last): contiguous all-reduce buckets."""
+        self._slots, self._order = {}, []
+        off = 0
+        for kind, layer, plist in reversed(self.params):
+            n = sum(p.numel() for p in plist)
+            key = self._key(kind, layer)
+            self._slots[key] = (off, n, plist)
+            self._order.append(key)
+            off += n
+        self._arena_numel = off
+
+    def _grad_slot(self, kind, layer):
+        key = self._key(kind, layer)
+        off, n, _ = self._slots[key]
+        self._filled.add(key)
+        return self._arena[off:off + n]
+
+    def _final_prefix(self):
+        """Arena offset below which every slot is either written or belongs to frozen parameters."""
+        while self._cursor < len(self._order):
+            key = self._order[self._cursor]
+            _, _, plist = self._slots[key]
+            if key in self._filled or not any(p.requires_grad for p in plist):
+                self._cursor += 1
+            else:
+                break
+        if self._cursor == len(self._order):
+            return self._arena_numel
+        return self._slots[self._order[self._cursor]][0]
+
+    # ------------------------------------------------------------------ network
+    def forward(self, images, speed, command, training, taping, dtype, base_seed=0):
+        """Returns probs [B,E], mean [B,E,2], std [B,E,2], speeds [B,E,1] (f32) and the tape."""
+        if images.dim() != 5:
+            raise ValueError(f"images: expected [B,T,C,H,W], got {tuple(images.shape)}")
+        if not images.is_cuda:
+            raise RuntimeError("pmoe_amd: inputs must be on the MI355X (cuda) device; there is no CPU path")
+        hip.load()
+        self.dev, self.dtype = images.device, dtype
+        self.training, self.taping = training, taping
+        self.base_seed = int(base_seed)
+        Bsz = images.shape[0]
+        self.B, self.N = Bsz, Bsz * self.E
+        E = self.E
+        self._ensure_built(self.dev, dtype)
+        self._refresh_tables(self.dev)
+        self._pack_all()
+        self.tape, self._bn_touched = [], []
+        self._ws = getattr(self, "_ws", None)
+        if self._ws is not None and self._ws.device != self.dev:
+            self._ws = None
+
+        H, W = images.shape[-2:]
+        cin = images.shape[1] * images.shape[2]
+        if cin != self.conv1.cin:
+            raise ValueError(f"images carry {cin} channels (T*C), the backbone stem expects {self.conv1.cin}")
+        if speed.shape != (Bsz, self.speed_enc["layers"][0].cin) or command.shape != (Bsz, self.cmd_enc["layers"][0].cin):
+            raise ValueError("speed / command shapes do not match the encoders")
+        img = images.reshape(Bsz, cin, H, W).contiguous().float()
+        x0 = Var(self._new(Bsz, H, W, r16(cin)))
+        ops.nchw_to_nhwc(img, x0.t)
+        spd = Var(self._new(Bsz, 1, 1, 16))
+        ops.pad_rows(speed.contiguous().float(), spd.t.view(Bsz, 16))
+        cmd = Var(self._new(Bsz, 1, 1, 16))
+        ops.pad_rows(command.contiguous().float(), cmd.t.view(Bsz, 16))
+
+        feat = Var(self._new(self.N, 1, 1, 1536))
+        # ---- perception stack: ResNet18 body with the ECA stem (backbone.py:63-70, basics.py:79-134)
+        x0s = self._eca(x0, self.eca1, shared=True)
+        z1, st = self._conv_stats(x0s, self.conv1)
+        a1 = self._bn(z1, self.bn_c1, relu=True, stats=st)
+        a1s = self._eca(a1, self.eca2, shared=False)
+        z2, st = self._conv_stats(a1s, self.conv2)
+        a2 = self._bn(z2, self.bn_c2, relu=True, stats=st)
+        a3 = self._bn(a2, self.bn1, relu=True)                 # torchvision bn1 + relu stay after the stem
+        o = self._maxpool(a3)
+        for blk in self.blocks:
+            zA, st = self._conv_stats(o, blk["conv1"])
+            aA = self._bn(zA, blk["bn1"], relu=True, stats=st)
+            zB, st = self._conv_stats(aA, blk["conv2"])
+            idn = o
+            if blk["down"] is not None:
+                zD, std_ = self._conv_stats(o, blk["down"][0])
+                idn = self._bn(zD, blk["down"][1], relu=False, stats=std_)
+            o = self._bn(zB, blk["bn2"], relu=True, res=idn, stats=st)
+        self._gap_to(o, feat, 0)
+        # ---- measurement encoders write straight into their slots of the 1536-d feature (moe.py:88-95)
+        self._mlp(spd, self.speed_enc, out=feat, out_coff=512, in_shared=True)
+        self._mlp(cmd, self.cmd_enc, out=feat, out_coff=1024, in_shared=True)
+        # ---- heads
+        sp = self._mlp(feat, self.speed_pred)
+        af = self._mlp(feat, self.action_feat)
+        if self.alt:
+            head = self._conv(af, self.head)                     # [N,1,1,16]: mean(2) raw-std(2)
+            al = self._mlp(feat, self.alpha_mlp)                 # [N,1,1,16]: col 0 = alpha
+            head5 = self._merge_alt_head(head, al)
+        else:
+            head5 = self._conv(af, self.head)                    # cols 0..3 action_pred, col 4 alpha
+        probs = torch.empty(Bsz, E, dtype=F32, device=self.dev)
+        mean = torch.empty(Bsz, E, 2, dtype=F32, device=self.dev)
+        std = torch.empty(Bsz, E, 2, dtype=F32, device=self.dev)
+        speeds = torch.empty(Bsz, E, 1, dtype=F32, device=self.dev)
+        ops.gate_mixture_fwd(head5.t.view(self.N, 16), sp.t.view(self.N, 16), probs, mean, std, speeds, Bsz, E,
+                             not self.alt)
+        if training and self._bn_touched:
+            torch._foreach_add_([m.num_batches_tracked for l in self._bn_touched for m in l.mods], 1)
+        state = dict(tape=self.tape, tail=(head5, sp, probs), B=self.B, N=self.N, dev=self.dev, dtype=self.dtype)
+        self.tape = None
+        return probs, mean, std, speeds, state
+
+    def _conv_stats(self, x, layer):
+        if self.training and self.fuse_conv_stats:
+            return self._conv(x, layer, bias=False, want_stats=True)
+        return self._conv(x, layer, bias=False), None
+
+    def _merge_alt_head(self, head, al):
+        """moe_alt: alpha comes from its own MLP; place it in column 4 of the head rows (device copy)."""
+        merged = Var(head.t.clone())
+        merged.t.view(self.N, 16)[:, 4] = al.t.view(self.N, 16)[:, 0]
+        merged.needs_grad = head.needs_grad or al.needs_grad
+        if self.taping and merged.needs_grad:
+            def bwd():
+                g = merged.grad
+                if g is None:
+                    return
+                gh = g.clone()
+                gh.view(self.N, 16)[:, 4] = 0
+                head.set_grad(gh)
+                ga = torch.zeros_like(al.t)
+                ga.view(self.N, 16)[:, 0] = g.view(self.N, 16)[:, 4]
+                al.set_grad(ga)
+            self.tape.append(bwd)
+        return merged
+
+    def backward(self, tape_state, dprobs, dmean, dstd, dspeeds):
+        """Run the recorded tape in reverse; returns the flat gradient arena and per-parameter views."""
+        tape, (head5, sp, probs) = tape_state["tape"], tape_state["tail"]
+        self.B, self.N, self.dev, self.dtype = (tape_state[k] for k in ("B", "N", "dev", "dtype"))
+        self._layout_arena()
+        self._arena = torch.zeros(self._arena_numel, dtype=F32, device=self.dev)
+        self._filled, self._cursor = set(), 0
+        reducer = None
+        if self.dp_group is not None or (dist.is_initialized() and self.dp_enabled):
+            reducer = BucketedAllReduce(self.dp_group, self.dp_buckets)
+            reducer.begin(self._arena)
+        dhead = torch.empty_like(head5.t)
+        dspd = torch.empty_like(sp.t)
+
+        def c(t):
+            return t.contiguous().float() if t is not None else None
+        ops.gate_mixture_bwd(head5.t.view(self.N, 16), probs, c(dprobs), c(dmean), c(dstd), c(dspeeds),
+                             dhead.view(self.N, 16), dspd.view(self.N, 16), self.B, self.E, not self.alt)
+        head5.set_grad(dhead)
+        sp.set_grad(dspd)
+        for fn in reversed(tape):
+            fn()
+            if reducer is not None:
+                # every launch of the finished closures is enqueued: buckets below the prefix can fly
+                reducer.ready(self._final_prefix())
+        if reducer is not None:
+            reducer.finish()
+        grads = {}
+        for key, (off, n, plist) in self._slots.items():
+            o = off
+            for p in plist:
+                grads[id(p)] = self._arena[o:o + p.numel()].view_as(p) if key in self._filled else None
+                o += p.numel()
+        return grads

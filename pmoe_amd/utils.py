@@ -1,0 +1,65 @@
+"""Host utilities whose semantics are part of the drop-in boundary (``PMoE/utils/nn.py``, ``utils/utility.py``)."""
+from typing import List
+
+import torch.nn as nn
+import yaml
+
+
+def freeze(model: nn.Module, exclude: List = (), verbose: bool = False) -> nn.Module:
+    """``utils/nn.py:22-58``: set requires_grad=False on every parameter whose NAME contains none of the
+    substrings in ``exclude`` (an empty list freezes everything)."""
+    exclude = list(exclude) if exclude is not None else []
+    frozen = []
+    for name, p in model.named_parameters():
+        if not exclude or not any(tag in name for tag in exclude):
+            p.requires_grad_(False)
+            frozen.append(name)
+    if verbose:
+        total = sum(1 for _ in model.parameters())
+        print(f"{len(frozen)} of {total} parameter tensors have been frozen.")
+    return model
+
+
+class AttrDict(dict):
+    """Attribute-access mapping accepted wherever the reference takes an OmegaConf node: supports
+    ``cfg.key``, ``**cfg.node`` and item assignment (``moe.py:55-66,274``)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    @staticmethod
+    def wrap(obj):
+        if isinstance(obj, dict):
+            return AttrDict({k: AttrDict.wrap(v) for k, v in obj.items()})
+        if isinstance(obj, (list, tuple)):
+            return [AttrDict.wrap(v) for v in obj]
+        return obj
+
+
+def get_conf(name: str):
+    """``utils/utility.py:9-17`` without OmegaConf (not installed here): load a YAML file into AttrDicts."""
+    name = name if name.split(".")[-1] == "yaml" else name + ".yaml"
+    with open(name) as f:
+        return AttrDict.wrap(yaml.safe_load(f))
+
+
+def stage2_model_cfg(model_type="moe", n_experts=4, dropout=0.3, n_commands=6, n_frames=4):
+    """The ``model:`` node of ``conf/stage_2_moe.yaml:76-133`` (defaults as shipped by the reference)."""
+    def mlp(dims, act, l_act=False):
+        return dict(dims=list(dims), act=act, l_act=l_act, bn=False, dropout=dropout)
+
+    return AttrDict.wrap(dict(
+        verbose=False, type=model_type, n_experts=n_experts, loss_coefs=[0.7, 0.3], exclude_freeze=[],
+        action_head=mlp([1536, 512, 512], "elu", True),
+        speed_encoder=mlp([1, 512, 512], "relu"),
+        command_encoder=mlp([n_commands, 512, 512], "relu"),
+        speed_prediction=mlp([1536, 512, 512, 1], "relu"),
+        backbone=dict(type="rgb", n_frames=n_frames, rgb=dict(arch="resnet18", pretrained=False, gamma=2, b=1)),
+        pmoe=dict(moe_dir="", punet_dir=""),
+    ))

@@ -1,0 +1,96 @@
+"""End-to-end parity (-m gpu): the drop-in MixtureOfExperts on cuda:0 through the C-ABI kernels versus
+the golden vectors of the imported reference and the live CPU oracle (tests/parity_util.py)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.parity_util import GOLDEN, build_pair, rel_err, run_parity_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g1_moe_e4_b2_128", "g3_moe_e8_b2_128"])
+def test_train_parity_f32(name):
+    run_parity_case(name, torch.float32, check_grads=True)
+
+
+@pytest.mark.parametrize("name", ["g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g1_moe_e4_b2_128"])
+def test_train_parity_bf16(name):
+    run_parity_case(name, torch.bfloat16, check_grads=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eval_parity_agent_shape(dtype):
+    """image_agent.py:158-159: B=1, 224x224, eval mode, model.sample()."""
+    run_parity_case("g2_moe_e4_b1_224_eval", dtype, check_grads=False)
+    g = torch.load(GOLDEN / "g2_moe_e4_b1_224_eval.pt", weights_only=False)
+    _, _, model, inp = build_pair(g, dtype)
+    with torch.no_grad():
+        a = model.sample(inp["images"].cuda(), inp["speed"].cuda(), inp["command"].cuda())
+    assert a.shape == (1, 2) and torch.isfinite(a).all()
+
+
+def test_fused_and_unfused_bn_stats_agree():
+    g = torch.load(GOLDEN / "g5_moe_e3_b3_96.pt", weights_only=False)
+    outs = []
+    for fuse in (True, False):
+        _, _, model, inp = build_pair(g, torch.float32)
+        model._engine().fuse_conv_stats = fuse
+        with torch.no_grad():
+            outs.append(model.mixture_params(inp["images"].cuda(), inp["speed"].cuda(), inp["command"].cuda()))
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < 1e-5
+
+
+def test_module_contract():
+    """deepcopy (AveragedModel), freeze-by-name, state_dict round trip, frozen parameters get no grads."""
+    from pmoe_amd.loss import moe_loss
+    from pmoe_amd.utils import freeze
+    g = torch.load(GOLDEN / "g4_moealt_e4_b2_64.pt", weights_only=False)
+    ocfg, oracle, model, inp = build_pair(g, torch.float32)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    swa = torch.optim.swa_utils.AveragedModel(model)
+    swa.update_parameters(model)
+    with torch.no_grad():
+        d1, s1 = model(dev["images"], dev["speed"], dev["command"])
+        model.eval(); swa.eval()
+        d2, s2 = swa(dev["images"], dev["speed"], dev["command"])
+        d3, s3 = model(dev["images"], dev["speed"], dev["command"])
+    assert rel_err(s2, s3) < 1e-6
+    model.train()
+    freeze(model, ["alpha", "action_pred"])
+    dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+    moe_loss(dist, speeds, dev["control"], dev["target_speed"], [0.7, 0.3]).backward()
+    for n, p in model.named_parameters():
+        if "alpha" in n or "action_pred" in n:
+            assert p.grad is not None and p.requires_grad, n
+        else:
+            assert p.grad is None, n
+    # generic torch.distributions path (what the reference trainer calls) gives the same loss as the fused kernel
+    for p in model.parameters():
+        p.requires_grad_(True)
+    model.eval()
+    dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+    fused = moe_loss(dist, speeds, dev["control"], dev["target_speed"], [0.7, 0.3])
+    generic = -dist.log_prob(dev["control"]).mean() * 0.7 + 0.3 * torch.nn.functional.mse_loss(
+        speeds, dev["target_speed"].unsqueeze(1).expand_as(speeds)) / speeds.shape[1]
+    assert abs(fused.item() - generic.item()) < 1e-5
+    generic.backward()
+    assert model.moe[0].backbone.layer1[0].conv1.weight.grad is not None
+
+
+def test_dropout_train_mode_runs_and_is_seeded():
+    g = torch.load(GOLDEN / "g4_moealt_e4_b2_64.pt", weights_only=False)
+    _, _, model, inp = build_pair(g, torch.bfloat16, dropout=0.3)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    torch.manual_seed(1)
+    with torch.no_grad():
+        a = model.mixture_params(dev["images"], dev["speed"], dev["command"])
+    torch.manual_seed(1)
+    with torch.no_grad():
+        b = model.mixture_params(dev["images"], dev["speed"], dev["command"])
+    with torch.no_grad():
+        c = model.mixture_params(dev["images"], dev["speed"], dev["command"])
+    # BN running stats do not influence train-mode outputs, so same seed -> same masks -> same outputs
+    assert torch.equal(a[3], b[3]) and not torch.equal(a[3], c[3])

@@ -1,0 +1,410 @@
+"""Per-kernel parity (-m gpu): each C-ABI entry point against a plain PyTorch fp32 CPU reference of
+the same op, called through the same ctypes binding the model uses.
+
+Tolerances: f32 kernels 1e-4 (exact-f32 MFMA chains vs CPU summation order); bf16 kernels 1e-2
+relative to the tensor's scale with the inputs pre-rounded to bf16 (north_star: 1e-4 fp32 / 1e-2 bf16).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from pmoe_amd import hip, ops  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(shape, g, dtype, scale=1.0):
+    x = torch.randn(shape, generator=g) * scale
+    return x.to(dtype).float() if dtype == torch.bfloat16 else x
+
+
+def close(got, ref, dtype, what=""):
+    got = got.float().cpu()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item() / scale
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert err <= tol, f"{what}: rel-to-max err {err:.3e} > {tol} (scale {scale:.3e})"
+
+
+def r16(c):
+    return (c + 15) // 16 * 16
+
+
+def r64(c):
+    return (c + 63) // 64 * 64
+
+
+def nhwc(x, cpad, dtype):
+    """CPU NCHW f32 -> device NHWC padded."""
+    n, c, h, w = x.shape
+    out = torch.zeros(n, h, w, cpad)
+    out[..., :c] = x.permute(0, 2, 3, 1)
+    return out.to(dtype).to(DEV).contiguous()
+
+
+def from_nhwc(t, c):
+    return t.float().cpu()[..., :c].permute(0, 3, 1, 2).contiguous()
+
+
+def pack(ws, ks, dtype, want_dgrad=False):
+    """ws: list (per expert) of CPU f32 [cout,cin,ks,ks] -> packed device tensors via the pack kernel."""
+    E = len(ws)
+    cout, cin = ws[0].shape[:2]
+    dev_ws = [w.to(DEV).contiguous() for w in ws]
+    tab = hip.ptr_table(dev_ws, DEV)
+    coutp, cinp = r64(cout), r16(cin)
+    fwd = torch.empty(E, coutp, ks * ks, cinp, dtype=dtype, device=DEV)
+    dg = None
+    cinp2, coutp2 = r64(cin), r16(cout)
+    if want_dgrad:
+        dg = torch.empty(E, cinp2, ks * ks, coutp2, dtype=dtype, device=DEV)
+    ops.pack_conv_weights(tab, fwd, dg, E, cout, cin, ks, coutp, cinp, cinp2, coutp2, dtype)
+    torch.cuda.synchronize()
+    return fwd, dg, dev_ws
+
+
+CONV_CASES = [
+    # E, ipe, cin, cout, H, W, ks, stride
+    (2, 3, 64, 64, 32, 32, 3, 1),
+    (2, 2, 12, 64, 40, 24, 3, 1),
+    (1, 2, 64, 128, 32, 32, 3, 2),
+    (2, 2, 64, 128, 32, 32, 1, 2),
+    (1, 3, 128, 128, 16, 16, 3, 1),
+    (2, 2, 128, 256, 14, 14, 3, 2),
+    (1, 5, 256, 256, 7, 7, 3, 1),
+    (2, 3, 512, 512, 4, 4, 3, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    E, ipe, cin, cout, H, W, ks, stride = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    pad = ks // 2
+    N = E * ipe
+    x = rnd((N, cin, H, W), g, dtype)
+    ws = [rnd((cout, cin, ks, ks), g, dtype, (2.0 / (cin * ks * ks)) ** 0.5) for _ in range(E)]
+    Ho, Wo = ops.conv_out_size(H, ks, stride, pad), ops.conv_out_size(W, ks, stride, pad)
+    dy = rnd((N, cout, Ho, Wo), g, dtype)
+
+    # reference (CPU fp32 autograd)
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    yr = torch.cat([F.conv2d(xr[e * ipe:(e + 1) * ipe], wr[e], stride=stride, padding=pad) for e in range(E)])
+    yr.backward(dy)
+
+    cinp, coutp = r16(cin), r64(cout)
+    wf, wd, _ = pack(ws, ks, dtype, want_dgrad=True)
+    xd = nhwc(x, cinp, dtype)
+    out = torch.full((N, Ho, Wo, r16(cout)), 7.0, dtype=dtype, device=DEV)
+    rows = ops.conv2d_stat_rows(N, H, W, Ho, Wo, cinp, cout, coutp, ipe, ks, stride, pad, dtype)
+    stats = torch.zeros(rows, 2, coutp, device=DEV)
+    ops.conv2d(xd, wf, out, cin=cinp, cout=cout, coutp=coutp, ipe=ipe, ks=ks, stride=stride, pad=pad, stats=stats)
+    y = from_nhwc(out, cout)
+    close(y, yr.detach(), dtype, "conv fwd")
+    # fused BN partial sums == column sums of the stored output
+    st = stats.view(E, rows // E, 2, coutp).sum(1).cpu()
+    yo = out.float().cpu()[..., :cout].reshape(E, -1, cout)
+    close(st[:, 0, :cout], yo.sum(1), torch.float32 if dtype == torch.float32 else dtype, "fused stats sum")
+    close(st[:, 1, :cout], (yo * yo).sum(1), torch.float32 if dtype == torch.float32 else dtype, "fused stats sumsq")
+
+    # data gradient: stride 1 = conv with flipped weights; stride 2 = dilated source
+    dyd = nhwc(dy, r16(cout), dtype)
+    dx = torch.empty(N, H, W, cinp, dtype=dtype, device=DEV)
+    ops.conv2d(dyd, wd, dx, cin=r16(cout), cout=cinp, coutp=r64(cin), ipe=ipe, ks=ks, stride=1,
+               pad=ks - 1 - pad, dilate=(stride == 2))
+    close(from_nhwc(dx, cin), xr.grad, dtype, "conv dgrad")
+
+    # weight gradient
+    ckw = 64 if dtype == torch.bfloat16 else 32
+    cpw, cow = (cinp + ckw - 1) // ckw * ckw, (r16(cout) + ckw - 1) // ckw * ckw
+    ws_buf = torch.zeros(E, ks * ks, cow, cpw, device=DEV)
+    ops.conv2d_wgrad(xd, dyd, ws_buf, cin=cinp, cout=r16(cout), cinp=cpw, coutp=cow, ipe=ipe, ks=ks, stride=stride, pad=pad)
+    grads = torch.empty(E, cout, cin, ks, ks, device=DEV)
+    ops.unpack_conv_wgrad(ws_buf, grads, E, cout, cin, ks, cow, cpw)
+    for e in range(E):
+        close(grads[e], wr[e].grad, dtype, f"conv wgrad e{e}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_shared_input_and_epilogues(dtype):
+    """in_shared (ECA1-style input read by all experts), bias+ReLU/ELU, residual add, column offsets."""
+    g = torch.Generator().manual_seed(3)
+    E, ipe, K, Nn = 3, 5, 6, 512
+    x = rnd((ipe, K), g, dtype)
+    ws = [rnd((Nn, K, 1, 1), g, dtype, 0.5) for _ in range(E)]
+    bs = [rnd((Nn,), g, torch.float32, 0.3) for _ in range(E)]
+    wf, _, _ = pack(ws, 1, dtype)
+    dev_b = [b.to(DEV) for b in bs]
+    bias = torch.empty(E, r64(Nn), device=DEV)
+    ops.pack_bias(hip.ptr_table(dev_b, DEV), bias, E, Nn, r64(Nn))
+    xd = torch.zeros(ipe, 1, 1, 16, dtype=dtype, device=DEV)
+    xd[:, 0, 0, :K] = x.to(dtype).to(DEV)
+    for act, fn in ((hip.ACT_RELU, torch.relu), (hip.ACT_ELU, F.elu), (hip.ACT_NONE, lambda t: t)):
+        out = torch.zeros(E * ipe, 1, 1, 1536, dtype=dtype, device=DEV)
+        ops.conv2d(xd, wf, out, cin=16, cout=Nn, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, in_shared=True,
+                   out_coff=512, bias=bias, act=act)
+        ref = torch.cat([fn(x @ ws[e][:, :, 0, 0].t() + bs[e]) for e in range(E)])
+        close(out.view(E * ipe, 1536)[:, 512:1024], ref, dtype, f"linear act{act}")
+        assert out.view(E * ipe, 1536)[:, :512].abs().max().item() == 0
+        assert out.view(E * ipe, 1536)[:, 1024:].abs().max().item() == 0
+    # residual add + reading a column slice
+    res = rnd((E * ipe, Nn), g, dtype)
+    resd = res.to(dtype).to(DEV).view(E * ipe, 1, 1, Nn).contiguous()
+    out2 = torch.empty(E * ipe, 1, 1, Nn, dtype=dtype, device=DEV)
+    ops.conv2d(xd, wf, out2, cin=16, cout=Nn, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, in_shared=True,
+               res=resd, res_mode=hip.RES_ADD)
+    ref = torch.cat([x @ ws[e][:, :, 0, 0].t() for e in range(E)]) + res
+    close(out2.view(E * ipe, Nn), ref, dtype, "res add")
+    # activation-derivative epilogues (MLP backward)
+    y_saved = rnd((E * ipe, Nn), g, dtype)
+    ysd = y_saved.to(dtype).to(DEV).view(E * ipe, 1, 1, Nn).contiguous()
+    lin = torch.cat([x @ ws[e][:, :, 0, 0].t() for e in range(E)])
+    out3 = torch.empty_like(out2)
+    ops.conv2d(xd, wf, out3, cin=16, cout=Nn, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, in_shared=True,
+               res=ysd, res_mode=hip.RES_DRELU)
+    close(out3.view(E * ipe, Nn), lin * (y_saved > 0), dtype, "drelu")
+    ops.conv2d(xd, wf, out3, cin=16, cout=Nn, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, in_shared=True,
+               res=ysd, res_mode=hip.RES_DELU)
+    close(out3.view(E * ipe, Nn), lin * torch.where(y_saved > 0, torch.ones_like(y_saved), y_saved + 1), dtype, "delu")
+
+
+def test_dropout_epilogue_statistics():
+    g = torch.Generator().manual_seed(5)
+    E, ipe, K, Nn = 1, 64, 16, 512
+    dtype = torch.float32
+    x = rnd((ipe, K), g, dtype)
+    ws = [rnd((Nn, K, 1, 1), g, dtype, 0.5)]
+    wf, _, _ = pack(ws, 1, dtype)
+    xd = x.to(DEV).view(ipe, 1, 1, K).contiguous()
+    a = torch.empty(ipe, 1, 1, Nn, device=DEV)
+    b = torch.empty_like(a)
+    ops.conv2d(xd, wf, a, cin=16, cout=Nn, coutp=512, ipe=ipe, ks=1, stride=1, pad=0)
+    ops.conv2d(xd, wf, b, cin=16, cout=Nn, coutp=512, ipe=ipe, ks=1, stride=1, pad=0, drop_p=0.3, seed=1234)
+    kept = (b != 0)
+    frac = kept.float().mean().item()
+    assert abs(frac - 0.7) < 0.02, frac
+    torch.testing.assert_close(b[kept], a[kept] / 0.7, rtol=1e-5, atol=1e-6)
+    c = torch.empty_like(a)
+    ops.conv2d(xd, wf, c, cin=16, cout=Nn, coutp=512, ipe=ipe, ks=1, stride=1, pad=0, drop_p=0.3, seed=1234)
+    assert torch.equal(b, c)          # same seed -> same mask
+    ops.conv2d(xd, wf, c, cin=16, cout=Nn, coutp=512, ipe=ipe, ks=1, stride=1, pad=0, drop_p=0.3, seed=99)
+    assert not torch.equal(b, c)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 3, 64, 20, 12), (1, 2, 128, 9, 9), (3, 2, 512, 4, 4)])
+def test_batchnorm_fwd_bwd(shape, dtype):
+    E, ipe, C_, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    N = E * ipe
+    x = (rnd((N, C_, H, W), g, dtype) * 1.5 + 0.3).to(dtype).float()
+    res = rnd((N, C_, H, W), g, dtype)
+    dy = rnd((N, C_, H, W), g, dtype)
+    gam = [1 + 0.1 * torch.randn(C_, generator=g) for _ in range(E)]
+    bet = [0.1 * torch.randn(C_, generator=g) for _ in range(E)]
+    rm = [0.05 * torch.randn(C_, generator=g) for _ in range(E)]
+    rv = [1 + 0.1 * torch.rand(C_, generator=g) for _ in range(E)]
+    # reference
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True)
+    gr = [t.clone().requires_grad_(True) for t in gam]
+    br = [t.clone().requires_grad_(True) for t in bet]
+    rmr, rvr = [t.clone() for t in rm], [t.clone() for t in rv]
+    yr = torch.cat([torch.relu(F.batch_norm(xr[e * ipe:(e + 1) * ipe], rmr[e], rvr[e], gr[e], br[e], True, 0.1, 1e-5)
+                               + rr[e * ipe:(e + 1) * ipe]) for e in range(E)])
+    yr.backward(dy)
+    # device
+    xd, resd, dyd = nhwc(x, C_, dtype), nhwc(res, C_, dtype), nhwc(dy, C_, dtype)
+    dg, db, drm, drv = ([t.to(DEV) for t in l] for l in (gam, bet, rm, rv))
+    tabs = [hip.ptr_table(l, DEV) for l in (dg, db, drm, drv)]
+    rpe = ipe * H * W
+    nparts = 4
+    part = torch.empty(E, nparts, 2, C_, device=DEV)
+    ops.colstats(rpe, xd, E, C_, part, nparts)
+    part2 = torch.empty(E, 2, 2, C_, device=DEV)
+    ops.reduce_partials(part, part2, E, nparts, 2, 2 * C_)
+    scale, shift, mean, invstd = (torch.empty(E, C_, device=DEV) for _ in range(4))
+    ops.bn_finalize(part2, 2, rpe, tabs[0], tabs[1], tabs[2], tabs[3], 0.1, 1e-5, True, scale, shift, mean, invstd, E, C_)
+    y = torch.empty_like(xd)
+    ops.bn_apply(xd, resd, y, scale, shift, rpe, E, C_, True)
+    close(from_nhwc(y, C_), yr.detach(), dtype, "bn fwd")
+    for e in range(E):
+        close(drm[e], rmr[e], torch.float32, "running_mean")
+        close(drv[e], rvr[e], torch.float32, "running_var")
+    # backward
+    bpart = torch.empty(E, nparts, 2, C_, device=DEV)
+    ops.bn_bwd_reduce(dyd, y, xd, mean, invstd, rpe, E, C_, True, bpart, nparts)
+    dgam, dbet, c1, c2 = (torch.empty(E, C_, device=DEV) for _ in range(4))
+    ops.bn_bwd_finalize(bpart, nparts, rpe, dgam, dbet, c1, c2, E, C_)
+    dx, gm = torch.empty_like(xd), torch.empty_like(xd)
+    ops.bn_bwd_apply(dyd, y, xd, mean, invstd, scale, c1, c2, dx, gm, rpe, E, C_, True)
+    close(from_nhwc(dx, C_), xr.grad, dtype, "bn dx")
+    close(from_nhwc(gm, C_), rr.grad, dtype, "bn residual grad")
+    for e in range(E):
+        close(dgam[e], gr[e].grad, dtype, "dgamma")
+        close(dbet[e], br[e].grad, dtype, "dbeta")
+    # eval mode: scale/shift from running buffers
+    ops.bn_finalize(part2, 2, rpe, tabs[0], tabs[1], tabs[2], tabs[3], 0.1, 1e-5, False, scale, shift, mean, invstd, E, C_)
+    ops.bn_apply(xd, None, y, scale, shift, rpe, E, C_, False)
+    yev = torch.cat([F.batch_norm(x[e * ipe:(e + 1) * ipe], rmr[e], rvr[e], gam[e], bet[e], False, 0.1, 1e-5)
+                     for e in range(E)])
+    close(from_nhwc(y, C_), yev, dtype, "bn eval")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw", [(16, 16), (13, 9)])
+def test_maxpool(hw, dtype):
+    g = torch.Generator().manual_seed(2)
+    N, C_ = 3, 64
+    H, W = hw
+    x = torch.relu(rnd((N, C_, H, W), g, dtype))       # post-ReLU input as in the model: many exact ties at 0
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = rnd(tuple(yr.shape), g, dtype)
+    yr.backward(dy)
+    xd = nhwc(x, C_, dtype)
+    Ho, Wo = yr.shape[-2:]
+    y = torch.empty(N, Ho, Wo, C_, dtype=dtype, device=DEV)
+    am = torch.empty(N, Ho, Wo, C_, dtype=torch.uint8, device=DEV)
+    ops.maxpool_fwd(xd, y, am)
+    close(from_nhwc(y, C_), yr.detach(), dtype, "maxpool fwd")
+    dx = torch.empty_like(xd)
+    ops.maxpool_bwd(nhwc(dy, C_, dtype), am, dx)
+    # ties at zero may route differently; compare where the input is positive (the ReLU mask upstream kills the rest)
+    got, ref = from_nhwc(dx, C_), xr.grad
+    m = x > 0
+    close(got * m, ref * m, dtype, "maxpool bwd")
+    assert abs(got.sum().item() - ref.sum().item()) <= 1e-2 * ref.abs().sum().item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(12, True), (64, False)])
+def test_eca(cfg, dtype):
+    creal, shared = cfg
+    g = torch.Generator().manual_seed(4)
+    E, ipe, H, W = 2, 3, 10, 6
+    C_ = r16(creal)
+    N = E * ipe
+    k = 3
+    nx = ipe if shared else N
+    x = rnd((nx, creal, H, W), g, dtype)
+    wk = [0.5 * torch.randn(1, 1, k, generator=g) for _ in range(E)]
+    dy = rnd((N, creal, H, W), g, dtype)
+
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in wk]
+    outs = []
+    for e in range(E):
+        xe = xr if shared else xr[e * ipe:(e + 1) * ipe]
+        gmean = xe.mean(dim=(2, 3))
+        s = torch.sigmoid(F.conv1d(gmean.unsqueeze(1), wr[e], padding=k // 2).squeeze(1))
+        outs.append(xe * s[:, :, None, None])
+    yr = torch.cat(outs)
+    yr.backward(dy)
+
+    xd = nhwc(x, C_, dtype)
+    dwk = [w.to(DEV).contiguous() for w in wk]
+    wtab = hip.ptr_table(dwk, DEV)
+    nparts = 3
+    part = torch.empty(nx, nparts, C_, device=DEV)
+    ops.gap_partial(xd, None, part, nparts)
+    gate = torch.empty(N, C_, device=DEV)
+    gapmean = torch.empty(N, C_, device=DEV)
+    ops.eca_gate(part, nparts, H * W, wtab, k, gate, gapmean, N, ipe, ipe if shared else 0, C_, creal)
+    y = torch.empty(N, H, W, C_, dtype=dtype, device=DEV)
+    ops.eca_scale(xd, gate, y, ipe if shared else 0)
+    close(from_nhwc(y, creal), yr.detach(), dtype, "eca fwd")
+    # backward
+    dyd = nhwc(dy, C_, dtype)
+    dot = torch.empty(N, nparts, C_, device=DEV)
+    ops.gap_partial(dyd, xd, dot, nparts, ipe if shared else 0)
+    dgap = torch.empty(N, C_, device=DEV)
+    dw = torch.empty(E, k, device=DEV)
+    ops.eca_bwd_small(dot, nparts, gate, gapmean, wtab, k, dgap, dw, N, ipe, C_, creal)
+    for e in range(E):
+        close(dw[e], wr[e].grad.flatten(), dtype, "eca dw")
+    if not shared:
+        dx = torch.empty_like(xd)
+        ops.eca_bwd_apply(dyd, gate, dgap, dx)
+        close(from_nhwc(dx, creal), xr.grad, dtype, "eca dx")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gap_and_layout(dtype):
+    g = torch.Generator().manual_seed(6)
+    N, C_, H, W = 4, 512, 4, 4
+    x = rnd((N, C_, H, W), g, dtype)
+    xd = nhwc(x, C_, dtype)
+    part = torch.empty(N, 2, C_, device=DEV)
+    ops.gap_partial(xd, None, part, 2)
+    feat = torch.zeros(N, 1536, dtype=dtype, device=DEV)
+    ops.gap_finish(part, feat, N, C_, 2, H * W, 1536, 0)
+    close(feat[:, :512], x.mean(dim=(2, 3)), dtype, "gap fwd")
+    dfe = rnd((N, 1536), g, dtype)
+    dfd = dfe.to(dtype).to(DEV)
+    dx = torch.empty_like(xd)
+    ops.gap_bwd(dfd, dx, 1536, 0)
+    close(from_nhwc(dx, C_), (dfe[:, :512] / (H * W))[:, :, None, None].expand(N, C_, H, W), dtype, "gap bwd")
+    img = torch.rand(3, 12, 9, 7, generator=g)
+    dst = torch.empty(3, 9, 7, 16, dtype=dtype, device=DEV)
+    ops.nchw_to_nhwc(img.to(DEV), dst)
+    close(from_nhwc(dst, 12), img.to(dtype).float(), dtype, "nchw->nhwc")
+    assert dst[..., 12:].abs().max().item() == 0
+    sp = torch.rand(5, 6, generator=g)
+    pd = torch.empty(5, 16, dtype=dtype, device=DEV)
+    ops.pad_rows(sp.to(DEV), pd)
+    close(pd[:, :6], sp.to(dtype).float(), dtype, "pad_rows")
+    assert pd[:, 6:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("E", [3, 4, 8])
+@pytest.mark.parametrize("alpha_relu", [True, False])
+def test_gate_mixture_and_loss(E, alpha_relu, dtype):
+    import torch.distributions as D
+    g = torch.Generator().manual_seed(E)
+    B = 37
+    head = rnd((E * B, 16), g, dtype)
+    spd = rnd((E * B, 16), g, dtype)
+    act = torch.rand(B, 2, generator=g) * 2 - 1
+    tgt = torch.rand(B, 1, generator=g)
+    hr = head.clone().requires_grad_(True)
+    sr = spd.clone().requires_grad_(True)
+    h3 = hr.view(E, B, 16).permute(1, 0, 2)
+    alpha = torch.relu(h3[..., 4]) if alpha_relu else h3[..., 4]
+    probs_r = torch.softmax(alpha, dim=1)
+    mean_r = h3[..., 0:2]
+    std_r = F.elu(h3[..., 2:4]) + 1
+    speeds_r = sr.view(E, B, 16).permute(1, 0, 2)[..., 0:1]
+    dist = D.MixtureSameFamily(D.Categorical(probs_r), D.Independent(D.Normal(mean_r, std_r), 1))
+    nll = -dist.log_prob(act).mean()
+    loss_r = 0.7 * nll + 0.3 * F.mse_loss(speeds_r, tgt.unsqueeze(1).expand_as(speeds_r)) / E
+    loss_r.backward()
+
+    hd, sd_ = head.to(dtype).to(DEV), spd.to(dtype).to(DEV)
+    probs = torch.empty(B, E, device=DEV)
+    mean = torch.empty(B, E, 2, device=DEV)
+    std = torch.empty(B, E, 2, device=DEV)
+    speeds = torch.empty(B, E, 1, device=DEV)
+    ops.gate_mixture_fwd(hd, sd_, probs, mean, std, speeds, B, E, alpha_relu)
+    close(probs, probs_r.detach(), torch.float32, "probs")
+    close(std, std_r.detach(), torch.float32, "std")
+    loss = torch.empty(1, device=DEV)
+    ll = torch.empty(B, device=DEV)
+    dp, dm, ds, dsp = torch.empty_like(probs), torch.empty_like(mean), torch.empty_like(std), torch.empty_like(speeds)
+    ops.moe_loss(probs, mean, std, speeds, act.to(DEV), tgt.to(DEV), 0.7, 0.3, loss, ll, dp, dm, ds, dsp, B, E)
+    assert abs(loss.item() - loss_r.item()) <= 2e-5 * max(1, abs(loss_r.item()))
+    close(ll, dist.log_prob(act).detach(), torch.float32, "loglik")
+    dhead = torch.empty_like(hd)
+    dspd = torch.empty_like(sd_)
+    ops.gate_mixture_bwd(hd, probs, dp, dm, ds, dsp, dhead, dspd, B, E, alpha_relu)
+    tol_dt = torch.float32 if dtype == torch.float32 else dtype
+    close(dhead, hr.grad, tol_dt, "dhead")
+    close(dspd, sr.grad, tol_dt, "dspd")
