@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: samples/sec, forward + moe_loss + backward (+ gradient all-reduce for N > 1),
+4-expert MixtureOfExperts ("PMoE" experts), 256x256 RGB x 4 frames, batch 64 per GPU, bf16.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One process per GPU; weak scaling (64 samples per GPU); inputs are synthetic, resident in HBM before
+the timed region; rank 0 prints ONE JSON line.  A "step" = zero_grad + forward + moe_loss + backward
+(incl. the bucketed RCCL all-reduce).  The full reference step recipe (clip_grad_norm_ 1.0 + Adam
+amsgrad, train_2.py:157-165) is timed separately and reported as `h1_step`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work per sample (SURVEY.md section 8d / BASELINE.md section 3), E=4, 256x256
+MAC_FWD_PER_EXPERT_SAMPLE_256 = 11.7299e9
+HBM_BYTES_PER_SAMPLE_E4_256_BF16 = 787e6
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--experts", type=int, default=4)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dropout", type=float, default=0.3, help="stage_2*.yaml value")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    return ap.parse_args()
+
+
+def make_batch(B, size, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(B, 4, 3, size, size, generator=g)
+    speed = torch.rand(B, 1, generator=g)
+    target = torch.rand(B, 1, generator=g)
+    command = torch.nn.functional.one_hot(torch.randint(0, 6, (B,), generator=g), 6).float()
+    control = torch.rand(B, 2, generator=g) * 2 - 1
+    return [t.to(device) for t in (images, speed, command, control, target)]
+
+
+def cpu_baseline(args):
+    """The CPU oracle (oracle/pmoe_oracle.py, a port of the reference path checked against goldens of the
+    imported reference) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import pmoe_oracle as O
+    from oracle import weights as W
+    n = os.cpu_count() or 1
+    torch.set_num_threads(n)
+    Bc = 4
+    model = O.get_model(O.stage2_cfg("moe", args.experts, dropout=0.0))
+    model.train()
+    inp = W.make_inputs(Bc, args.size, args.size, seed=7)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        d, s = model(inp["images"], inp["speed"], inp["command"])
+        O.moe_loss(d, s, inp["control"], inp["target_speed"], [0.7, 0.3]).backward()
+
+    small = W.make_inputs(1, 64, 64, seed=7)
+    d, s = model(small["images"], small["speed"], small["command"])       # thread-pool / allocator warm-up
+    O.moe_loss(d, s, small["control"], small["target_speed"], [0.7, 0.3]).backward()
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 2 or (time.perf_counter() - t0 < 12 and iters < 6):
+        step()
+        iters += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc * iters / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{iters} x (fwd+moe_loss+bwd) at batch {Bc}, {args.size}x{args.size}, "
+            f"E={args.experts}, fp32, torch {torch.__version__} CPU"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pmoe_amd import hip, ops
+    from pmoe_amd.loss import moe_loss
+    from pmoe_amd.model.moe import get_model
+    from pmoe_amd.utils import stage2_model_cfg
+    hip.load()
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = get_model(stage2_model_cfg("moe", args.experts, dropout=args.dropout)).to(dev)
+    model.compute_dtype = dtype
+    model.train()
+    if world > 1:
+        # identical replicas: broadcast rank 0's random init
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+        model.enable_data_parallel()
+    images, speed, command, control, target = make_batch(args.batch, args.size, 1234 + rank, dev)
+    coefs = [0.7, 0.3]
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        d, s = model(images, speed, command)
+        loss = moe_loss(d, s, control, target, coefs)
+        loss.backward()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms = elapsed / args.steps * 1e3
+    total_samples = args.batch * world * args.steps
+    value = total_samples / elapsed
+
+    out = {
+        "metric": "samples/sec fwd+bwd, 256x256 RGB 4-expert PMoE", "value": round(value, 2), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.experts}-expert MoE (PMoE experts), {args.size}x{args.size}x3 x4 frames, "
+                               f"batch {args.batch}/GPU, fwd+moe_loss+bwd, dropout {args.dropout}",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+        "loss": round(float(loss.item()), 5),
+    }
+
+    if rank == 0:
+        # ---- whole-step rooflines from the algorithmic work model
+        scale = (args.size / 256.0) ** 2 * args.experts / 4.0
+        flop_per_sample = 6 * MAC_FWD_PER_EXPERT_SAMPLE_256 * 4 * scale
+        out["step_mfma_frac"] = round(flop_per_sample * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)
+        out["step_hbm_frac_model"] = round(HBM_BYTES_PER_SAMPLE_E4_256_BF16 * scale * value / world / 1e9 / PEAK_HBM_GBS, 4)
+
+    # ---- per-kernel timing with HIP events on the launch stream (one instrumented step, untimed region)
+    if rank == 0 and not args.no_kernel_profile:
+        ops.profile_begin()
+        step()
+        torch.cuda.synchronize()
+        recs = ops.profile_end()
+        by = {}
+        for name, meta, ms_k in recs:
+            k = by.setdefault(name, {"ms": 0.0, "n": 0, "flop": 0.0, "bytes": 0.0})
+            k["ms"] += ms_k
+            k["n"] += 1
+            k["flop"] += meta.get("flop", 0.0)
+            k["bytes"] += meta.get("bytes", 0.0)
+        tot = sum(v["ms"] for v in by.values())
+        out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}
+        out["kernel_ms_total"] = round(tot, 3)
+        dom = by.get("conv2d")
+        if dom and dom["ms"] > 0:
+            achieved = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+            traffic = None
+            tf = REPO / "profiles" / "traffic.json"
+            if tf.exists():
+                traffic = json.loads(tf.read_text()).get("conv_igemm_bytes_per_launch")
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd + dgrad convs, grouped GEMMs)",
+                               "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
+                               "unit": "TFLOP/s",
+                               "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
+                               "traffic": traffic, "launches_per_step": dom["n"],
+                               "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
+                               "flop_per_launch": dom["flop"] / dom["n"]}
+        wg = by.get("conv2d_wgrad")
+        if wg and wg["ms"] > 0:
+            out["wgrad_tflops"] = round(wg["flop"] / (wg["ms"] * 1e-3) / 1e12, 2)
+
+    # ---- reference step recipe H1 (train_2.py:157-165): + clip_grad_norm_(1.0) + Adam(amsgrad)
+    if rank == 0 or world > 1:
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
+
+        def h1():
+            d, s = model(images, speed, command)
+            loss = moe_loss(d, s, control, target, coefs)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+        h1()
+        fence()
+        t0 = time.perf_counter()
+        n_h1 = max(2, min(5, args.steps))
+        for _ in range(n_h1):
+            h1()
+        fence()
+        out["h1_step"] = {"ms_per_step": round((time.perf_counter() - t0) / n_h1 * 1e3, 3),
+                          "what": "fwd+moe_loss+bwd+clip_grad_norm_(1.0)+Adam(amsgrad) (torch optimizer kernels)"}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,20 +44,18 @@ class _GroupFn(torch.autograd.Function):
     """The whole grouped network as one autograd node (inputs: the flat parameter list)."""
 
     @staticmethod
-    def forward(ctx, engine, images, speed, command, training, dtype, seed, *params):
-        taping = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, engine, images, speed, command, training, dtype, seed, taping, *params):
         probs, mean, std, speeds, state = engine.forward(images, speed, command, training, taping, dtype, seed)
         ctx.engine, ctx.state = engine, state
         ctx.param_ids = [id(p) for p in params]
-        ctx.mark_non_differentiable()
         return probs, mean, std, speeds
 
     @staticmethod
     def backward(ctx, dprobs, dmean, dstd, dspeeds):
         grads = ctx.engine.backward(ctx.state, dprobs, dmean, dstd, dspeeds)
         ctx.state = None
-        out = [grads.get(i) if need else None for i, need in zip(ctx.param_ids, ctx.needs_input_grad[7:])]
-        return (None,) * 7 + tuple(out)
+        out = [grads.get(i) if need else None for i, need in zip(ctx.param_ids, ctx.needs_input_grad[8:])]
+        return (None,) * 8 + tuple(out)
 
 
 class _Grouped(nn.Module):
@@ -91,7 +89,9 @@ class _Grouped(nn.Module):
         eng = self._engine()
         dtype = self.compute_dtype or _DEFAULT_DTYPE
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if self.training else 0
-        return _GroupFn.apply(eng, images, speed, command, self.training, dtype, seed, *eng.flat_params)
+        # grad mode is off inside Function.forward, so decide here whether a backward tape is needed
+        taping = torch.is_grad_enabled() and any(p.requires_grad for p in eng.flat_params)
+        return _GroupFn.apply(eng, images, speed, command, self.training, dtype, seed, taping, *eng.flat_params)
 
     def enable_data_parallel(self, group=None, n_buckets=6):
         """Average parameter gradients over ``group`` (default WORLD) inside backward, bucketed and

@@ -230,3 +230,56 @@ def moe_loss(probs, mean, std, speeds, actions, target, c0, c1, loss, loglik, dp
                                float(c0), float(c1), ptr(loss, "loss", f32), ptr(loglik, "loglik", f32),
                                ptr(dprobs, "dprobs", f32), ptr(dmean, "dmean", f32), ptr(dstd, "dstd", f32),
                                ptr(dspeeds, "dspeeds", f32), B, E, stream_ptr()), "pmoe_moe_loss")
+
+
+# ---------------------------------------------------------------------------------------------------
+# Optional per-launch timing with HIP events on the launch stream (used by bench.py for the roofline
+# object and the per-kernel breakdown; off by default -> zero overhead besides one `is None` test).
+import functools as _functools
+
+_prof = None
+_next_meta = {}
+
+
+def set_meta(**kw):
+    """Algorithmic work (flop=..., bytes=...) of the NEXT launch, recorded only while profiling."""
+    global _next_meta
+    if _prof is not None:
+        _next_meta = kw
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """-> [(op name, meta dict, milliseconds)] for every launch since profile_begin()."""
+    global _prof
+    recs, _prof = _prof, None
+    torch.cuda.synchronize()
+    return [(n, m, e0.elapsed_time(e1)) for n, m, e0, e1 in recs]
+
+
+def _timed(fn):
+    @_functools.wraps(fn)
+    def wrapper(*a, **k):
+        global _next_meta
+        if _prof is None:
+            return fn(*a, **k)
+        meta, _next_meta = _next_meta, {}
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        _prof.append((fn.__name__, meta, e0, e1))
+        return r
+    return wrapper
+
+
+for _n in ("conv2d", "conv2d_wgrad", "pack_conv_weights", "unpack_conv_wgrad", "pack_bias", "colstats",
+           "reduce_partials", "bn_finalize", "bn_apply", "bn_bwd_reduce", "bn_bwd_finalize", "bn_bwd_apply",
+           "maxpool_fwd", "maxpool_bwd", "gap_partial", "gap_finish", "gap_bwd", "eca_gate", "eca_scale",
+           "eca_bwd_small", "eca_bwd_apply", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",
+           "moe_loss"):
+    globals()[_n] = _timed(globals()[_n])
