@@ -89,6 +89,7 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -131,9 +132,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    log("model + inputs resident; warm-up")
+    for i in range(args.warmup):
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     fence()
+    log("timing")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -165,6 +175,7 @@ def main():
         out["step_hbm_frac_model"] = round(HBM_BYTES_PER_SAMPLE_E4_256_BF16 * scale * value / world / 1e9 / PEAK_HBM_GBS, 4)
 
     # ---- per-kernel timing with HIP events on the launch stream (one instrumented step, untimed region)
+    log(f"timed: {ms:.2f} ms/step")
     if rank == 0 and not args.no_kernel_profile:
         ops.profile_begin()
         step()
@@ -209,6 +220,7 @@ def main():
             loss.backward()
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
             opt.step()
+        log("kernel profile done; H1 step")
         h1()
         fence()
         t0 = time.perf_counter()
@@ -219,6 +231,7 @@ def main():
         out["h1_step"] = {"ms_per_step": round((time.perf_counter() - t0) / n_h1 * 1e3, 3),
                           "what": "fwd+moe_loss+bwd+clip_grad_norm_(1.0)+Adam(amsgrad) (torch optimizer kernels)"}
 
+    log("H1 done; CPU baseline")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -588,6 +588,7 @@ class ExpertGroupEngine:
         self._refresh_tables(self.dev)
         self._pack_all()
         self.tape, self._bn_touched = [], []
+        self._seed_counter = itertools.count(1)       # dropout masks are a function of (base_seed, layer order)
         self._ws = getattr(self, "_ws", None)
         if self._ws is not None and self._ws.device != self.dev:
             self._ws = None

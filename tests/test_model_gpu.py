@@ -53,7 +53,6 @@ def test_module_contract():
     swa = torch.optim.swa_utils.AveragedModel(model)
     swa.update_parameters(model)
     with torch.no_grad():
-        d1, s1 = model(dev["images"], dev["speed"], dev["command"])
         model.eval(); swa.eval()
         d2, s2 = swa(dev["images"], dev["speed"], dev["command"])
         d3, s3 = model(dev["images"], dev["speed"], dev["command"])
