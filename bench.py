@@ -61,7 +61,12 @@ def cpu_baseline(args):
     imported reference) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import pmoe_oracle as O
     from oracle import weights as W
-    n = os.cpu_count() or 1
+    # the box grants one GPU a 16-CPU share; os.cpu_count() reports the whole host and oversubscribes
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, 16))
     torch.set_num_threads(n)
     Bc = 4
     model = O.get_model(O.stage2_cfg("moe", args.experts, dropout=0.0))
