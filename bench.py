@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.3, help="stage_2*.yaml value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="per-layer launch table on stderr")
     return ap.parse_args()
 
 
@@ -186,6 +187,17 @@ def main():
         step()
         torch.cuda.synchronize()
         recs = ops.profile_end()
+        if args.detail:
+            agg = {}
+            for name, meta, ms_k in recs:
+                key = (name, meta.get("name", ""))
+                a = agg.setdefault(key, [0.0, 0, 0.0])
+                a[0] += ms_k
+                a[1] += 1
+                a[2] += meta.get("flop", 0.0)
+            for (name, lname), (ms_k, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+                tf = fl / (ms_k * 1e-3) / 1e12 if ms_k > 0 and fl else 0.0
+                print(f"  {name:18s} {lname:24s} n={n:3d} {ms_k:8.3f} ms  {tf:8.1f} TF/s", file=sys.stderr)
         by = {}
         for name, meta, ms_k in recs:
             k = by.setdefault(name, {"ms": 0.0, "n": 0, "flop": 0.0, "bytes": 0.0})

@@ -316,7 +316,7 @@ class ExpertGroupEngine:
             stats = torch.empty(rows, 2, layer.coutp, dtype=F32, device=self.dev)
         seed = (next(self._seed_counter) * 0x9E3779B1 + self.base_seed) & 0xFFFFFFFFFFFF if drop_p > 0 else 0
         flop = 2.0 * self.N * Ho * Wo * layer.cout * layer.cin * layer.taps
-        ops.set_meta(flop=flop)
+        ops.set_meta(flop=flop, name=layer.name)
         ops.conv2d(x.t, layer.w_fwd, o.t, cin=layer.cinp, cout=layer.cout_st, coutp=layer.coutp, ipe=self.B,
                    ks=layer.ks, stride=layer.stride, pad=layer.pad, in_shared=in_shared, in_coff=x.coff,
                    out_coff=o.coff, bias=layer.bias_packed if bias else None, act=act, drop_p=drop_p, seed=seed,
@@ -342,7 +342,7 @@ class ExpertGroupEngine:
             cow = (layer.cout_st + ckw - 1) // ckw * ckw
             ws = self._wgrad_ws(E * layer.taps * cow * cpw)
             ws.zero_()
-            ops.set_meta(flop=flop)
+            ops.set_meta(flop=flop, name=layer.name)
             ops.conv2d_wgrad(x.t, dy, ws, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B,
                              ks=layer.ks, stride=layer.stride, pad=layer.pad, x_shared=in_shared, x_coff=x.coff,
                              dy_coff=o.coff)
@@ -374,7 +374,7 @@ class ExpertGroupEngine:
             elif prev is not None:
                 res, res_mode = prev, hip.RES_ADD       # second consumer: accumulate in the epilogue
             g = prev if prev is not None else torch.empty_like(x.t)
-            ops.set_meta(flop=flop)
+            ops.set_meta(flop=flop, name=layer.name + ":dgrad")
             ops.conv2d(dy, layer.w_dg, g, cin=layer.dg_red, cout=layer.cinp, coutp=layer.dg_rows, ipe=self.B,
                        ks=layer.ks, stride=1, pad=layer.ks - 1 - layer.pad, dilate=(layer.stride == 2),
                        in_coff=o.coff, out_coff=x.coff, res=res, res_coff=x.coff, res_mode=res_mode,

