@@ -1,0 +1,75 @@
+"""CPU-side host logic: state_dict contract against the reference goldens, freeze-by-name, config helpers,
+deepcopy (AveragedModel), loud failure without the device."""
+import copy
+
+import pytest
+import torch
+
+from pmoe_amd.model import blocks as B
+from pmoe_amd.model.moe import MixtureOfExperts, get_model
+from pmoe_amd.utils import AttrDict, freeze, stage2_model_cfg
+
+
+def _g(golden_dir, name):
+    return torch.load(golden_dir / f"{name}.pt", weights_only=False)
+
+
+@pytest.mark.parametrize("name,typ,E", [("g1_moe_e4_b2_128", "moe", 4), ("g3_moe_e8_b2_128", "moe", 8),
+                                        ("g4_moealt_e4_b2_64", "moe_alt", 4), ("g5_moe_e3_b3_96", "moe", 3)])
+def test_state_dict_keys_match_reference(golden_dir, name, typ, E):
+    g = _g(golden_dir, name)
+    m = get_model(stage2_model_cfg(typ, E, dropout=0.0))
+    sd = m.state_dict()
+    assert list(sd.keys()) == g["state_dict_keys"]
+    assert [tuple(v.shape) for v in sd.values()] == g["state_dict_shapes"]
+
+
+def test_mlp_layouts_match_reference(golden_dir):
+    g = _g(golden_dir, "micro")
+    for (bn, p, dims), keys in g["mlp_layouts"].items():
+        assert list(B.make_mlp(list(dims), "relu", False, bn, p).state_dict().keys()) == keys
+    for c, k in g["eca_k"].items():
+        assert B.eca_kernel_size(c) == k
+
+
+def test_get_model_errors_like_reference():
+    with pytest.raises(ValueError, match="UNKNOWN"):
+        get_model(AttrDict(type="nope"))
+    with pytest.raises(NotImplementedError):
+        get_model(stage2_model_cfg("pmoe", 4))
+
+
+def test_freeze_semantics():
+    m = get_model(stage2_model_cfg("moe", 2, dropout=0.3))
+    freeze(m, ["alpha", "lat_weights"])
+    for n, p in m.named_parameters():
+        assert p.requires_grad == ("alpha" in n), n
+    freeze(m, [])
+    assert not any(p.requires_grad for p in m.parameters())
+
+
+def test_deepcopy_and_engine_grouping():
+    m = get_model(stage2_model_cfg("moe", 3, dropout=0.0))
+    eng = m._engine()
+    assert eng.E == 3 and sum(p.numel() for p in eng.flat_params) == sum(p.numel() for p in m.parameters())
+    assert len({id(p) for p in eng.flat_params}) == len(list(m.parameters()))
+    m2 = copy.deepcopy(m)
+    assert "_eng" not in m2.__dict__ and "_eng" in m.__dict__
+    assert m2._engine() is not eng
+    swa = torch.optim.swa_utils.AveragedModel(m)
+    assert isinstance(swa.module, MixtureOfExperts)
+
+
+def test_cpu_inputs_fail_loudly():
+    m = get_model(stage2_model_cfg("moe", 2, dropout=0.0))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 4, 3, 32, 32), torch.zeros(1, 1), torch.zeros(1, 6))
+    with pytest.raises(RuntimeError, match="parameter container"):
+        m.moe[0].speed_encoder(torch.zeros(1, 1))
+
+
+def test_product_never_imports_the_oracle():
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parents[1] / "pmoe_amd"
+    for f in root.rglob("*.py"):
+        assert "oracle" not in f.read_text(), f
