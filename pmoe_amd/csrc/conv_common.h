@@ -12,6 +12,14 @@ template <int LOG_RB, int MODE> __device__ __forceinline__ int swz_chunk(int x) 
     return ((x >> 1) & 1) << (LOG_RB - 5);
 }
 
+// byte offset of 16-byte chunk j of patch pixel pp.  MODE 2 (weight-gradient kernel): no swizzle, pixel rows
+// padded from 128 to 192 bytes -- 4 consecutive pixels x 64 B (one ds_read_b64_tr_b16 block) then fall in 4
+// different 64-byte bank ranges (0,192,128,64 mod 256), and a tap shift is ONE wave-uniform add.
+template <int LOG_RB, int MODE> __device__ __forceinline__ int lds_chunk_off(int pp, int j) {
+    if (MODE == 2) return pp * 192 + (j << 4);
+    return (pp << LOG_RB) + ((j ^ swz_chunk<LOG_RB, MODE>(pp)) << 4);
+}
+
 struct PatchGeom {
     int n0, n_end, e_first_img;   // first image of the tile, one-past-last image of the expert, e*ipe
     int Y0, X0;                   // source coordinate of patch pixel (0,0)
@@ -68,3 +76,59 @@ __device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const 
             if (dst[u] >= 0) *reinterpret_cast<v4i*>(patch + dst[u]) = v[u];
     }
 }
+
+// Split-phase variant (T14 "issue early / write late"): issue() puts every 16-byte load of one
+// patch in flight into registers; commit() writes them to LDS later (after the MFMA phase that hid
+// their latency and the barrier that retired the previous patch's readers).  MAXV bounds the loads
+// per thread (NPIX * CPR <= MAXV * NTHR, checked by the launcher).
+template <typename T, int LOG_RB, int NTHR, int MAXV>
+struct PatchStage {
+    static constexpr int RB = 1 << LOG_RB, CPR = RB / 16, LOG_CPR = LOG_RB - 4;
+    static constexpr int PSTEP = NTHR / CPR;
+    static constexpr int VE = 16 / (int)sizeof(T);
+    v4i v[MAXV];
+
+    __device__ __forceinline__ void issue(const T* in, const PatchGeom& g, int c0, int tid) {
+        const int pj = tid & (CPR - 1);
+        int pp = tid >> LOG_CPR;
+        int ix = pp % g.PW;
+        const int row = pp / g.PW;
+        int iy = row % g.PH, pn = row / g.PH;
+        const bool cok = (c0 + pj * VE) < g.cmax;
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u) {
+            v[u] = v4i{0, 0, 0, 0};
+            if (pp < g.NPIX) {
+                const int n = g.n0 + pn;
+                int Y = g.Y0 + iy, X = g.X0 + ix;
+                bool ok = cok && n < g.n_end;
+                if (g.dilate) {
+                    ok = ok && Y >= 0 && X >= 0 && !((Y | X) & 1);
+                    Y >>= 1; X >>= 1;
+                    ok = ok && Y < g.H && X < g.W;
+                } else {
+                    ok = ok && (unsigned)Y < (unsigned)g.H && (unsigned)X < (unsigned)g.W;
+                }
+                if (ok) {
+                    const int nin = g.shared ? (n - g.e_first_img) : n;
+                    v[u] = ldg16(in + (((size_t)nin * g.H + Y) * g.W + X) * g.ld + g.coff + c0 + pj * VE);
+                }
+            }
+            pp += PSTEP;
+            ix += PSTEP;
+            while (ix >= g.PW) {
+                ix -= g.PW;
+                if (++iy == g.PH) { iy = 0; ++pn; }
+            }
+        }
+    }
+
+    template <int MODE> __device__ __forceinline__ void commit(char* patch, int npix, int tid) const {
+        const int pj = tid & (CPR - 1);
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u) {
+            const int pp = (tid >> LOG_CPR) + u * PSTEP;
+            if (pp < npix) *reinterpret_cast<v4i*>(patch + lds_chunk_off<LOG_RB, MODE>(pp, pj)) = v[u];
+        }
+    }
+};

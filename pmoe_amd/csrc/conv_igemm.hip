@@ -113,7 +113,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     geo.H = a.H; geo.W = a.W; geo.ld = a.in_ld; geo.coff = a.in_coff; geo.cmax = a.Cin;
     geo.dilate = a.dilate; geo.shared = a.in_shared;
     const T* in = (const T*)a.in;
-    auto load_patch = [&](int c0) { load_halo_patch<T, LOG_RB, NTHR, 0>(patch, in, geo, c0, tid); };
+    const bool one_batch = NPIX * CPR <= 12 * NTHR;     // every load of the patch in flight at once
+    auto load_patch = [&](int c0) {
+        if (one_batch) {
+            PatchStage<T, LOG_RB, NTHR, 12> ps;
+            ps.issue(in, geo, c0, tid);
+            ps.template commit<0>(patch, NPIX, tid);
+        } else {
+            load_halo_patch<T, LOG_RB, NTHR, 0>(patch, in, geo, c0, tid);
+        }
+    };
 
     const int nchunks = a.Cin / CK;
     int cur = 0;

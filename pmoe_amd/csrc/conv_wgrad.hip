@@ -11,12 +11,19 @@
 // [32 cout][32 cin] x taps accumulators in registers across ALL the m-blocks the workgroup walks
 // (K-split over gridDim.x), and flushes once with f32 atomics whose lanes run along cin
 // (2 x 128-byte segments per wave-instruction: the full-rate shape).
+//
+// Pipeline (one workgroup per CU, one wave per SIMD, the whole 512-register file): the global loads
+// of m-block i+1 (dY tile + X halo patch, up to 28 x 16 B per lane) are issued into registers
+// right after the barrier that publishes m-block i and land under its ~4600 cycles of MFMA; they
+// are written to LDS after the next barrier (issue early / write late).
 #include "conv_common.h"
 #include "kernels.h"
 
 template <typename T> struct WgradCfg;
-template <> struct WgradCfg<bf16> { static constexpr int WCO = 2, WCI = 2, WK = 1; };   // 64 x 64 channels / WG
-template <> struct WgradCfg<float> { static constexpr int WCO = 1, WCI = 1, WK = 4; };  // 32 x 32, pixels split 4 ways
+// bf16: 8 waves = 2(cout) x 2(cin) x 2(pixel halves): two waves per SIMD share an output tile and split the
+// pixels, so one wave's LDS reads / address math run under the other's MFMAs.  f32: 4 waves split pixels 4 ways.
+template <> struct WgradCfg<bf16> { static constexpr int WCO = 2, WCI = 2, WK = 2, NW = 8; };   // 64 x 64 channels / WG
+template <> struct WgradCfg<float> { static constexpr int WCO = 1, WCI = 1, WK = 4, NW = 4; };  // 32 x 32 channels / WG
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -24,20 +31,23 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
 }
 
-template <typename T, int TAPS>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
+template <typename T, int TAPS, int MAXV>
+__global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int NTHR = WgradCfg<T>::NW * 64;
     constexpr int LOG_RB = 7, RB = 128;
     constexpr int VE = 16 / (int)sizeof(T);
     constexpr int CKW = RB / (int)sizeof(T);            // channels per operand tile: 64 bf16 / 32 f32
     constexpr int WCI = WgradCfg<T>::WCI, WK = WgradCfg<T>::WK;
     constexpr int KS = TAPS == 9 ? 3 : 1;
+    constexpr int MAXDY = 256 * 8 / NTHR;               // dY tile: up to 256 pixels x 8 chunks
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int co_sub = (WK == 1) ? wave / WCI : 0;
-    const int ci_sub = (WK == 1) ? wave % WCI : 0;
-    const int k_sub = (WK == 1) ? 0 : wave;
+    constexpr int WCO = WgradCfg<T>::WCO;
+    const int ci_sub = wave % WCI;
+    const int co_sub = (wave / WCI) % WCO;
+    const int k_sub = wave / (WCI * WCO);
 
     const int e = blockIdx.z;
     const int n_ci_blk = (a.Cin + CKW - 1) / CKW;
@@ -52,8 +62,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     const int BMP = a.TN << (lTW + lTH);
     const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
 
-    char* dyt = smem;                                   // [BMP][128 B]
-    char* patch = smem + BMP * RB;                      // [NPIX][128 B]
+    char* dyt = smem;                                   // [BMP][192 B]
+    constexpr int RS = 192;                             // LDS row stride (128 B of channels + 64 B pad)
+    char* patch = smem + BMP * RS;                      // [NPIX][192 B]
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -67,35 +78,51 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     int mb_end = mb_begin + a.mb_per_wg;
     if (mb_end > mbpe) mb_end = mbpe;
 
-    for (int mbi = mb_begin; mbi < mb_end; ++mbi) {
+    PatchStage<T, LOG_RB, NTHR, MAXV> xs;
+    v4i dyv[MAXDY];
+    const int dyj = tid & 7;
+    const bool dy_cok = co0 + dyj * VE < a.Cout;
+
+    auto issue = [&](int mbi) {
         int t = mbi;
         const int px = t % a.tiles_x; t /= a.tiles_x;
         const int py = t % a.tiles_y; t /= a.tiles_y;
         const int ng = t;
         const int n0 = e * a.ipe + ng * a.TN, n_end = (e + 1) * a.ipe;
         const int oy0 = py * TH, ox0 = px * TW;
-
-        __syncthreads();                                // previous tile's operand reads are done
-        // dY tile: thread -> (chunk j, pixel slot), 32 pixels per sweep
-        {
-            const int j = tid & 7;
-            for (int p = tid >> 3; p < BMP; p += 32) {
-                const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
-                const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
-                v4i v = v4i{0, 0, 0, 0};
-                if (n < n_end && oy < a.Ho && ox < a.Wo && co0 + j * VE < a.Cout)
-                    v = ldg16(dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.dy_ld + a.dy_coff + co0 + j * VE);
-                *reinterpret_cast<v4i*>(dyt + p * RB + ((j ^ swz_chunk<LOG_RB, 1>(p)) << 4)) = v;
-            }
+#pragma unroll
+        for (int u = 0; u < MAXDY; ++u) {
+            const int p = (tid >> 3) + u * (NTHR / 8);
+            const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+            const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
+            dyv[u] = v4i{0, 0, 0, 0};
+            if (p < BMP && dy_cok && n < n_end && oy < a.Ho && ox < a.Wo)
+                dyv[u] = ldg16(dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.dy_ld + a.dy_coff + co0 + dyj * VE);
         }
         PatchGeom geo;
         geo.n0 = n0; geo.n_end = n_end; geo.e_first_img = e * a.ipe;
         geo.Y0 = oy0 * S - a.pad; geo.X0 = ox0 * S - a.pad; geo.PH = PH; geo.PW = PW; geo.NPIX = NPIX;
         geo.H = a.H; geo.W = a.W; geo.ld = a.x_ld; geo.coff = a.x_coff; geo.cmax = a.Cin;
         geo.dilate = 0; geo.shared = a.x_shared;
-        load_halo_patch<T, LOG_RB, 256, 1>(patch, x, geo, ci0, tid);
-        __syncthreads();
+        xs.issue(x, geo, ci0, tid);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < MAXDY; ++u) {
+            const int p = (tid >> 3) + u * (NTHR / 8);
+            if (p < BMP) *reinterpret_cast<v4i*>(dyt + lds_chunk_off<LOG_RB, 2>(p, dyj)) = dyv[u];
+        }
+        xs.template commit<2>(patch, NPIX, tid);
+    };
 
+    if (mb_begin < mb_end) issue(mb_begin);
+    for (int mbi = mb_begin; mbi < mb_end; ++mbi) {
+        __syncthreads();                                // previous tile's operand reads are done
+        commit();
+        __syncthreads();
+        if (mbi + 1 < mb_end) issue(mbi + 1);           // in flight under this tile's MFMAs
+
+#pragma unroll 2
         for (int kb = k_sub; kb < (BMP >> 4); kb += WK) {
             const int p0 = kb << 4;
             if constexpr (sizeof(T) == 2) {
@@ -111,23 +138,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
                     const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
                     ppB[tt] = (pn * PH + my * S) * PW + mx * S;
                 }
-                const int ca = co_sub * 32 + cblk, cb = ci_sub * 32 + cblk;
+                const int ca = (co_sub * 32 + cblk) * 2, cb = (ci_sub * 32 + cblk) * 2;   // byte offsets in a row
                 bf16x8 fa;
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    const s16x4 r = tr_read(dyt + pA[tt] * RB + (((ca >> 3) ^ swz_chunk<LOG_RB, 1>(pA[tt])) << 4) + ((ca & 7) << 1));
+                    const s16x4 r = tr_read(dyt + pA[tt] * RS + ca);
                     const bf16x4 rb = __builtin_bit_cast(bf16x4, r);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[4 * tt + i] = rb[i];
                 }
+                const char* bB[2] = {patch + ppB[0] * RS + cb, patch + ppB[1] * RS + cb};
 #pragma unroll
                 for (int tap = 0; tap < TAPS; ++tap) {
-                    const int tapoff = (tap / KS) * PW + (tap % KS);
+                    const int tapoff = ((tap / KS) * PW + (tap % KS)) * RS;      // wave-uniform
                     bf16x8 fb;
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        const int pp = ppB[tt] + tapoff;
-                        const s16x4 r = tr_read(patch + pp * RB + (((cb >> 3) ^ swz_chunk<LOG_RB, 1>(pp)) << 4) + ((cb & 7) << 1));
+                        const s16x4 r = tr_read(bB[tt] + tapoff);
                         const bf16x4 rb = __builtin_bit_cast(bf16x4, r);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) fb[4 * tt + i] = rb[i];
@@ -141,13 +168,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
                     const int p = p0 + 2 * m + h;
                     const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
                     const int ppb = (pn * PH + my * S) * PW + mx * S;
-                    const float av = *reinterpret_cast<const float*>(
-                        dyt + p * RB + (((l31 >> 2) ^ swz_chunk<LOG_RB, 1>(p)) << 4) + ((l31 & 3) << 2));
+                    const float av = *reinterpret_cast<const float*>(dyt + p * RS + (l31 << 2));
 #pragma unroll
                     for (int tap = 0; tap < TAPS; ++tap) {
                         const int pp = ppb + (tap / KS) * PW + (tap % KS);
-                        const float bv = *reinterpret_cast<const float*>(
-                            patch + pp * RB + (((l31 >> 2) ^ swz_chunk<LOG_RB, 1>(pp)) << 4) + ((l31 & 3) << 2));
+                        const float bv = *reinterpret_cast<const float*>(patch + pp * RS + (l31 << 2));
                         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
                     }
                 }
@@ -168,8 +193,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-template <typename T, int TAPS> static int launch_wg(const WgradArgs& a, int E, size_t smem, hipStream_t st) {
-    auto k = conv_wgrad_kernel<T, TAPS>;
+template <typename T, int TAPS, int MAXV> static int launch_wg(const WgradArgs& a, int E, size_t smem, hipStream_t st) {
+    auto k = conv_wgrad_kernel<T, TAPS, MAXV>;
     static bool attr_done = false;
     if (!attr_done) {
         HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -177,7 +202,7 @@ template <typename T, int TAPS> static int launch_wg(const WgradArgs& a, int E, 
     }
     constexpr int CKW = 128 / (int)sizeof(T);
     const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
-    dim3 grid((mbpe + a.mb_per_wg - 1) / a.mb_per_wg, ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW), E), block(256, 1, 1);
+    dim3 grid((mbpe + a.mb_per_wg - 1) / a.mb_per_wg, ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW), E), block(WgradCfg<T>::NW * 64, 1, 1);
     hipLaunchKernelGGL(k, grid, block, smem, st, a);
     return (int)hipGetLastError();
 }
@@ -197,20 +222,26 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st) {
         const int TN = BMP >> (lTW + lTH);
         const int TW = 1 << lTW, TH = 1 << lTH;
         const int PW = (TW - 1) * a.stride + a.ks, PH = (TH - 1) * a.stride + a.ks;
-        const size_t smem = (size_t)BMP * 128 + (size_t)TN * PH * PW * 128;
+        const int NPIX = TN * PH * PW;
+        constexpr int NTHR = WgradCfg<T>::NW * 64;
+        const int need = (NPIX * 8 + NTHR - 1) / NTHR;  // 16-byte patch loads per thread
+        constexpr int M1 = 48 / WgradCfg<T>::NW, M2 = 80 / WgradCfg<T>::NW;   // patch loads per thread: 6|10 (8 waves), 12|20 (4 waves)
+        if (need > M2) continue;
+        const size_t smem = (size_t)BMP * 192 + (size_t)NPIX * 192;
         if (smem > 150 * 1024) continue;
         a.lTW = lTW; a.lTH = lTH; a.TN = TN;
         a.n_groups = (a.ipe + TN - 1) / TN;
         a.tiles_y = (a.Ho + TH - 1) / TH;
         a.tiles_x = (a.Wo + TW - 1) / TW;
         const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
-        // K-split: aim for ~4 workgroups per CU over the whole launch
+        // K-split: one workgroup per CU is resident; aim for ~2 rounds of 256 workgroups
         const int pairs = ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW) * E;
-        int want = (1024 + pairs - 1) / pairs;
+        int want = (512 + pairs - 1) / pairs;
         if (want < 1) want = 1;
         if (want > mbpe) want = mbpe;
         a.mb_per_wg = (mbpe + want - 1) / want;
-        return a.ks == 3 ? launch_wg<T, 9>(a, E, smem, st) : launch_wg<T, 1>(a, E, smem, st);
+        if (need <= M1) return a.ks == 3 ? launch_wg<T, 9, M1>(a, E, smem, st) : launch_wg<T, 1, M1>(a, E, smem, st);
+        return a.ks == 3 ? launch_wg<T, 9, M2>(a, E, smem, st) : launch_wg<T, 1, M2>(a, E, smem, st);
     }
     return PMOE_ERR_UNSUPPORTED;
 }
