@@ -122,16 +122,18 @@ int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const voi
 /* y = [relu]( x*scale + shift [+ res] ) */
 int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,
                   int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream);
-/* backward reduce: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat -> part [E][nparts][2][C] */
+/* backward reduce: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat -> part [E][nparts][2][C].
+ * y may be NULL when relu is set and the forward had no residual: the mask is then recomputed as
+ * x*scale+shift > 0 and the saved output is not read at all (one tensor pass less). */
 int pmoe_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                       int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, float* part, int32_t nparts,
+                       const float* scale, const float* shift, int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, float* part, int32_t nparts,
                        int32_t dtype, void* stream);
 /* dgamma/dbeta [E][C] (written to the grad arena) + the two per-channel means used by bwd_apply */
 int pmoe_bn_bwd_finalize(const float* part, int32_t nparts, int64_t count, float* dgamma, float* dbeta, float* c1,
                          float* c2, int32_t E, int32_t C, void* stream);
 /* dx = gamma*invstd * (g - c1 - xhat*c2); optionally also stores g (the masked grad) to gmask_out */
 int pmoe_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                      const float* scale, const float* c1, const float* c2, void* dx, void* gmask_out,
+                      const float* scale, const float* shift, const float* c1, const float* c2, void* dx, void* gmask_out,
                       int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream);
 
 /* ---- pooling (nn.MaxPool2d(3,2,1) and AdaptiveAvgPool2d(1) of the torchvision ResNet; the GAP of

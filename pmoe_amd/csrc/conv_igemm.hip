@@ -342,13 +342,25 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
     return PMOE_ERR_UNSUPPORTED;
 }
 
+// resident-weight ping-pong kernel for the <=64-channel 3x3 stride-1 layers (conv_res.hip)
+struct ResPlan {
+    int lTW, lTH, TN, n_groups, tiles_y, tiles_x, tiles_per_expert, wgs_per_expert, log_rb;
+    size_t smem;
+};
+bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan);
+int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st);
+
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
+    ResPlan plan;
+    if (conv_res_plan(a, dtype, &plan)) return conv_res_launch(a, plan, st);
     if (dtype == PMOE_DT_BF16) return launch_dtype<bf16>(a, st, nullptr);
     if (dtype == PMOE_DT_F32) return launch_dtype<float>(a, st, nullptr);
     return PMOE_ERR_ARG;
 }
 
 int conv_igemm_mblocks(const ConvArgs& a, int dtype) {
+    ResPlan plan;
+    if (conv_res_plan(a, dtype, &plan)) return (a.N / a.ipe) * plan.wgs_per_expert;
     int mb = 0;
     int rc = (dtype == PMOE_DT_BF16) ? launch_dtype<bf16>(a, nullptr, &mb) : launch_dtype<float>(a, nullptr, &mb);
     return rc ? rc : mb;

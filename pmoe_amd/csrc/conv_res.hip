@@ -1,0 +1,307 @@
+// Resident-weight 3x3 convolution (stride 1, pad 1, <= 64 input and <= 64 output channels, bf16):
+// the stem convs, the four layer1 convs and all their data gradients -- 45 % of the network's conv
+// FLOPs and its most HBM-heavy layers.
+//
+// Persistent workgroups (one per CU, 8 waves, all 160 KiB of LDS): the whole filter bank of the expert
+// [9 taps][64 couts][Cin] stays in LDS for the life of the workgroup; the two 4-wave halves of the
+// workgroup PING-PONG over consecutive 256-pixel tiles.  While half A runs the 144 MFMAs per wave of
+// tile t out of its own halo patch, half B -- on the same SIMDs, in the MFMA shadow -- stages tile
+// t-1's accumulators through its LDS region, writes them out as whole 16-byte channel vectors
+// (+ residual add, + BatchNorm partial sums kept in registers for the whole workgroup lifetime),
+// and commits the halo patch of tile t+1 whose global loads it issued one full tile earlier
+// (issue early / write late).  Then the roles swap.  Three workgroup barriers per tile, no weight
+// traffic, no prologue / epilogue bubble: the MFMA pipe of each SIMD always has one wave feeding it.
+#include "conv_common.h"
+#include "kernels.h"
+
+template <int LOG_RB> __device__ __forceinline__ int rswz(int x) { return swz_chunk<LOG_RB, 0>(x); }
+
+struct ResPlan {
+    int lTW, lTH, TN, n_groups, tiles_y, tiles_x, tiles_per_expert, wgs_per_expert, log_rb;
+    size_t smem;
+};
+
+template <int LOG_RB>
+__global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, const int tiles_per_expert,
+                                                         const int wgs_per_expert, const int region_bytes) {
+    constexpr int RB = 1 << LOG_RB, CPR = RB / 16, LOG_CPR = LOG_RB - 4;
+    constexpr int KSUB = RB / 32;
+    constexpr int VE = 8;                                // bf16 per 16 bytes
+    constexpr int MAXV = 11;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, gw = wave & 3, gtid = tid & 255;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int e = blockIdx.y, wg = blockIdx.x;
+    const int t0 = (int)((long long)wg * tiles_per_expert / wgs_per_expert);
+    const int t1 = (int)((long long)(wg + 1) * tiles_per_expert / wgs_per_expert);
+    const int n = t1 - t0;
+
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int PW = TW + 2, PH = TH + 2;
+    const int NPIX = a.TN * PH * PW;
+
+    char* Wl = smem;                                     // [9][64][RB]
+    char* region = smem + 9 * 64 * RB + grp * region_bytes;   // this half's patch / staging area
+
+    // ---- resident filter bank of expert e
+    {
+        const bf16* wsrc = (const bf16*)a.w + (size_t)e * a.CoutP * 9 * a.Cin;
+        for (int v = tid; v < 9 * 64 * CPR; v += 512) {
+            const int j = v & (CPR - 1);
+            const int row = (v >> LOG_CPR) & 63;
+            const int tap = v >> (LOG_CPR + 6);
+            const v4i val = ldg16(wsrc + ((size_t)row * 9 + tap) * a.Cin + j * VE);
+            *reinterpret_cast<v4i*>(Wl + (tap * 64 + row) * RB + ((j ^ rswz<LOG_RB>(row)) << 4)) = val;
+        }
+    }
+
+    auto geom = [&](int t, PatchGeom& g, int& n0, int& oy0, int& ox0) {
+        int q = t0 + t;
+        const int px = q % a.tiles_x; q /= a.tiles_x;
+        const int py = q % a.tiles_y; q /= a.tiles_y;
+        n0 = e * a.ipe + q * a.TN;
+        oy0 = py * TH; ox0 = px * TW;
+        g.n0 = n0; g.n_end = (e + 1) * a.ipe; g.e_first_img = e * a.ipe;
+        g.Y0 = oy0 - 1; g.X0 = ox0 - 1; g.PH = PH; g.PW = PW; g.NPIX = NPIX;
+        g.H = a.H; g.W = a.W; g.ld = a.in_ld; g.coff = a.in_coff; g.cmax = a.Cin;
+        g.dilate = 0; g.shared = a.in_shared;
+    };
+
+    const bf16* in = (const bf16*)a.in;
+    PatchStage<bf16, LOG_RB, 256, MAXV> ps;
+    auto issue_tile = [&](int t) {
+        PatchGeom g; int n0, oy0, ox0;
+        geom(t, g, n0, oy0, ox0);
+        ps.issue(in, g, 0, gtid);
+    };
+
+    // per-lane pixel bases of the B operand (pixels gw*64 + mt*32 + l31 of the tile)
+    int ppb[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int p = gw * 64 + mt * 32 + l31;
+        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+        ppb[mt] = (pn * PH + my) * PW + mx;
+    }
+    int arow_off[2][KSUB];                                // loop-invariant A (weight) fragment offsets
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KSUB; ++ks) {
+            const int row = nt * 32 + l31;
+            arow_off[nt][ks] = row * RB + (((ks * 2 + hh) ^ rswz<LOG_RB>(row)) << 4);
+        }
+
+    f32x16 acc[2][2];
+    float s1[VE], s2[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) s1[i] = s2[i] = 0.f;
+    const int cc = gtid & 7, pr = gtid >> 3;              // store phase: channel chunk / pixel lane
+    const bool cvalid = cc * VE < a.Cout;
+    bf16* out = (bf16*)a.out;
+    const bf16* res = (const bf16*)a.res;
+
+    // ---- prologue
+    if (grp == 0 && n > 0) {
+        issue_tile(0);
+        ps.template commit<0>(region, NPIX, gtid);
+    }
+    if (grp == 1 && n > 1) issue_tile(1);
+    __syncthreads();
+
+    auto taps = [&](int tap_lo) {
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            const int tap = tap_lo + tp;
+            const int tapoff = (tap / 3) * PW + (tap % 3);
+            const char* wt = Wl + tap * 64 * RB;
+            int pp[2], fp[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                pp[mt] = ppb[mt] + tapoff;
+                fp[mt] = rswz<LOG_RB>(pp[mt]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSUB; ++ks) {
+                v4i af[2], bfr[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) af[nt] = *reinterpret_cast<const v4i*>(wt + arow_off[nt][ks]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    bfr[mt] = *reinterpret_cast<const v4i*>(region + (pp[mt] << LOG_RB) + (((ks * 2 + hh) ^ fp[mt]) << 4));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[nt]),
+                                                                              __builtin_bit_cast(bf16x8, bfr[mt]),
+                                                                              acc[nt][mt], 0, 0, 0);
+            }
+        }
+    };
+
+    for (int h = 0; h <= n; ++h) {
+        if (grp == (h & 1)) {
+            // ================= MFMA role: tile h =================
+            const bool live = h < n;
+            if (h + 2 < n) issue_tile(h + 2);            // lands under this tile's MFMAs, committed next half-period
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+                taps(0);
+            }
+            __syncthreads();
+            if (live) taps(3);
+            __syncthreads();
+            if (live) taps(6);
+            __syncthreads();
+        } else {
+            // ================= I/O role: write out tile h-1, bring in tile h+1 =================
+            const bool have = h >= 1;
+            if (have) {
+                // D[cout][pixel] -> bf16 [256 px][64 cout] staging, 16-byte chunks XOR-swizzled by pixel
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int p = gw * 64 + mt * 32 + l31;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            bf16x4 v;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = (bf16)acc[nt][mt][4 * g + i];
+                            *reinterpret_cast<bf16x4*>(region + p * 128 + (((nt * 4 + g) ^ (p & 7)) << 4) + 8 * hh) = v;
+                        }
+                    }
+            }
+            __syncthreads();
+            if (have) {
+                PatchGeom gg; int n0, oy0, ox0;
+                geom(h - 1, gg, n0, oy0, ox0);
+                for (int p = pr; p < 256; p += 32) {
+                    const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+                    const int nn = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
+                    const v4i raw = *reinterpret_cast<const v4i*>(region + p * 128 + ((cc ^ (p & 7)) << 4));
+                    if (cvalid && nn < gg.n_end && oy < a.Ho && ox < a.Wo) {
+                        const size_t opix = ((size_t)nn * a.Ho + oy) * a.Wo + ox;
+                        v4i pk = raw;
+                        if (a.res_mode == PMOE_RES_ADD) {
+                            float v[VE], rv[VE];
+                            unpack16<bf16>(raw, v);
+                            unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cc * VE), rv);
+#pragma unroll
+                            for (int i = 0; i < VE; ++i) v[i] += rv[i];
+                            pk = pack16<bf16>(v);
+                        }
+                        if (a.stats) {
+                            float rr[VE];
+                            unpack16<bf16>(pk, rr);
+#pragma unroll
+                            for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
+                        }
+                        stg16(out + opix * a.out_ld + a.out_coff + cc * VE, pk);
+                    }
+                }
+            }
+            __syncthreads();
+            if (h + 1 < n) ps.template commit<0>(region, NPIX, gtid);
+            __syncthreads();
+        }
+    }
+
+    if (a.stats) {
+        // one [2][CoutP] partial row per workgroup: lanes sharing a channel chunk combine by xor-shuffle,
+        // the 8 waves through LDS (the filter bank is dead by now)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [8 waves][2][64]
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                s1[i] += __shfl_xor(s1[i], off);
+                s2[i] += __shfl_xor(s2[i], off);
+            }
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                red[(wave * 2 + 0) * 64 + cc * VE + i] = s1[i];
+                red[(wave * 2 + 1) * 64 + cc * VE + i] = s2[i];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, c = tid & 63;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += red[(w * 2 + which) * 64 + c];
+            a.stats[(((size_t)e * wgs_per_expert + wg) * 2 + which) * a.CoutP + c] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan) {
+    if (dtype != PMOE_DT_BF16 || a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dilate) return false;
+    if (a.CoutP != 64 || a.Cout % 8 || (a.Cin != 64 && a.Cin != 16)) return false;
+    if (a.act != PMOE_ACT_NONE || a.drop_p > 0.f || a.bias) return false;
+    if (a.res_mode != PMOE_RES_NONE && a.res_mode != PMOE_RES_ADD) return false;
+    if (a.N % a.ipe || a.Ho != a.H || a.Wo != a.W) return false;
+    auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    int lTW = p2(a.Wo); if (lTW > 5) lTW = 5;
+    int lTH = p2(a.Ho); if (lTH > 8 - lTW) lTH = 8 - lTW;
+    const int TN = 256 >> (lTW + lTH);
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int NPIX = TN * (TH + 2) * (TW + 2);
+    const int log_rb = a.Cin == 64 ? 7 : 5;
+    const int rb = 1 << log_rb, cpr = rb / 16;
+    if (NPIX * cpr > 11 * 256) return false;
+    size_t region = (size_t)NPIX * rb;
+    if (region < 256 * 128) region = 256 * 128;
+    region = (region + 255) & ~(size_t)255;
+    const size_t smem = (size_t)9 * 64 * rb + 2 * region;
+    if (smem > 163840) return false;
+    const int E = a.N / a.ipe;
+    plan->lTW = lTW; plan->lTH = lTH; plan->TN = TN;
+    plan->n_groups = (a.ipe + TN - 1) / TN;
+    plan->tiles_y = (a.Ho + TH - 1) / TH;
+    plan->tiles_x = (a.Wo + TW - 1) / TW;
+    plan->tiles_per_expert = plan->n_groups * plan->tiles_y * plan->tiles_x;
+    int wpe = 256 / E; if (wpe < 1) wpe = 1;
+    if (wpe > plan->tiles_per_expert) wpe = plan->tiles_per_expert;
+    plan->wgs_per_expert = wpe;
+    plan->log_rb = log_rb;
+    plan->smem = smem;
+    return true;
+}
+
+int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
+    a.lTW = p.lTW; a.lTH = p.lTH; a.TN = p.TN; a.n_groups = p.n_groups; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
+    const int E = a.N / a.ipe;
+    const int region = (int)((p.smem - (size_t)9 * 64 * (1 << p.log_rb)) / 2);
+    dim3 grid(p.wgs_per_expert, E), block(512);
+    static bool attr7 = false, attr5 = false;
+    if (p.log_rb == 7) {
+        if (!attr7) {
+            HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_res_kernel<7>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+            attr7 = true;
+        }
+        hipLaunchKernelGGL(conv3x3_res_kernel<7>, grid, block, p.smem, st, a, p.tiles_per_expert, p.wgs_per_expert, region);
+    } else {
+        if (!attr5) {
+            HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_res_kernel<5>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+            attr5 = true;
+        }
+        hipLaunchKernelGGL(conv3x3_res_kernel<5>, grid, block, p.smem, st, a, p.tiles_per_expert, p.wgs_per_expert, region);
+    }
+    return (int)hipGetLastError();
+}

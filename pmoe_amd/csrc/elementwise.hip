@@ -20,7 +20,8 @@ static inline bool pow2(int v) { return v > 0 && !(v & (v - 1)); }
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                       const T* __restrict__ y, const float* __restrict__ mean,
-                                                      const float* __restrict__ invstd, long long rpe, int C, int ld,
+                                                      const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, long long rpe, int C, int ld,
                                                       int coff, int relu, float* __restrict__ part, int nparts) {
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE, RL = 256 / CV;
@@ -29,12 +30,15 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
     const long long rpp = (rpe + nparts - 1) / nparts;
     long long r0 = (long long)pi * rpp, r1 = r0 + rpp;
     if (r1 > rpe) r1 = rpe;
-    float s1[VE], s2[VE], mu[VE], is[VE];
+    float s1[VE], s2[VE], mu[VE], is[VE], sc[VE], sh[VE];
+    const bool remask = MODE && relu && !y;       // ReLU mask recomputed from x (no residual): y is not read
 #pragma unroll
     for (int i = 0; i < VE; ++i) {
         s1[i] = s2[i] = 0.f;
         mu[i] = MODE ? mean[e * C + cv * VE + i] : 0.f;
         is[i] = MODE ? invstd[e * C + cv * VE + i] : 0.f;
+        sc[i] = remask ? scale[e * C + cv * VE + i] : 0.f;
+        sh[i] = remask ? shift[e * C + cv * VE + i] : 0.f;
     }
     const size_t ebase = (size_t)e * rpe;
     for (long long r = r0 + rl; r < r1; r += RL) {
@@ -47,7 +51,10 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
         } else {
             float gv[VE], yv[VE];
             unpack16<T>(ldg16(dy + off), gv);
-            if (relu) {
+            if (remask) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) gv[i] = (xv[i] * sc[i] + sh[i]) > 0.f ? gv[i] : 0.f;
+            } else if (relu) {
                 unpack16<T>(ldg16(y + off), yv);
 #pragma unroll
                 for (int i = 0; i < VE; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
@@ -73,17 +80,17 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
 
 template <typename T>
 static int colstats_launch(const void* x, const void* dy, const void* y, const float* mean, const float* invstd,
-                           long long rpe, int E, int C, int ld, int coff, int relu, float* part, int nparts, int mode,
+                           const float* scale, const float* shift, long long rpe, int E, int C, int ld, int coff, int relu, float* part, int nparts, int mode,
                            hipStream_t st) {
     constexpr int VE = 16 / (int)sizeof(T);
     if (C % VE || !pow2(C / VE) || C / VE > 256 || nparts < 1) return PMOE_ERR_ARG;
     dim3 grid(nparts, E), block(256);
     if (mode == 0)
         hipLaunchKernelGGL((colstats_kernel<T, 0>), grid, block, 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr,
-                           rpe, C, ld, coff, 0, part, nparts);
+                           nullptr, nullptr, rpe, C, ld, coff, 0, part, nparts);
     else
         hipLaunchKernelGGL((colstats_kernel<T, 1>), grid, block, 0, st, (const T*)x, (const T*)dy, (const T*)y, mean,
-                           invstd, rpe, C, ld, coff, relu, part, nparts);
+                           invstd, scale, shift, rpe, C, ld, coff, relu, part, nparts);
     return (int)hipGetLastError();
 }
 
@@ -206,7 +213,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                           const T* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd,
-                                                          const float* __restrict__ scale, const float* __restrict__ c1,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ c1,
                                                           const float* __restrict__ c2, T* __restrict__ dx,
                                                           T* __restrict__ gm, long long rpe, int C, int relu) {
     constexpr int VE = 16 / (int)sizeof(T);
@@ -220,7 +228,13 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
         float gv[VE], xv[VE], o[VE];
         unpack16<T>(ldg16(dy + off), gv);
         unpack16<T>(ldg16(x + off), xv);
-        if (relu) {
+        if (relu && !y) {
+#pragma unroll
+            for (int k = 0; k < VE; ++k) {
+                const int c = e * C + cv * VE + k;
+                gv[k] = (xv[k] * scale[c] + shift[c]) > 0.f ? gv[k] : 0.f;
+            }
+        } else if (relu) {
             float yv[VE];
             unpack16<T>(ldg16(y + off), yv);
 #pragma unroll
@@ -532,14 +546,15 @@ extern "C" {
 
 int pmoe_colstats(const void* x, int64_t rows_per_expert, int32_t E, int32_t C, int32_t ld, int32_t coff, float* part,
                   int32_t nparts, int32_t dtype, void* stream) {
-    DISPATCH_DT(dtype, return colstats_launch<T>(x, nullptr, nullptr, nullptr, nullptr, rows_per_expert, E, C, ld, coff,
+    DISPATCH_DT(dtype, return colstats_launch<T>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows_per_expert, E, C, ld, coff,
                                                  0, part, nparts, 0, (hipStream_t)stream));
 }
 
 int pmoe_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                       int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, float* part, int32_t nparts,
+                       const float* scale, const float* shift, int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, float* part, int32_t nparts,
                        int32_t dtype, void* stream) {
-    DISPATCH_DT(dtype, return colstats_launch<T>(x, dy, y, mean, invstd, rows_per_expert, E, C, C, 0, relu, part,
+    if (relu && !y && (!scale || !shift)) return PMOE_ERR_ARG;
+    DISPATCH_DT(dtype, return colstats_launch<T>(x, dy, y, mean, invstd, scale, shift, rows_per_expert, E, C, C, 0, relu, part,
                                                  nparts, 1, (hipStream_t)stream));
 }
 
@@ -583,14 +598,14 @@ int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, c
 }
 
 int pmoe_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                      const float* scale, const float* c1, const float* c2, void* dx, void* gmask_out,
+                      const float* scale, const float* shift, const float* c1, const float* c2, void* dx, void* gmask_out,
                       int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream) {
     DISPATCH_DT(dtype, {
         constexpr int VE = 16 / (int)sizeof(T);
         if (C % VE) return PMOE_ERR_ARG;
         const long long nvec = rows_per_expert * (C / VE);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(nvec, 2048), E), dim3(256), 0, (hipStream_t)stream,
-                           (const T*)dy, (const T*)y, (const T*)x, mean, invstd, scale, c1, c2, (T*)dx, (T*)gmask_out,
+                           (const T*)dy, (const T*)y, (const T*)x, mean, invstd, scale, shift, c1, c2, (T*)dx, (T*)gmask_out,
                            (long long)rows_per_expert, C, relu);
         return (int)hipGetLastError();
     });

@@ -36,6 +36,7 @@ struct WgradArgs {
     int lTW, lTH, TN, n_groups, tiles_y, tiles_x, mb_per_wg;
 };
 
+struct ResPlan;
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st);
 int conv_igemm_mblocks(const ConvArgs& a, int dtype);
 int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);

@@ -413,17 +413,19 @@ class ExpertGroupEngine:
         y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
         if self.taping and y.needs_grad:
             train = self.training
-            self.tape.append(lambda: self._bn_bwd(z, layer, y, res, relu, scale, mean, invstd, rpe, train))
+            self.tape.append(lambda: self._bn_bwd(z, layer, y, res, relu, scale, shift, mean, invstd, rpe, train))
         return y
 
-    def _bn_bwd(self, z, layer, y, res, relu, scale, mean, invstd, rpe, train):
+    def _bn_bwd(self, z, layer, y, res, relu, scale, shift, mean, invstd, rpe, train):
         dy = y.grad
+        # without a residual the ReLU mask is a function of z alone: skip reading the saved output
+        ysrc = y.t if (res is not None or not relu) else None
         if dy is None:
             return
         E, C_ = self.E, layer.C
         nparts = min(128, max(1, rpe // 512))
         part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
-        ops.bn_bwd_reduce(dy, y.t, z.t, mean, invstd, rpe, E, C_, relu, part, nparts)
+        ops.bn_bwd_reduce(dy, ysrc, z.t, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts)
         c1, c2 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(2))
         ops.bn_bwd_finalize(part, nparts, rpe, self._grad_slot("gamma", layer).view(E, C_),
                             self._grad_slot("beta", layer).view(E, C_), c1, c2, E, C_)
@@ -437,7 +439,7 @@ class ExpertGroupEngine:
             return
         if dz is None:
             dz = torch.empty_like(z.t)
-        ops.bn_bwd_apply(dy, y.t, z.t, mean, invstd, scale, c1, c2, dz, gm, rpe, E, C_, relu)
+        ops.bn_bwd_apply(dy, ysrc, z.t, mean, invstd, scale, shift, c1, c2, dz, gm, rpe, E, C_, relu)
         if z.needs_grad:
             if z.grad is not None:
                 raise RuntimeError("BN input consumed twice")

@@ -125,9 +125,10 @@ def bn_apply(x, res, y, scale, shift, rpe, E, C_, relu):
                                E, C_, int(relu), dt(x), stream_ptr()), "pmoe_bn_apply")
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd, rpe, E, C_, relu, part, nparts):
+def bn_bwd_reduce(dy, y, x, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts):
+    """y=None (relu, no residual in forward): the ReLU mask is recomputed from x, the saved output is not read."""
     check(load().pmoe_bn_bwd_reduce(ptr(dy, "dy"), ptr(y, "y", dy.dtype), ptr(x, "x", dy.dtype), ptr(mean), ptr(invstd),
-                                    rpe, E, C_, int(relu), ptr(part, "part", torch.float32), nparts, dt(dy),
+                                    ptr(scale), ptr(shift), rpe, E, C_, int(relu), ptr(part, "part", torch.float32), nparts, dt(dy),
                                     stream_ptr()), "pmoe_bn_bwd_reduce")
 
 
@@ -136,9 +137,9 @@ def bn_bwd_finalize(part, nparts, count, dgamma, dbeta, c1, c2, E, C_):
                                       stream_ptr()), "pmoe_bn_bwd_finalize")
 
 
-def bn_bwd_apply(dy, y, x, mean, invstd, scale, c1, c2, dx, gmask, rpe, E, C_, relu):
+def bn_bwd_apply(dy, y, x, mean, invstd, scale, shift, c1, c2, dx, gmask, rpe, E, C_, relu):
     check(load().pmoe_bn_bwd_apply(ptr(dy, "dy"), ptr(y, "y", dy.dtype), ptr(x, "x", dy.dtype), ptr(mean), ptr(invstd),
-                                   ptr(scale), ptr(c1), ptr(c2), ptr(dx, "dx", dy.dtype), ptr(gmask, "gmask", dy.dtype),
+                                   ptr(scale), ptr(shift), ptr(c1), ptr(c2), ptr(dx, "dx", dy.dtype), ptr(gmask, "gmask", dy.dtype),
                                    rpe, E, C_, int(relu), dt(dy), stream_ptr()), "pmoe_bn_bwd_apply")
 
 

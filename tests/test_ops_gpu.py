@@ -240,16 +240,28 @@ def test_batchnorm_fwd_bwd(shape, dtype):
         close(drv[e], rvr[e], torch.float32, "running_var")
     # backward
     bpart = torch.empty(E, nparts, 2, C_, device=DEV)
-    ops.bn_bwd_reduce(dyd, y, xd, mean, invstd, rpe, E, C_, True, bpart, nparts)
+    ops.bn_bwd_reduce(dyd, y, xd, mean, invstd, scale, shift, rpe, E, C_, True, bpart, nparts)
     dgam, dbet, c1, c2 = (torch.empty(E, C_, device=DEV) for _ in range(4))
     ops.bn_bwd_finalize(bpart, nparts, rpe, dgam, dbet, c1, c2, E, C_)
     dx, gm = torch.empty_like(xd), torch.empty_like(xd)
-    ops.bn_bwd_apply(dyd, y, xd, mean, invstd, scale, c1, c2, dx, gm, rpe, E, C_, True)
+    ops.bn_bwd_apply(dyd, y, xd, mean, invstd, scale, shift, c1, c2, dx, gm, rpe, E, C_, True)
     close(from_nhwc(dx, C_), xr.grad, dtype, "bn dx")
     close(from_nhwc(gm, C_), rr.grad, dtype, "bn residual grad")
     for e in range(E):
         close(dgam[e], gr[e].grad, dtype, "dgamma")
         close(dbet[e], br[e].grad, dtype, "dbeta")
+    # no-residual ReLU: the mask is recomputed from x (y = None) and must equal the y-based mask
+    y2 = torch.empty_like(xd)
+    ops.bn_apply(xd, None, y2, scale, shift, rpe, E, C_, True)
+    pa, pb = torch.empty_like(bpart), torch.empty_like(bpart)
+    ops.bn_bwd_reduce(dyd, y2, xd, mean, invstd, scale, shift, rpe, E, C_, True, pa, nparts)
+    ops.bn_bwd_reduce(dyd, None, xd, mean, invstd, scale, shift, rpe, E, C_, True, pb, nparts)
+    close(pb, pa.cpu(), torch.float32, "mask-from-x reduce")
+    dxa, dxb = torch.empty_like(xd), torch.empty_like(xd)
+    ops.bn_bwd_finalize(pa, nparts, rpe, dgam, dbet, c1, c2, E, C_)
+    ops.bn_bwd_apply(dyd, y2, xd, mean, invstd, scale, shift, c1, c2, dxa, None, rpe, E, C_, True)
+    ops.bn_bwd_apply(dyd, None, xd, mean, invstd, scale, shift, c1, c2, dxb, None, rpe, E, C_, True)
+    close(dxb, dxa.float().cpu(), dtype, "mask-from-x apply")
     # eval mode: scale/shift from running buffers
     ops.bn_finalize(part2, 2, rpe, tabs[0], tabs[1], tabs[2], tabs[3], 0.1, 1e-5, False, scale, shift, mean, invstd, E, C_)
     ops.bn_apply(xd, None, y, scale, shift, rpe, E, C_, False)
