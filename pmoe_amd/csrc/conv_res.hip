@@ -109,10 +109,13 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
         issue_tile(0);
         ps.template commit<0>(region, NPIX, gtid);
     }
-    if (grp == 1 && n > 1) issue_tile(1);
     __syncthreads();
 
     auto taps = [&](int tap_lo) {
+        // opaque copies: keeps LICM from hoisting all 72 per-(tap,k-step) operand addresses out of the tile
+        // loop (they would be spilled to scratch and reloaded between the MFMAs)
+        int pb[2] = {ppb[0], ppb[1]};
+        asm volatile("" : "+v"(pb[0]), "+v"(pb[1]));
 #pragma unroll
         for (int tp = 0; tp < 3; ++tp) {
             const int tap = tap_lo + tp;
@@ -121,7 +124,7 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
             int pp[2], fp[2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                pp[mt] = ppb[mt] + tapoff;
+                pp[mt] = pb[mt] + tapoff;
                 fp[mt] = rswz<LOG_RB>(pp[mt]);
             }
 #pragma unroll
@@ -147,7 +150,6 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
         if (grp == (h & 1)) {
             // ================= MFMA role: tile h =================
             const bool live = h < n;
-            if (h + 2 < n) issue_tile(h + 2);            // lands under this tile's MFMAs, committed next half-period
             if (live) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -164,8 +166,15 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
             __syncthreads();
         } else {
             // ================= I/O role: write out tile h-1, bring in tile h+1 =================
-            const bool have = h >= 1;
+            // Order matters for the vmcnt queue (loads and stores share one in-order counter on CDNA): the
+            // patch loads of tile h+1 are issued first and this tile's global stores LAST, after the patch
+            // commit, so the commit's wait never covers stores issued moments ago.
+            const bool have = h >= 1, next = h + 1 < n;
+            PatchGeom gg; int n0 = 0, oy0 = 0, ox0 = 0;
+            v4i rb[8];
+            if (next) issue_tile(h + 1);                   // ~1.5 us of staging / barriers before its commit
             if (have) {
+                geom(h - 1, gg, n0, oy0, ox0);
                 // D[cout][pixel] -> bf16 [256 px][64 cout] staging, 16-byte chunks XOR-swizzled by pixel
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -183,18 +192,26 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
             }
             __syncthreads();
             if (have) {
-                PatchGeom gg; int n0, oy0, ox0;
-                geom(h - 1, gg, n0, oy0, ox0);
-                for (int p = pr; p < 256; p += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = pr + 32 * u;
+                    rb[u] = *reinterpret_cast<const v4i*>(region + p * 128 + ((cc ^ (p & 7)) << 4));
+                }
+            }
+            __syncthreads();
+            if (next) ps.template commit<0>(region, NPIX, gtid);
+            if (have) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = pr + 32 * u;
                     const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
                     const int nn = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
-                    const v4i raw = *reinterpret_cast<const v4i*>(region + p * 128 + ((cc ^ (p & 7)) << 4));
                     if (cvalid && nn < gg.n_end && oy < a.Ho && ox < a.Wo) {
                         const size_t opix = ((size_t)nn * a.Ho + oy) * a.Wo + ox;
-                        v4i pk = raw;
+                        v4i pk = rb[u];
                         if (a.res_mode == PMOE_RES_ADD) {
                             float v[VE], rv[VE];
-                            unpack16<bf16>(raw, v);
+                            unpack16<bf16>(rb[u], v);
                             unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cc * VE), rv);
 #pragma unroll
                             for (int i = 0; i < VE; ++i) v[i] += rv[i];
@@ -210,8 +227,6 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
                     }
                 }
             }
-            __syncthreads();
-            if (h + 1 < n) ps.template commit<0>(region, NPIX, gtid);
             __syncthreads();
         }
     }
