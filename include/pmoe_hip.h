@@ -153,6 +153,22 @@ int pmoe_gap_finish(const float* part, void* out, int32_t N, int32_t C, int32_t 
 int pmoe_gap_bwd(const void* g, void* dx, int32_t N, int64_t HW, int32_t C, int32_t g_ld, int32_t g_coff,
                  int32_t dtype, void* stream);
 
+/* ---- fused stem tail: z2 -> BN+ReLU (conv2.1/.2, basics.py:121-123) -> BN+ReLU (ResNet bn1/relu) -> MaxPool(3,2,1).
+ * The two intermediate activations and their gradients are re-derived from z2 in registers, never stored.
+ * All per-channel arrays are [E][C] f32.  part: [E][nparts][2][C] partial sums (finish with pmoe_bn_finalize /
+ * pmoe_bn_bwd_finalize). */
+int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, float* part, int32_t nparts, int32_t E,
+                         int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* sc2, const float* sh2, const float* sc1,
+                        const float* sh1, int32_t N, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                        void* stream);
+/* phase 1: sums for the bn1 backward; phase 2: sums for the conv2-BN backward; phase 3: writes dz2.
+ * consts: HOST array of 12 device pointers: sc2 sh2 sc1 sh1 mu1 is1 mu2 is2 c11 c21 c12 c22 (later ones may be
+ * null in earlier phases). */
+int pmoe_stem_tail_bwd(int32_t phase, const void* z2, const void* dpool, const uint8_t* argmax, void* dz2,
+                       const float* const* consts, float* part, int32_t nparts, int32_t E, int32_t ipe, int32_t H,
+                       int32_t W, int32_t C, int32_t dtype, void* stream);
+
 /* ---- ECA channel attention (EfficientBlock.forward, basics.py:69-76) -------------------------
  * gate[n][c] = sigmoid(sum_j w[e][j] * mean_hw(x)[n][c + j - k/2]) from GAP partials (creal = number
  * of real channels the conv1d sees, rest is padding) */

@@ -26,6 +26,7 @@ struct PatchGeom {
     int PH, PW, NPIX;
     int H, W, ld, coff, cmax;      // cmax: channels [0,cmax) past coff exist, the rest reads as 0
     int dilate, shared;
+    int step;                      // source pixels per patch pixel (2 for a strided 1x1 conv: only the used pixels are staged)
 };
 
 // Stage channels [c0, c0 + RB/sizeof(T)) of the halo patch into LDS.  thread -> (16-byte chunk,
@@ -48,7 +49,7 @@ __device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const 
             dst[u] = -1;
             if (pp < g.NPIX) {
                 const int n = g.n0 + pn;
-                int Y = g.Y0 + iy, X = g.X0 + ix;
+                int Y = g.Y0 + iy * g.step, X = g.X0 + ix * g.step;
                 bool ok = n < g.n_end && (c0 + pj * VE) < g.cmax;
                 if (g.dilate) {
                     ok = ok && Y >= 0 && X >= 0 && !((Y | X) & 1);
@@ -100,7 +101,7 @@ struct PatchStage {
             v[u] = v4i{0, 0, 0, 0};
             if (pp < g.NPIX) {
                 const int n = g.n0 + pn;
-                int Y = g.Y0 + iy, X = g.X0 + ix;
+                int Y = g.Y0 + iy * g.step, X = g.X0 + ix * g.step;
                 bool ok = cok && n < g.n_end;
                 if (g.dilate) {
                     ok = ok && Y >= 0 && X >= 0 && !((Y | X) & 1);

@@ -56,12 +56,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     const int e = t / a.n_groups;
     const int lTW = a.lTW, lTH = a.lTH;
     const int TW = 1 << lTW, TH = 1 << lTH;
-    const int S = a.stride, KS = a.ks, TAPS = KS * KS;
+    // a strided 1x1 conv stages only the pixels it uses: LDS pixel stride 1, source step = stride
+    const int KS = a.ks, TAPS = KS * KS;
+    const int S = KS == 1 ? 1 : a.stride, step = KS == 1 ? a.stride : 1;
     const int PW = (TW - 1) * S + KS, PH = (TH - 1) * S + KS;
     const int NPIX = a.TN * PH * PW;
     const int n0 = e * a.ipe + ng * a.TN, n_end = (e + 1) * a.ipe;
     const int oy0 = py * TH, ox0 = px * TW;
-    const int Y0 = oy0 * S - a.pad, X0 = ox0 * S - a.pad;
+    const int Y0 = oy0 * a.stride - a.pad, X0 = ox0 * a.stride - a.pad;
     const int cout0 = blockIdx.y * BN;
 
     char* patch = smem;
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     geo.n0 = n0; geo.n_end = n_end; geo.e_first_img = e * a.ipe;
     geo.Y0 = Y0; geo.X0 = X0; geo.PH = PH; geo.PW = PW; geo.NPIX = NPIX;
     geo.H = a.H; geo.W = a.W; geo.ld = a.in_ld; geo.coff = a.in_coff; geo.cmax = a.Cin;
-    geo.dilate = a.dilate; geo.shared = a.in_shared;
+    geo.dilate = a.dilate; geo.shared = a.in_shared; geo.step = step;
     const T* in = (const T*)a.in;
     const bool one_batch = NPIX * CPR <= 12 * NTHR;     // every load of the patch in flight at once
     auto load_patch = [&](int c0) {
@@ -324,7 +326,8 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         int lTH = p2(a.Ho); if (lTH > lBM - lTW) lTH = lBM - lTW;
         const int TN = BM >> (lTW + lTH);
         const int TW = 1 << lTW, TH = 1 << lTH;
-        const int PW = (TW - 1) * a.stride + a.ks, PH = (TH - 1) * a.stride + a.ks;
+        const int lstride = a.ks == 1 ? 1 : a.stride;
+        const int PW = (TW - 1) * lstride + a.ks, PH = (TH - 1) * lstride + a.ks;
         size_t smem = (((size_t)TN * PH * PW * rb + 255) & ~(size_t)255) + 2 * (size_t)BN * rb;
         const size_t stg = (size_t)BM * BN * 4;
         if (smem < stg) smem = stg;

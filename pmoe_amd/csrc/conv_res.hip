@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
         g.n0 = n0; g.n_end = (e + 1) * a.ipe; g.e_first_img = e * a.ipe;
         g.Y0 = oy0 - 1; g.X0 = ox0 - 1; g.PH = PH; g.PW = PW; g.NPIX = NPIX;
         g.H = a.H; g.W = a.W; g.ld = a.in_ld; g.coff = a.in_coff; g.cmax = a.Cin;
-        g.dilate = 0; g.shared = a.in_shared;
+        g.dilate = 0; g.shared = a.in_shared; g.step = 1;
     };
 
     const bf16* in = (const bf16*)a.in;

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
 
     const int lTW = a.lTW, lTH = a.lTH;
     const int TW = 1 << lTW, TH = 1 << lTH;
-    const int S = a.stride;
+    const int S = KS == 1 ? 1 : a.stride, step = KS == 1 ? a.stride : 1;   // strided 1x1: stage only used pixels
     const int PW = (TW - 1) * S + KS, PH = (TH - 1) * S + KS;
     const int NPIX = a.TN * PH * PW;
     const int BMP = a.TN << (lTW + lTH);
@@ -101,9 +101,9 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
         }
         PatchGeom geo;
         geo.n0 = n0; geo.n_end = n_end; geo.e_first_img = e * a.ipe;
-        geo.Y0 = oy0 * S - a.pad; geo.X0 = ox0 * S - a.pad; geo.PH = PH; geo.PW = PW; geo.NPIX = NPIX;
+        geo.Y0 = oy0 * a.stride - a.pad; geo.X0 = ox0 * a.stride - a.pad; geo.PH = PH; geo.PW = PW; geo.NPIX = NPIX;
         geo.H = a.H; geo.W = a.W; geo.ld = a.x_ld; geo.coff = a.x_coff; geo.cmax = a.Cin;
-        geo.dilate = 0; geo.shared = a.x_shared;
+        geo.dilate = 0; geo.shared = a.x_shared; geo.step = step;
         xs.issue(x, geo, ci0, tid);
     };
     auto commit = [&]() {
@@ -221,7 +221,8 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st) {
         const int BMP = 1 << lBM;
         const int TN = BMP >> (lTW + lTH);
         const int TW = 1 << lTW, TH = 1 << lTH;
-        const int PW = (TW - 1) * a.stride + a.ks, PH = (TH - 1) * a.stride + a.ks;
+        const int lstride = a.ks == 1 ? 1 : a.stride;
+        const int PW = (TW - 1) * lstride + a.ks, PH = (TH - 1) * lstride + a.ks;
         const int NPIX = TN * PH * PW;
         constexpr int NTHR = WgradCfg<T>::NW * 64;
         const int need = (NPIX * 8 + NTHR - 1) / NTHR;  // 16-byte patch loads per thread

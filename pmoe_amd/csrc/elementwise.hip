@@ -182,15 +182,17 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
                                                       T* __restrict__ y, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, long long rpe, int C, int relu) {
     constexpr int VE = 16 / (int)sizeof(T);
-    const int CV = C / VE;
+    const int CV = C / VE;                       // power of two <= 256*gridDim.x: a thread keeps ONE channel vector
     const int e = blockIdx.y;
     const long long nvec = rpe * CV;
     const size_t ebase = (size_t)e * rpe * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % CV);
-        float sc[VE], sh[VE], xv[VE];
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cv = (int)(i0 % CV);
+    float sc[VE], sh[VE];
 #pragma unroll
-        for (int k = 0; k < VE; ++k) { sc[k] = scale[e * C + cv * VE + k]; sh[k] = shift[e * C + cv * VE + k]; }
+    for (int k = 0; k < VE; ++k) { sc[k] = scale[e * C + cv * VE + k]; sh[k] = shift[e * C + cv * VE + k]; }
+    for (long long i = i0; i < nvec; i += (long long)gridDim.x * 256) {
+        float xv[VE];
         const size_t off = ebase + (size_t)i * VE;
         unpack16<T>(ldg16(x + off), xv);
 #pragma unroll
@@ -222,18 +224,28 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     const int e = blockIdx.y;
     const long long nvec = rpe * CV;
     const size_t ebase = (size_t)e * rpe * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % CV);
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cv = (int)(i0 % CV);               // constant per thread (grid stride is a multiple of CV)
+    // dx = scale*(g - c1 - xhat*c2) = g*A + x*Bx + K   with per-channel A, Bx, K
+    float A[VE], Bx[VE], K[VE], sc[VE], sh[VE];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) {
+        const int c = e * C + cv * VE + k;
+        sc[k] = scale[c];
+        sh[k] = shift ? shift[c] : 0.f;
+        A[k] = sc[k];
+        Bx[k] = -sc[k] * invstd[c] * c2[c];
+        K[k] = -sc[k] * (c1[c] - mean[c] * invstd[c] * c2[c]);
+    }
+    const bool remask = relu && !y;
+    for (long long i = i0; i < nvec; i += (long long)gridDim.x * 256) {
         const size_t off = ebase + (size_t)i * VE;
         float gv[VE], xv[VE], o[VE];
         unpack16<T>(ldg16(dy + off), gv);
         unpack16<T>(ldg16(x + off), xv);
-        if (relu && !y) {
+        if (remask) {
 #pragma unroll
-            for (int k = 0; k < VE; ++k) {
-                const int c = e * C + cv * VE + k;
-                gv[k] = (xv[k] * scale[c] + shift[c]) > 0.f ? gv[k] : 0.f;
-            }
+            for (int k = 0; k < VE; ++k) gv[k] = (xv[k] * sc[k] + sh[k]) > 0.f ? gv[k] : 0.f;
         } else if (relu) {
             float yv[VE];
             unpack16<T>(ldg16(y + off), yv);
@@ -241,11 +253,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
             for (int k = 0; k < VE; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < VE; ++k) {
-            const int c = e * C + cv * VE + k;
-            const float xh = (xv[k] - mean[c]) * invstd[c];
-            o[k] = scale[c] * (gv[k] - c1[c] - xh * c2[c]);
-        }
+        for (int k = 0; k < VE; ++k) o[k] = gv[k] * A[k] + (xv[k] * Bx[k] + K[k]);
         stg16(dx + off, pack16<T>(o));
         if (gm) stg16(gm + off, pack16<T>(gv));
     }
@@ -589,7 +597,7 @@ int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, c
                   int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream) {
     DISPATCH_DT(dtype, {
         constexpr int VE = 16 / (int)sizeof(T);
-        if (C % VE) return PMOE_ERR_ARG;
+        if (C % VE || !pow2(C / VE) || C / VE > 256) return PMOE_ERR_ARG;   // kernels keep one channel vector per thread
         const long long nvec = rows_per_expert * (C / VE);
         hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(nvec, 2048), E), dim3(256), 0, (hipStream_t)stream,
                            (const T*)x, (const T*)res, (T*)y, scale, shift, (long long)rows_per_expert, C, relu);
@@ -602,7 +610,7 @@ int pmoe_bn_bwd_apply(const void* dy, const void* y, const void* x, const float*
                       int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream) {
     DISPATCH_DT(dtype, {
         constexpr int VE = 16 / (int)sizeof(T);
-        if (C % VE) return PMOE_ERR_ARG;
+        if (C % VE || !pow2(C / VE) || C / VE > 256) return PMOE_ERR_ARG;   // kernels keep one channel vector per thread
         const long long nvec = rows_per_expert * (C / VE);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(nvec, 2048), E), dim3(256), 0, (hipStream_t)stream,
                            (const T*)dy, (const T*)y, (const T*)x, mean, invstd, scale, shift, c1, c2, (T*)dx, (T*)gmask_out,

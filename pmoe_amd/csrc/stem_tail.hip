@@ -1,0 +1,272 @@
+// Fused "stem tail" of the ECA/ResNet stem:   z2 -> BN(c2)+ReLU -> BN(bn1)+ReLU -> MaxPool(3,2,1)
+// (blocks/basics.py:121-123 conv2.{1,2}; torchvision ResNet.bn1 / relu / maxpool kept by backbone.py:63-65).
+//
+// At 256x256 these are the three largest activations of the network (2.1 GB each for E*B = 256
+// images in bf16).  Unfused, forward + backward move ~37 GB through HBM for them; here the two
+// intermediate activations (a2, a3) and their gradients are never materialised: every pass
+// re-derives them from z2 in registers (two fused multiply-adds and two max per element).
+//   forward : stats pass (sum a2, sum a2^2 for bn1)            1 read of z2
+//             pool pass  (a3 -> 3x3/s2 max + winning tap)      1 read of z2, 1/4-size write
+//   backward: phase 1 (bn1:  sum g3, sum g3*xhat1)             1 read of z2 + pooled grad
+//             phase 2 (c2 :  sum g2, sum g2*xhat2)             1 read of z2 + pooled grad
+//             phase 3 (dz2 = BN backward)                      1 read of z2 + pooled grad, 1 write
+// Reductions: per-workgroup LDS, fixed-order partial rows (bit-reproducible).
+#include "common.h"
+
+struct TailConsts {            // per (expert, channel) f32 arrays
+    const float *sc2, *sh2;    // BN(c2) scale/shift
+    const float *sc1, *sh1;    // bn1 scale/shift
+    const float *mu1, *is1;    // bn1 batch mean / invstd (of a2)
+    const float *mu2, *is2;    // BN(c2) batch mean / invstd (of z2)
+    const float *c11, *c21;    // bn1 backward means  (sum g3 / M, sum g3*xhat1 / M)
+    const float *c12, *c22;    // BN(c2) backward means
+};
+
+// MODE 0: forward statistics of a2.  MODE 1/2/3: backward phases.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2, const T* __restrict__ dpool,
+                                                       const uint8_t* __restrict__ amax, T* __restrict__ dz2,
+                                                       TailConsts k, float* __restrict__ part, int nparts, int ipe,
+                                                       int H, int W, int C) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int CV = C / VE, RL = 256 / CV;
+    const int tid = threadIdx.x, cv = tid % CV, rl = tid / CV;
+    const int e = blockIdx.y, pi = blockIdx.x;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    // a workgroup walks whole image rows: the (image,row) decode is wave-uniform, lanes sweep the row
+    const int rows_total = ipe * H;
+    const int rpp = (rows_total + nparts - 1) / nparts;
+    int r0 = pi * rpp, r1 = r0 + rpp;
+    if (r1 > rows_total) r1 = rows_total;
+
+    // per-channel constants, folded so that each phase keeps at most 8 of them live:
+    //   xhat1 = a2*is1 - m1                      da2 = g3*sc1 + a2*P + Q     (bn1 backward)
+    //   xhat2 = z *is2 - m2                      dz2 = g2*sc2 + z *R + S     (conv2-BN backward)
+    float sc2[VE], sh2[VE], sc1[VE], sh1[VE], is1[VE], m1[VE], P[VE], Q[VE], is2[VE], m2[VE], R[VE], S[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+        const int c = e * C + cv * VE + i;
+        sc2[i] = k.sc2[c]; sh2[i] = k.sh2[c];
+        sc1[i] = MODE ? k.sc1[c] : 0.f; sh1[i] = MODE ? k.sh1[c] : 0.f;
+        is1[i] = MODE ? k.is1[c] : 0.f; m1[i] = MODE ? k.mu1[c] * k.is1[c] : 0.f;
+        P[i] = Q[i] = is2[i] = m2[i] = R[i] = S[i] = 0.f;
+        if (MODE >= 2) {
+            const float c11 = k.c11[c], c21 = k.c21[c];
+            P[i] = -is1[i] * sc1[i] * c21;
+            Q[i] = sc1[i] * (m1[i] * c21 - c11);
+            is2[i] = k.is2[c]; m2[i] = k.mu2[c] * k.is2[c];
+        }
+        if (MODE == 3) {
+            const float c12 = k.c12[c], c22 = k.c22[c];
+            R[i] = -sc2[i] * is2[i] * c22;
+            S[i] = sc2[i] * (m2[i] * c22 - c12);
+        }
+    }
+    float s1[VE], s2[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) s1[i] = s2[i] = 0.f;
+
+    for (int row = r0; row < r1; ++row) {
+      // wave-uniform row geometry: scalar base pointers, lanes add a small 32-bit offset
+      const int yy = row % H;
+      const int n = e * ipe + row / H;
+      const T* zrow = z2 + ((size_t)n * H + yy) * W * C;
+      T* dzrow = MODE == 3 ? dz2 + ((size_t)n * H + yy) * W * C : nullptr;
+      const int oyA = yy >> 1, oyB = (yy + 1) >> 1;                  // the one or two pooled rows whose windows hold yy
+      const bool twoRows = oyB != oyA && oyB < Ho;
+      const size_t prA = ((size_t)n * Ho + oyA) * Wo * C, prB = ((size_t)n * Ho + oyB) * Wo * C;
+      const int tapA = (yy - (2 * oyA - 1)) * 3, tapB = (yy - (2 * oyB - 1)) * 3;
+      for (int xx = rl; xx < W; xx += RL) {
+        const int voff = xx * C + cv * VE;
+        float zv[VE], a2[VE];
+        unpack16<T>(ldg16(zrow + voff), zv);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) a2[i] = fmaxf(zv[i] * sc2[i] + sh2[i], 0.f);
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) { s1[i] += a2[i]; s2[i] += a2[i] * a2[i]; }
+            continue;
+        }
+        // gradient arriving at a3 through the max-pool: gather from the <= 4 windows that contain (yy,xx)
+        float g3[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) g3[i] = 0.f;
+        const int oxA = xx >> 1, oxB = (xx + 1) >> 1;
+        auto gather = [&](size_t prow, int ox, int tap) {
+            const size_t po = prow + (size_t)(ox * C + cv * VE);
+            float d[VE];
+            unpack16<T>(ldg16(dpool + po), d);
+            unsigned long long amw;                                  // the VE winning taps as one packed word
+            if (VE == 8) amw = *reinterpret_cast<const unsigned long long*>(amax + po);
+            else amw = *reinterpret_cast<const unsigned*>(amax + po);
+#pragma unroll
+            for (int i = 0; i < VE; ++i)
+                if (((unsigned)(amw >> (8 * i)) & 0xffu) == (unsigned)tap) g3[i] += d[i];
+        };
+        const int tqA = xx - (2 * oxA - 1), tqB = xx - (2 * oxB - 1);
+        const bool twoCols = oxB != oxA && oxB < Wo;
+        gather(prA, oxA, tapA + tqA);
+        if (twoCols) gather(prA, oxB, tapA + tqB);
+        if (twoRows) {
+            gather(prB, oxA, tapB + tqA);
+            if (twoCols) gather(prB, oxB, tapB + tqB);
+        }
+#pragma unroll
+        for (int i = 0; i < VE; ++i) g3[i] = (a2[i] * sc1[i] + sh1[i]) > 0.f ? g3[i] : 0.f;     // ReLU after bn1
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) { s1[i] += g3[i]; s2[i] += g3[i] * (a2[i] * is1[i] - m1[i]); }
+            continue;
+        }
+        float g2[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            const float da2 = g3[i] * sc1[i] + (a2[i] * P[i] + Q[i]);                          // bn1 backward
+            g2[i] = a2[i] > 0.f ? da2 : 0.f;                                                   // ReLU after BN(c2)
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) { s1[i] += g2[i]; s2[i] += g2[i] * (zv[i] * is2[i] - m2[i]); }
+            continue;
+        }
+        float o[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) o[i] = g2[i] * sc2[i] + (zv[i] * R[i] + S[i]);
+        stg16(dzrow + voff, pack16<T>(o));
+      }
+    }
+    if (MODE == 3) return;
+    __shared__ float red[2][256 * 8];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+        red[0][rl * C + cv * VE + i] = s1[i];
+        red[1][rl * C + cv * VE + i] = s2[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * C; c += 256) {
+        const int which = c / C, cc = c % C;
+        float s = 0.f;
+        for (int q = 0; q < RL; ++q) s += red[which][q * C + cc];
+        part[(((size_t)e * nparts + pi) * 2 + which) * C + cc] = s;
+    }
+}
+
+// forward pool pass: a3 = relu(bn1(relu(bn_c2(z2)))) -> max over the 3x3/s2 window (first max wins), tap kept
+template <typename T>
+__global__ void __launch_bounds__(256) stem_tail_pool_kernel(const T* __restrict__ z2, T* __restrict__ y,
+                                                            uint8_t* __restrict__ am, const float* __restrict__ sc2a,
+                                                            const float* __restrict__ sh2a, const float* __restrict__ sc1a,
+                                                            const float* __restrict__ sh1a, int N, int ipe, int H, int W,
+                                                            int C, int Ho, int Wo) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int CV = C / VE;
+    const long long total = (long long)N * Ho * Wo * CV;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        long long t = i / CV;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int e = n / ipe;
+        float sc2[VE], sh2[VE], sc1[VE], sh1[VE];
+#pragma unroll
+        for (int q = 0; q < VE; ++q) {
+            const int c = e * C + cv * VE + q;
+            sc2[q] = sc2a[c]; sh2[q] = sh2a[c]; sc1[q] = sc1a[c]; sh1[q] = sh1a[c];
+        }
+        float best[VE];
+        int bi[VE];
+#pragma unroll
+        for (int q = 0; q < VE; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+        bool first = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) {
+                const int yy = 2 * oy - 1 + r, xx = 2 * ox - 1 + q3;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                    float v[VE];
+                    unpack16<T>(ldg16(z2 + (((size_t)n * H + yy) * W + xx) * C + cv * VE), v);
+#pragma unroll
+                    for (int q = 0; q < VE; ++q) {
+                        const float a2 = fmaxf(v[q] * sc2[q] + sh2[q], 0.f);
+                        // round like the unfused path stores a3 (T precision) so ties resolve identically
+                        const float a3 = to_f32(from_f32<T>(fmaxf(a2 * sc1[q] + sh1[q], 0.f)));
+                        if (first || a3 > best[q]) { best[q] = a3; bi[q] = r * 3 + q3; }
+                    }
+                    first = false;
+                }
+            }
+        const size_t off = (size_t)i * VE;
+        stg16(y + off, pack16<T>(best));
+#pragma unroll
+        for (int q = 0; q < VE; ++q) am[off + q] = (uint8_t)bi[q];
+    }
+}
+
+static inline bool pow2i(int v) { return v > 0 && !(v & (v - 1)); }
+
+extern "C" {
+
+int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, float* part, int32_t nparts, int32_t E,
+                         int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    TailConsts k{};
+    k.sc2 = sc2; k.sh2 = sh2;
+    const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
+    if (C % ve || !pow2i(C / ve) || C / ve > 256 || nparts < 1) return PMOE_ERR_ARG;
+    if (dtype == PMOE_DT_BF16)
+        hipLaunchKernelGGL((stem_tail_kernel<bf16, 0>), dim3(nparts, E), dim3(256), 0, (hipStream_t)stream, (const bf16*)z2,
+                           nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C);
+    else if (dtype == PMOE_DT_F32)
+        hipLaunchKernelGGL((stem_tail_kernel<float, 0>), dim3(nparts, E), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)z2, nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C);
+    else
+        return PMOE_ERR_ARG;
+    return (int)hipGetLastError();
+}
+
+int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* sc2, const float* sh2, const float* sc1,
+                        const float* sh1, int32_t N, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                        void* stream) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
+    if (C % ve || N % ipe) return PMOE_ERR_ARG;
+    long long g = ((long long)N * Ho * Wo * (C / ve) + 255) / 256;
+    if (g > 16384) g = 16384;
+    if (dtype == PMOE_DT_BF16)
+        hipLaunchKernelGGL((stem_tail_pool_kernel<bf16>), dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16*)z2,
+                           (bf16*)y, argmax, sc2, sh2, sc1, sh1, N, ipe, H, W, C, Ho, Wo);
+    else if (dtype == PMOE_DT_F32)
+        hipLaunchKernelGGL((stem_tail_pool_kernel<float>), dim3((int)g), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)z2, (float*)y, argmax, sc2, sh2, sc1, sh1, N, ipe, H, W, C, Ho, Wo);
+    else
+        return PMOE_ERR_ARG;
+    return (int)hipGetLastError();
+}
+
+/* phase 1: part = (sum g3, sum g3*xhat1); phase 2: (sum g2, sum g2*xhat2); phase 3: writes dz2.
+ * consts: 12 per-(expert,channel) f32 arrays in the order of struct TailConsts (unused ones may be null). */
+int pmoe_stem_tail_bwd(int32_t phase, const void* z2, const void* dpool, const uint8_t* argmax, void* dz2,
+                       const float* const* consts, float* part, int32_t nparts, int32_t E, int32_t ipe, int32_t H,
+                       int32_t W, int32_t C, int32_t dtype, void* stream) {
+    TailConsts k{consts[0], consts[1], consts[2], consts[3], consts[4], consts[5],
+                 consts[6], consts[7], consts[8], consts[9], consts[10], consts[11]};
+    const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
+    if (C % ve || !pow2i(C / ve) || C / ve > 256 || nparts < 1 || phase < 1 || phase > 3) return PMOE_ERR_ARG;
+    dim3 grid(nparts, E), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define TAIL_LAUNCH(TT, M)                                                                                           \
+    hipLaunchKernelGGL((stem_tail_kernel<TT, M>), grid, block, 0, st, (const TT*)z2, (const TT*)dpool, argmax, (TT*)dz2, k, \
+                       part, nparts, ipe, H, W, C)
+    if (dtype == PMOE_DT_BF16) {
+        if (phase == 1) TAIL_LAUNCH(bf16, 1); else if (phase == 2) TAIL_LAUNCH(bf16, 2); else TAIL_LAUNCH(bf16, 3);
+    } else if (dtype == PMOE_DT_F32) {
+        if (phase == 1) TAIL_LAUNCH(float, 1); else if (phase == 2) TAIL_LAUNCH(float, 2); else TAIL_LAUNCH(float, 3);
+    } else {
+        return PMOE_ERR_ARG;
+    }
+#undef TAIL_LAUNCH
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -124,6 +124,7 @@ class ExpertGroupEngine:
         self._built_for = None
         self._seed_counter = itertools.count(1)
         self.fuse_conv_stats = True
+        self.fuse_stem_tail = True
         self._collect()
 
     # ------------------------------------------------------------------ structure
@@ -381,26 +382,31 @@ class ExpertGroupEngine:
                        drop_p=x.drop_p if res_mode in (hip.RES_DRELU, hip.RES_DELU) else 0.0)
             x.set_grad(g)
 
-    def _bn(self, z, layer, relu, res=None, stats=None):
-        """y = [relu](bn(z) [+ res]); train mode: batch statistics (fused conv partials or a colstats pass)."""
+    @staticmethod
+    def _nparts(rpe):
+        """partial-sum rows per expert of a streaming reduction: enough workgroups to keep HBM busy
+        (E * nparts blocks of 256 threads), at least 256 rows each."""
+        return min(1024, max(1, rpe // 256))
+
+    def _fold_parts(self, part, nparts, width):
+        """deterministic second stage: [E][nparts][width] -> at most 128 rows before a finalize kernel."""
+        if nparts <= 128:
+            return part, nparts
+        small = torch.empty(self.E, 128, width, dtype=F32, device=self.dev)
+        ops.reduce_partials(part, small, self.E, nparts, 128, width)
+        return small, 128
+
+    def _bn_coeffs(self, layer, rpe, part=None, nparts=0, z=None):
+        """scale/shift/mean/invstd [E,C] of a BatchNorm: batch statistics from partial sums (train) or the
+        running buffers (eval); updates the running statistics in train mode (momentum, unbiased var)."""
         E, C_ = self.E, layer.C
-        n, h, w, _ = z.t.shape
-        rpe = self.B * h * w
         scale, shift, mean, invstd = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(4))
         if self.training:
-            if stats is not None:
-                rows = stats.shape[0] // E
-                part, nparts = stats, rows
-                if stats.shape[2] != C_:
-                    raise RuntimeError("fused stats width mismatch")
-                if rows > 128:
-                    part = torch.empty(E, 128, 2, C_, dtype=F32, device=self.dev)
-                    ops.reduce_partials(stats, part, E, rows, 128, 2 * C_)
-                    nparts = 128
-            else:
-                nparts = min(128, max(1, rpe // 512))
+            if part is None:
+                nparts = self._nparts(rpe)
                 part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
                 ops.colstats(rpe, z.t, E, C_, part, nparts)
+            part, nparts = self._fold_parts(part, nparts, 2 * C_)
             ops.bn_finalize(part, nparts, rpe, self._tab("gamma", layer), self._tab("beta", layer),
                             self._tab("rm", layer), self._tab("rv", layer), layer.momentum, layer.eps, True, scale,
                             shift, mean, invstd, E, C_)
@@ -408,6 +414,16 @@ class ExpertGroupEngine:
         else:
             ops.bn_finalize(scale, 0, rpe, self._tab("gamma", layer), self._tab("beta", layer), self._tab("rm", layer),
                             self._tab("rv", layer), layer.momentum, layer.eps, False, scale, shift, mean, invstd, E, C_)
+        return scale, shift, mean, invstd
+
+    def _bn(self, z, layer, relu, res=None, stats=None):
+        """y = [relu](bn(z) [+ res]); train mode: batch statistics (fused conv partials or a colstats pass)."""
+        E, C_ = self.E, layer.C
+        n, h, w, _ = z.t.shape
+        rpe = self.B * h * w
+        if stats is not None and stats.shape[2] != C_:
+            raise RuntimeError("fused stats width mismatch")
+        scale, shift, mean, invstd = self._bn_coeffs(layer, rpe, stats, stats.shape[0] // E if stats is not None else 0, z)
         y = Var(torch.empty_like(z.t))
         ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, rpe, E, C_, relu)
         y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
@@ -423,9 +439,10 @@ class ExpertGroupEngine:
         if dy is None:
             return
         E, C_ = self.E, layer.C
-        nparts = min(128, max(1, rpe // 512))
+        nparts = self._nparts(rpe)
         part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
         ops.bn_bwd_reduce(dy, ysrc, z.t, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts)
+        part, nparts = self._fold_parts(part, nparts, 2 * C_)
         c1, c2 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(2))
         ops.bn_bwd_finalize(part, nparts, rpe, self._grad_slot("gamma", layer).view(E, C_),
                             self._grad_slot("beta", layer).view(E, C_), c1, c2, E, C_)
@@ -448,6 +465,55 @@ class ExpertGroupEngine:
             if res.grad is not None:
                 raise RuntimeError("residual gradient slot already filled")
             res.set_grad(gm)
+
+    def _stem_tail(self, z2, stats):
+        """relu(bn_c2(z2)) -> relu(bn1(.)) -> maxpool(3,2,1) without materialising the two intermediates
+        (csrc/stem_tail.hip); backward re-derives them from z2 in three streaming passes."""
+        E, C_ = self.E, self.bn_c2.C
+        n, h, w, _ = z2.t.shape
+        rpe = self.B * h * w
+        sc2, sh2, mu2, is2 = self._bn_coeffs(self.bn_c2, rpe, stats, stats.shape[0] // E if stats is not None else 0, z2)
+        nparts = self._nparts(rpe)
+        part = None
+        if self.training:
+            part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
+            ops.stem_tail_stats(z2.t, sc2, sh2, part, nparts, E, self.B)
+        sc1, sh1, mu1, is1 = self._bn_coeffs(self.bn1, rpe, part, nparts)
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = Var(self._new(n, ho, wo, C_))
+        am = torch.empty(n, ho, wo, C_, dtype=torch.uint8, device=self.dev)
+        ops.stem_tail_pool(z2.t, y.t, am, sc2, sh2, sc1, sh1, self.B)
+        y.needs_grad = z2.needs_grad or self.bn_c2.trainable or self.bn1.trainable
+        if self.taping and y.needs_grad:
+            train = self.training
+
+            def bwd():
+                dp = y.grad
+                if dp is None:
+                    return
+                c11, c21, c12, c22 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(4))
+                consts = [sc2, sh2, sc1, sh1, mu1, is1, mu2, is2, c11, c21, c12, c22]
+                p1 = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
+                ops.stem_tail_bwd(1, z2.t, dp, am, None, consts, p1, nparts, E, self.B)
+                pf, nf = self._fold_parts(p1, nparts, 2 * C_)
+                ops.bn_bwd_finalize(pf, nf, rpe, self._grad_slot("gamma", self.bn1).view(E, C_),
+                                    self._grad_slot("beta", self.bn1).view(E, C_), c11, c21, E, C_)
+                if not train:
+                    c11.zero_()
+                    c21.zero_()
+                ops.stem_tail_bwd(2, z2.t, dp, am, None, consts, p1, nparts, E, self.B)
+                pf, nf = self._fold_parts(p1, nparts, 2 * C_)
+                ops.bn_bwd_finalize(pf, nf, rpe, self._grad_slot("gamma", self.bn_c2).view(E, C_),
+                                    self._grad_slot("beta", self.bn_c2).view(E, C_), c12, c22, E, C_)
+                if not train:
+                    c12.zero_()
+                    c22.zero_()
+                if z2.needs_grad:
+                    dz = torch.empty_like(z2.t)
+                    ops.stem_tail_bwd(3, z2.t, dp, am, dz, consts, p1, nparts, E, self.B)
+                    z2.set_grad(dz)
+            self.tape.append(bwd)
+        return y
 
     def _maxpool(self, x):
         n, h, w, c = x.t.shape
@@ -616,9 +682,12 @@ class ExpertGroupEngine:
         a1 = self._bn(z1, self.bn_c1, relu=True, stats=st)
         a1s = self._eca(a1, self.eca2, shared=False)
         z2, st = self._conv_stats(a1s, self.conv2)
-        a2 = self._bn(z2, self.bn_c2, relu=True, stats=st)
-        a3 = self._bn(a2, self.bn1, relu=True)                 # torchvision bn1 + relu stay after the stem
-        o = self._maxpool(a3)
+        if self.fuse_stem_tail:
+            o = self._stem_tail(z2, st)                        # BN+ReLU, bn1+ReLU, maxpool in one fused chain
+        else:
+            a2 = self._bn(z2, self.bn_c2, relu=True, stats=st)
+            a3 = self._bn(a2, self.bn1, relu=True)             # torchvision bn1 + relu stay after the stem
+            o = self._maxpool(a3)
         for blk in self.blocks:
             zA, st = self._conv_stats(o, blk["conv1"])
             aA = self._bn(zA, blk["bn1"], relu=True, stats=st)

@@ -143,6 +143,29 @@ def bn_bwd_apply(dy, y, x, mean, invstd, scale, shift, c1, c2, dx, gmask, rpe, E
                                    rpe, E, C_, int(relu), dt(dy), stream_ptr()), "pmoe_bn_bwd_apply")
 
 
+def stem_tail_stats(z2, sc2, sh2, part, nparts, E, ipe):
+    n, h, w_, c = _nhwc(z2, "z2")
+    check(load().pmoe_stem_tail_stats(ptr(z2, "z2"), ptr(sc2), ptr(sh2), ptr(part, "part", torch.float32), nparts, E, ipe,
+                                      h, w_, c, dt(z2), stream_ptr()), "pmoe_stem_tail_stats")
+
+
+def stem_tail_pool(z2, y, argmax, sc2, sh2, sc1, sh1, ipe):
+    n, h, w_, c = _nhwc(z2, "z2")
+    check(load().pmoe_stem_tail_pool(ptr(z2, "z2"), ptr(y, "y", z2.dtype), ptr(argmax, "argmax", torch.uint8), ptr(sc2),
+                                     ptr(sh2), ptr(sc1), ptr(sh1), n, ipe, h, w_, c, dt(z2), stream_ptr()),
+          "pmoe_stem_tail_pool")
+
+
+def stem_tail_bwd(phase, z2, dpool, argmax, dz2, consts, part, nparts, E, ipe):
+    """consts: list of 12 f32 [E,C] tensors (or None): sc2 sh2 sc1 sh1 mu1 is1 mu2 is2 c11 c21 c12 c22."""
+    n, h, w_, c = _nhwc(z2, "z2")
+    arr = (C.c_void_p * 12)(*[t.data_ptr() if t is not None else None for t in consts])
+    check(load().pmoe_stem_tail_bwd(phase, ptr(z2, "z2"), ptr(dpool, "dpool", z2.dtype),
+                                    ptr(argmax, "argmax", torch.uint8), ptr(dz2, "dz2", z2.dtype), arr,
+                                    ptr(part, "part", torch.float32), nparts, E, ipe, h, w_, c, dt(z2), stream_ptr()),
+          "pmoe_stem_tail_bwd")
+
+
 def maxpool_fwd(x, y, argmax):
     n, h, w_, c = _nhwc(x, "x")
     check(load().pmoe_maxpool3s2_fwd(ptr(x, "x"), ptr(y, "y", x.dtype), ptr(argmax, "argmax", torch.uint8), n, h, w_, c,
@@ -278,7 +301,7 @@ def _timed(fn):
     return wrapper
 
 
-for _n in ("conv2d", "conv2d_wgrad", "pack_conv_weights", "unpack_conv_wgrad", "pack_bias", "colstats",
+for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "conv2d", "conv2d_wgrad", "pack_conv_weights", "unpack_conv_wgrad", "pack_bias", "colstats",
            "reduce_partials", "bn_finalize", "bn_apply", "bn_bwd_reduce", "bn_bwd_finalize", "bn_bwd_apply",
            "maxpool_fwd", "maxpool_bwd", "gap_partial", "gap_finish", "gap_bwd", "eca_gate", "eca_scale",
            "eca_bwd_small", "eca_bwd_apply", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",
