@@ -86,6 +86,8 @@ typedef struct pmoe_wgrad_desc {
     int32_t ipe, x_shared;
     int32_t ks, stride, pad;
     int32_t dtype;
+    int32_t per_image;    /* 1: dw_ws is [N][ks*ks][coutp][cinp], one slab per image (used to derive the ECA
+                           * gate gradient of the stem from per-image filter gradients); needs ho*wo >= 256 */
 } pmoe_wgrad_desc;
 int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
 
@@ -178,10 +180,19 @@ int pmoe_eca_gate(const float* gap_part, int32_t nparts, int64_t HW, const void*
 /* y[n] = x[n or n%ipe] * gate[n]   (x_shared_ipe>0: x holds ipe images shared by all experts) */
 int pmoe_eca_scale(const void* x, const float* gate, void* y, int32_t N, int64_t HW, int32_t C, int32_t x_shared_ipe,
                    int32_t dtype, void* stream);
-/* from dgate-sums (sum_hw dy*x, partials) -> dpre, dgap [N][C] and dw [E][k] (written to the arena) */
+/* from dgate-sums (sum_hw dy*x, partials) -> dpre, dgap [N][C] and dw [E][k] (written to the arena);
+ * dw_scratch: [N][k] f32 caller-owned scratch (per-image partials, summed per expert in fixed order) */
 int pmoe_eca_bwd_small(const float* dot_part, int32_t nparts, const float* gate, const float* gapmean,
-                       const void* const* w_ptrs, int32_t k, float* dgap, float* dw, int32_t N, int32_t ipe,
-                       int32_t C, int32_t creal, void* stream);
+                       const void* const* w_ptrs, int32_t k, float* dgap, float* dw, float* dw_scratch, int32_t N,
+                       int32_t ipe, int32_t C, int32_t creal, void* stream);
+/* Stem input stage (conv1 reads frames * ECA gate): from per-image filter gradients G [N][ks*ks][coutp][cinp]
+ * (pmoe_conv2d_wgrad with per_image=1 on the unscaled, shared frames) produce
+ *   dw [E][cout][cin][ks][ks] = sum_n gate[n][c] * G[n]      and      ds [N][cinp] = sum_{k,t} W[e] * G[n],
+ * the gradient of conv1.weight and of the ECA gate; no data-gradient convolution of conv1 is needed.
+ * gate, ds: [N][gate_ld] f32; w_ptrs: E pointers to f32 [cout][cin][ks][ks]. */
+int pmoe_eca_stem_fold(const float* G, const float* gate, const void* const* w_ptrs, float* dw, float* ds, int32_t N,
+                       int32_t ipe, int32_t cout, int32_t cin, int32_t ks, int32_t coutp, int32_t cinp, int32_t gate_ld,
+                       void* stream);
 /* dx = dy*gate + dgap/HW */
 int pmoe_eca_bwd_apply(const void* dy, const float* gate, const float* dgap, void* dx, int32_t N, int64_t HW,
                        int32_t C, int32_t dtype, void* stream);

@@ -73,7 +73,7 @@ int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream) {
     a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout; a.CoutP = d->coutp;
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.dy_ld = d->dy_ld; a.dy_coff = d->dy_coff;
     a.ipe = d->ipe; a.x_shared = d->x_shared;
-    a.ks = d->ks; a.stride = d->stride; a.pad = d->pad;
+    a.ks = d->ks; a.stride = d->stride; a.pad = d->pad; a.per_image = d->per_image;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = a.mb_per_wg = 0;
     return conv_wgrad_launch(a, d->dtype, (hipStream_t)stream);
 }

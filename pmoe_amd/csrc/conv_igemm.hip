@@ -116,9 +116,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     geo.dilate = a.dilate; geo.shared = a.in_shared; geo.step = step;
     const T* in = (const T*)a.in;
     const bool one_batch = NPIX * CPR <= 12 * NTHR;     // every load of the patch in flight at once
+    const bool big_batch = NPIX * CPR <= 20 * NTHR;     // stride-2 halos (17x33 pixels): one workgroup per CU anyway
     auto load_patch = [&](int c0) {
         if (one_batch) {
             PatchStage<T, LOG_RB, NTHR, 12> ps;
+            ps.issue(in, geo, c0, tid);
+            ps.template commit<0>(patch, NPIX, tid);
+        } else if (big_batch) {
+            PatchStage<T, LOG_RB, NTHR, 20> ps;
             ps.issue(in, geo, c0, tid);
             ps.template commit<0>(patch, NPIX, tid);
         } else {

@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
     const int cin = ci0 + ci_sub * 32 + l31;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-        float* base = a.dw + (((size_t)e * TAPS + tap) * a.CoutP) * a.CinP;
+        const size_t slab = a.per_image ? (size_t)e * a.ipe + blockIdx.x : (size_t)e;      // per image / per expert
+        float* base = a.dw + ((slab * TAPS + tap) * a.CoutP) * a.CinP;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cout = co0 + co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -241,6 +242,10 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st) {
         if (want < 1) want = 1;
         if (want > mbpe) want = mbpe;
         a.mb_per_wg = (mbpe + want - 1) / want;
+        if (a.per_image) {                              // one workgroup walks exactly one image
+            if (TN != 1) return PMOE_ERR_UNSUPPORTED;
+            a.mb_per_wg = a.tiles_y * a.tiles_x;
+        }
         if (need <= M1) return a.ks == 3 ? launch_wg<T, 9, M1>(a, E, smem, st) : launch_wg<T, 1, M1>(a, E, smem, st);
         return a.ks == 3 ? launch_wg<T, 9, M2>(a, E, smem, st) : launch_wg<T, 1, M2>(a, E, smem, st);
     }

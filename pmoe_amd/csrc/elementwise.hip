@@ -451,48 +451,56 @@ __global__ void __launch_bounds__(256) eca_scale_kernel(const T* __restrict__ x,
     }
 }
 
-// grid (E): walks the expert's images; dpre = ds*g*(1-g); dgap = conv1d-transpose(dpre); dw[j] = sum dpre*gm shifted
+// grid (N): one workgroup per image: dpre = ds*g*(1-g); dgap = conv1d-transpose(dpre); per-image dw[j] = sum_c dpre*gm shifted
 __global__ void __launch_bounds__(256) eca_bwd_small_kernel(const float* __restrict__ dot_part, int nparts,
                                                            const float* __restrict__ gate,
                                                            const float* __restrict__ gapmean, const float* const* w,
-                                                           int k, float* __restrict__ dgap, float* __restrict__ dw,
+                                                           int k, float* __restrict__ dgap, float* __restrict__ dw_img,
                                                            int ipe, int C, int creal) {
-    const int e = blockIdx.x;
+    const int n = blockIdx.x, e = n / ipe;
     __shared__ float dpre[1024];
     __shared__ float wacc[256][9];
     const float* we = w[e];
     const int pad = k / 2;
     float dwl[9];
     for (int j = 0; j < 9; ++j) dwl[j] = 0.f;
-    for (int n = e * ipe; n < (e + 1) * ipe; ++n) {
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float s = 0.f;
-            for (int i = 0; i < nparts; ++i) s += dot_part[((size_t)n * nparts + i) * C + c];
-            const float g = gate[(size_t)n * C + c];
-            dpre[c] = c < creal ? s * g * (1.f - g) : 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int i = 0; i < nparts; ++i) s += dot_part[((size_t)n * nparts + i) * C + c];
+        const float g = gate[(size_t)n * C + c];
+        dpre[c] = c < creal ? s * g * (1.f - g) : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float d = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int cc = c - j + pad;
+            if (cc >= 0 && cc < creal) d += we[j] * dpre[cc];
         }
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float d = 0.f;
+        if (dgap) dgap[(size_t)n * C + c] = c < creal ? d : 0.f;
+        if (c < creal)
             for (int j = 0; j < k; ++j) {
-                const int cc = c - j + pad;
-                if (cc >= 0 && cc < creal) d += we[j] * dpre[cc];
+                const int cc = c + j - pad;
+                if (cc >= 0 && cc < creal) dwl[j] += dpre[c] * gapmean[(size_t)n * C + cc];
             }
-            if (dgap) dgap[(size_t)n * C + c] = c < creal ? d : 0.f;
-            if (c < creal)
-                for (int j = 0; j < k; ++j) {
-                    const int cc = c + j - pad;
-                    if (cc >= 0 && cc < creal) dwl[j] += dpre[c] * gapmean[(size_t)n * C + cc];
-                }
-        }
     }
     for (int j = 0; j < 9; ++j) wacc[threadIdx.x][j] = dwl[j];
     __syncthreads();
     if (threadIdx.x < k) {
         float s = 0.f;
         for (int t = 0; t < 256; ++t) s += wacc[t][threadIdx.x];
-        dw[e * k + threadIdx.x] = s;
+        dw_img[(size_t)n * k + threadIdx.x] = s;
+    }
+}
+
+// grid (E): dw[e][j] = sum over the expert's images, fixed order
+__global__ void __launch_bounds__(64) eca_bwd_dw_kernel(const float* __restrict__ dw_img, float* __restrict__ dw, int ipe,
+                                                       int k) {
+    const int e = blockIdx.x, j = threadIdx.x;
+    if (j < k) {
+        float s = 0.f;
+        for (int n = e * ipe; n < (e + 1) * ipe; ++n) s += dw_img[(size_t)n * k + j];
+        dw[e * k + j] = s;
     }
 }
 
@@ -696,11 +704,12 @@ int pmoe_eca_scale(const void* x, const float* gate, void* y, int32_t N, int64_t
 }
 
 int pmoe_eca_bwd_small(const float* dot_part, int32_t nparts, const float* gate, const float* gapmean,
-                       const void* const* w_ptrs, int32_t k, float* dgap, float* dw, int32_t N, int32_t ipe, int32_t C,
-                       int32_t creal, void* stream) {
-    if (C > 1024 || k > 9 || k < 1 || N % ipe) return PMOE_ERR_ARG;
-    hipLaunchKernelGGL(eca_bwd_small_kernel, dim3(N / ipe), dim3(256), 0, (hipStream_t)stream, dot_part, nparts, gate,
-                       gapmean, (const float* const*)w_ptrs, k, dgap, dw, ipe, C, creal);
+                       const void* const* w_ptrs, int32_t k, float* dgap, float* dw, float* dw_scratch, int32_t N,
+                       int32_t ipe, int32_t C, int32_t creal, void* stream) {
+    if (C > 1024 || k > 9 || k < 1 || N % ipe || !dw_scratch) return PMOE_ERR_ARG;
+    hipLaunchKernelGGL(eca_bwd_small_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dot_part, nparts, gate,
+                       gapmean, (const float* const*)w_ptrs, k, dgap, dw_scratch, ipe, C, creal);
+    hipLaunchKernelGGL(eca_bwd_dw_kernel, dim3(N / ipe), dim3(64), 0, (hipStream_t)stream, dw_scratch, dw, ipe, k);
     return (int)hipGetLastError();
 }
 

@@ -205,6 +205,52 @@ __global__ void __launch_bounds__(256) moe_loss_kernel(const float* __restrict__
     if (threadIdx.x == 0) loss[0] = c0 * r1[0] / (float)B + c1 * r2[0] / ((float)B * (float)E * (float)E);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stem input stage: conv1 reads x0 * gate[n][c] (ECA, basics.py:69-76).  From the per-IMAGE filter gradients
+// G[n][t][k][c] = sum_p dz1[n][p][k] * x0[n % B][p + t][c] (conv_wgrad with per_image=1 on the UNscaled frames):
+//   dW[e][k][c][t] = sum_{n in e} gate[n][c] * G[n][t][k][c]          (gradient of conv1.weight)
+//   ds [n][c]      = sum_{k,t} W[e][k][c][t] * G[n][t][k][c]          (gradient wrt the ECA gate)
+// which replaces the whole data-gradient convolution of conv1 (2.2 GB read + 0.5 GB written at B=64).
+__global__ void __launch_bounds__(256) eca_stem_fold_dw_kernel(const float* __restrict__ G, const float* __restrict__ gate,
+                                                              float* __restrict__ dw, int ipe, int cout, int cin,
+                                                              int taps, int coutp, int cinp, int gate_ld) {
+    const int e = blockIdx.y;
+    const int total = cout * cin * taps;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int t = i % taps;
+        const int c = (i / taps) % cin;
+        const int k = i / (taps * cin);
+        float s = 0.f;
+        for (int n = e * ipe; n < (e + 1) * ipe; ++n)
+            s += gate[(size_t)n * gate_ld + c] * G[(((size_t)n * taps + t) * coutp + k) * cinp + c];
+        dw[(size_t)e * total + i] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) eca_stem_fold_ds_kernel(const float* __restrict__ G, const float* const* __restrict__ w,
+                                                              float* __restrict__ ds, int ipe, int cout, int cin, int taps,
+                                                              int coutp, int cinp, int gld) {
+    const int n = blockIdx.x, e = n / ipe;
+    const float* we = w[e];
+    __shared__ float red[256];
+    // thread -> (channel c, slice of the cout*taps terms); gld = row length of gate / ds (16 for the 12-ch stem)
+    const int lanes_per_c = 256 / gld;
+    const int c = threadIdx.x % gld, sl = threadIdx.x / gld;
+    float s = 0.f;
+    if (c < cin)
+        for (int kt = sl; kt < cout * taps; kt += lanes_per_c) {
+            const int k = kt / taps, t = kt % taps;
+            s += we[((size_t)k * cin + c) * taps + t] * G[(((size_t)n * taps + t) * coutp + k) * cinp + c];
+        }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < gld) {
+        float tsum = 0.f;
+        for (int q = 0; q < lanes_per_c; ++q) tsum += red[q * gld + threadIdx.x];
+        ds[(size_t)n * gld + threadIdx.x] = threadIdx.x < cin ? tsum : 0.f;
+    }
+}
+
 static inline int pow2ceil(int v) { int g = 1; while (g < v) g <<= 1; return g; }
 
 extern "C" {
@@ -243,6 +289,19 @@ int pmoe_unpack_conv_wgrad(const float* dw_ws, float* grads, int32_t E, int32_t 
 int pmoe_pack_bias(const void* const* src_ptrs, float* dst, int32_t E, int32_t cout, int32_t coutp, void* stream) {
     hipLaunchKernelGGL(pack_bias_kernel, dim3((coutp + 255) / 256, E), dim3(256), 0, (hipStream_t)stream,
                        (const float* const*)src_ptrs, dst, cout, coutp);
+    return (int)hipGetLastError();
+}
+
+int pmoe_eca_stem_fold(const float* G, const float* gate, const void* const* w_ptrs, float* dw, float* ds, int32_t N,
+                       int32_t ipe, int32_t cout, int32_t cin, int32_t ks, int32_t coutp, int32_t cinp, int32_t gate_ld,
+                       void* stream) {
+    if (N % ipe || gate_ld > 256 || 256 % gate_ld || cin > cinp || cin > gate_ld || cout > coutp) return PMOE_ERR_ARG;
+    const int taps = ks * ks, E = N / ipe;
+    int g = (cout * cin * taps + 255) / 256;
+    hipLaunchKernelGGL(eca_stem_fold_dw_kernel, dim3(g, E), dim3(256), 0, (hipStream_t)stream, G, gate, dw, ipe, cout, cin,
+                       taps, coutp, cinp, gate_ld);
+    hipLaunchKernelGGL(eca_stem_fold_ds_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, G,
+                       (const float* const*)w_ptrs, ds, ipe, cout, cin, taps, coutp, cinp, gate_ld);
     return (int)hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ struct WgradArgs {
     int x_ld, x_coff, dy_ld, dy_coff;
     int ipe, x_shared;
     int ks, stride, pad;
+    int per_image;         // 1: dw is [N][taps][CoutP][CinP] -- one slab per IMAGE (no sum over the expert's images)
     int lTW, lTH, TN, n_groups, tiles_y, tiles_x, mb_per_wg;
 };
 

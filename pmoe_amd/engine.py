@@ -125,6 +125,7 @@ class ExpertGroupEngine:
         self._seed_counter = itertools.count(1)
         self.fuse_conv_stats = True
         self.fuse_stem_tail = True
+        self.fold_stem_input = True
         self._collect()
 
     # ------------------------------------------------------------------ structure
@@ -302,7 +303,7 @@ class ExpertGroupEngine:
         return torch.empty(n, h, w, c, dtype=dtype or self.dtype, device=self.dev)
 
     def _conv(self, x, layer, *, bias=True, act=hip.ACT_NONE, drop_p=0.0, out=None, out_coff=0, in_shared=False,
-              want_stats=False):
+              want_stats=False, tape=True):
         H, W = x.t.shape[1], x.t.shape[2]
         Ho = ops.conv_out_size(H, layer.ks, layer.stride, layer.pad)
         Wo = ops.conv_out_size(W, layer.ks, layer.stride, layer.pad)
@@ -326,7 +327,7 @@ class ExpertGroupEngine:
         o.needs_grad = x.needs_grad or layer.trainable
         if out is not None and o.needs_grad:
             out.needs_grad = True
-        if self.taping and o.needs_grad:
+        if tape and self.taping and o.needs_grad:
             self.tape.append(lambda: self._conv_bwd(x, layer, o, in_shared, flop))
         return (o, stats) if want_stats else o
 
@@ -535,7 +536,7 @@ class ExpertGroupEngine:
     def _gap_parts(self, hw):
         return min(16, max(1, hw // 1024))
 
-    def _eca(self, x, layer, shared):
+    def _eca(self, x, layer, shared, tape=True):
         """y[n] = x[n or n % B] * sigmoid(conv1d(GAP(x)))  (EfficientBlock, basics.py:69-76)."""
         nx, h, w, c = x.t.shape
         hw = h * w
@@ -549,6 +550,8 @@ class ExpertGroupEngine:
         y = Var(self._new(self.N, h, w, c))
         ops.eca_scale(x.t, gate, y.t, self.B if shared else 0)
         y.needs_grad = x.needs_grad or layer.trainable
+        if not tape:
+            return y, gate, gapmean
         if self.taping and y.needs_grad:
             def bwd():
                 dy = y.grad
@@ -677,8 +680,16 @@ class ExpertGroupEngine:
 
         feat = Var(self._new(self.N, 1, 1, 1536))
         # ---- perception stack: ResNet18 body with the ECA stem (backbone.py:63-70, basics.py:79-134)
-        x0s = self._eca(x0, self.eca1, shared=True)
-        z1, st = self._conv_stats(x0s, self.conv1)
+        hw_ok = H * W >= 256                                 # per-image filter gradients need one tile <= one image
+        if self.fold_stem_input and self.taping and hw_ok and (self.conv1.trainable or self.eca1.trainable):
+            # backward of (ECA gate -> conv1) from per-image filter gradients: no data-gradient conv (heads.hip)
+            x0s, gate, gapmean = self._eca(x0, self.eca1, shared=True, tape=False)
+            z1, st = self._conv_stats(x0s, self.conv1, tape=False)
+            z1.needs_grad = True
+            self.tape.append(lambda: self._stem_in_bwd(x0, z1, gate, gapmean))
+        else:
+            x0s = self._eca(x0, self.eca1, shared=True)
+            z1, st = self._conv_stats(x0s, self.conv1)
         a1 = self._bn(z1, self.bn_c1, relu=True, stats=st)
         a1s = self._eca(a1, self.eca2, shared=False)
         z2, st = self._conv_stats(a1s, self.conv2)
@@ -722,10 +733,32 @@ class ExpertGroupEngine:
         self.tape = None
         return probs, mean, std, speeds, state
 
-    def _conv_stats(self, x, layer):
+    def _conv_stats(self, x, layer, tape=True):
         if self.training and self.fuse_conv_stats:
-            return self._conv(x, layer, bias=False, want_stats=True)
-        return self._conv(x, layer, bias=False), None
+            return self._conv(x, layer, bias=False, want_stats=True, tape=tape)
+        return self._conv(x, layer, bias=False, tape=tape), None
+
+    def _stem_in_bwd(self, x0, z1, gate, gapmean):
+        dy = z1.grad
+        if dy is None:
+            return
+        E, layer, ecal = self.E, self.conv1, self.eca1
+        ckw = 64 if self.dtype == torch.bfloat16 else 32
+        cpw = (layer.cinp + ckw - 1) // ckw * ckw
+        cow = (layer.cout_st + ckw - 1) // ckw * ckw
+        G = self._wgrad_ws(self.N * layer.taps * cow * cpw)
+        G.zero_()
+        ops.set_meta(flop=2.0 * self.N * dy.shape[1] * dy.shape[2] * layer.cout * layer.cin * layer.taps, name=layer.name)
+        ops.conv2d_wgrad(x0.t, dy, G, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B, ks=layer.ks,
+                         stride=1, pad=layer.pad, x_shared=True, per_image=True)
+        ds = torch.empty(self.N, gate.shape[-1], dtype=F32, device=self.dev)
+        dw = self._grad_slot("w", layer) if layer.trainable else torch.empty(E * layer.cout * layer.cin * layer.taps,
+                                                                             dtype=F32, device=self.dev)
+        ops.eca_stem_fold(G, gate, self._tab("w", layer), dw, ds, self.N, self.B, layer.cout, layer.cin, layer.ks, cow, cpw)
+        if ecal.trainable:
+            # ds plays the role of the (single) partial row of sum_hw dy*x in the generic ECA backward
+            ops.eca_bwd_small(ds, 1, gate, gapmean, self._tab("eca", ecal), ecal.k, None,
+                              self._grad_slot("eca", ecal).view(E, ecal.k), self.N, self.B, gate.shape[-1], ecal.creal)
 
     def _merge_alt_head(self, head, al):
         """moe_alt: alpha comes from its own MLP; place it in column 4 of the head rows (device copy)."""

@@ -48,6 +48,7 @@ class WgradDesc(C.Structure):
         ("x_ld", C.c_int32), ("x_coff", C.c_int32), ("dy_ld", C.c_int32), ("dy_coff", C.c_int32),
         ("ipe", C.c_int32), ("x_shared", C.c_int32),
         ("ks", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dtype", C.c_int32),
+        ("per_image", C.c_int32),
     ]
 
 
@@ -81,7 +82,8 @@ SIGNATURES = {
     "pmoe_gap_bwd": [_P, _P, _I, _L, _I, _I, _I, _I, _P],
     "pmoe_eca_gate": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "pmoe_eca_scale": [_P, _P, _P, _I, _L, _I, _I, _I, _P],
-    "pmoe_eca_bwd_small": [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "pmoe_eca_bwd_small": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pmoe_eca_stem_fold": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_eca_bwd_apply": [_P, _P, _P, _P, _I, _L, _I, _I, _P],
     "pmoe_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pad_rows": [_P, _P, _I, _I, _I, _I, _P],

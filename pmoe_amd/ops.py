@@ -69,7 +69,8 @@ def conv2d_stat_rows(n, h, w_, ho, wo, cin, cout, coutp, ipe, ks, stride, pad, d
     return rows
 
 
-def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, x_shared=False, x_coff=0, dy_coff=0):
+def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, x_shared=False, x_coff=0, dy_coff=0,
+                 per_image=False):
     nin, h, w_, ldx = _nhwc(x, "x")
     n, ho, wo, ldy = _nhwc(dy, "dy")
     d = WgradDesc()
@@ -79,7 +80,8 @@ def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, 
     d.x_ld, d.x_coff, d.dy_ld, d.dy_coff = ldx, x_coff, ldy, dy_coff
     d.ipe, d.x_shared = ipe, int(x_shared)
     d.ks, d.stride, d.pad, d.dtype = ks, stride, pad, dt(x)
-    if dw_ws.numel() < (n // ipe) * ks * ks * coutp * cinp:
+    d.per_image = int(per_image)
+    if dw_ws.numel() < (n if per_image else n // ipe) * ks * ks * coutp * cinp:
         raise ValueError("conv2d_wgrad: workspace too small")
     check(load().pmoe_conv2d_wgrad(C.byref(d), stream_ptr()), "pmoe_conv2d_wgrad")
     return dw_ws
@@ -208,8 +210,17 @@ def eca_scale(x, gate, y, x_shared_ipe=0):
 
 
 def eca_bwd_small(dot_part, nparts, gate, gapmean, w_tab, k, dgap, dw, n, ipe, c, creal):
+    scratch = torch.empty(n, k, dtype=torch.float32, device=gate.device)
     check(load().pmoe_eca_bwd_small(ptr(dot_part), nparts, ptr(gate), ptr(gapmean), ptr(w_tab), k, ptr(dgap), ptr(dw),
-                                    n, ipe, c, creal, stream_ptr()), "pmoe_eca_bwd_small")
+                                    ptr(scratch), n, ipe, c, creal, stream_ptr()), "pmoe_eca_bwd_small")
+
+
+def eca_stem_fold(G, gate, w_tab, dw, ds, n, ipe, cout, cin, ks, coutp, cinp):
+    f32 = torch.float32
+    check(load().pmoe_eca_stem_fold(ptr(G, "G", f32), ptr(gate, "gate", f32), ptr(w_tab), ptr(dw, "dw", f32),
+                                    ptr(ds, "ds", f32), n, ipe, cout, cin, ks, coutp, cinp, gate.shape[-1],
+                                    stream_ptr()),
+          "pmoe_eca_stem_fold")
 
 
 def eca_bwd_apply(dy, gate, dgap, dx):
@@ -304,6 +315,6 @@ def _timed(fn):
 for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "conv2d", "conv2d_wgrad", "pack_conv_weights", "unpack_conv_wgrad", "pack_bias", "colstats",
            "reduce_partials", "bn_finalize", "bn_apply", "bn_bwd_reduce", "bn_bwd_finalize", "bn_bwd_apply",
            "maxpool_fwd", "maxpool_bwd", "gap_partial", "gap_finish", "gap_bwd", "eca_gate", "eca_scale",
-           "eca_bwd_small", "eca_bwd_apply", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",
+           "eca_bwd_small", "eca_bwd_apply", "eca_stem_fold", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",
            "moe_loss"):
     globals()[_n] = _timed(globals()[_n])

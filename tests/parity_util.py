@@ -22,7 +22,8 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 # Gradients -- the random-weight 20-layer ReLU/BN network is chaotic for gradients: tools/bf16_conditioning.py
 # shows the CPU oracle in f32 vs f64 differs by up to 2e-2 rel-L2 on some tensors, and the oracle with
 # bf16-rounded activations differs from f64 by a MEDIAN of 0.4 rel-L2 (DESIGN.md "numerics").  So:
-#   f32 : every parameter gradient rel-L2 <= 2e-2 vs the oracle, median <= 5e-3, and the reference's golden
+#   f32 : every parameter gradient within max(5e-3, 4x the f32-oracle's own drift from the f64 oracle) of the
+#         float64 oracle (conditioning-aware), median rel-L2 vs the f32 oracle <= 5e-3, and the reference's golden
 #         gradient slices / norms; this is what proves the backward algorithm.
 #   bf16: statistical agreement only (median cosine >= 0.85, total norm within 20%); the bf16 KERNELS are
 #         held to 1e-2 per op in tests/test_ops_gpu.py.
@@ -109,7 +110,20 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
         errs.sort()
         report["grad_median_rel_l2"], report["grad_worst"] = errs[len(errs) // 2][0], errs[-1]
         if dtype == torch.float32:
-            assert errs[-1][0] <= GRAD_TOL[dtype], f"{name} grad {errs[-1][1]}: rel L2 {errs[-1][0]:.3e}"
+            # conditioning-aware bound: the same oracle in float64 tells how far two exact-f32 evaluations of this
+            # tensor can drift apart; the HIP f32 path must stay within 4x that (floor 5e-3) of the f64 truth
+            import copy
+            o64 = copy.deepcopy(oracle).double()
+            o64.zero_grad()
+            d64, s64 = o64(inp["images"].double(), inp["speed"].double(), inp["command"].double())
+            O.moe_loss(d64, s64, inp["control"].double(), inp["target_speed"].double(), ocfg.loss_coefs).backward()
+            g64 = {k: p.grad.float() for k, p in o64.named_parameters()}
+            for k, p in named.items():
+                if g64[k].norm().item() < 1e-6 * total_ref:
+                    continue
+                e_ref = rel_l2(onamed[k].grad, g64[k])
+                e_hip = rel_l2(p.grad, g64[k])
+                assert e_hip <= max(5e-3, 4 * e_ref), f"{name} grad {k}: {e_hip:.3e} vs f32-oracle drift {e_ref:.3e}"
             assert errs[len(errs) // 2][0] <= GRAD_MEDIAN_TOL, errs[len(errs) // 2]
             assert abs(total - total_ref) <= 1e-3 * total_ref
             # golden slices produced by the reference itself (not just the oracle)

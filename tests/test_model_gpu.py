@@ -126,3 +126,21 @@ def test_fused_stem_tail_matches_unfused(dtype):
         errs = sorted(((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-20)).item() for k in ga if gb[k].norm() > 1e-8)
         assert errs[len(errs) // 2] <= 1e-3, errs[len(errs) // 2]
         assert errs[int(0.95 * len(errs))] <= 2e-2, errs[int(0.95 * len(errs))]
+
+
+def test_stem_input_fold_matches_dgrad_path():
+    """conv1.weight / eca1 gradients from per-image filter gradients (eca_stem_fold) vs the explicit
+    data-gradient convolution + ECA backward."""
+    from pmoe_amd.loss import moe_loss
+    g = torch.load(GOLDEN / "g5_moe_e3_b3_96.pt", weights_only=False)
+    grads = []
+    for fold in (True, False):
+        _, _, model, inp = build_pair(g, torch.float32)
+        model._engine().fold_stem_input = fold
+        dev = {k: v.cuda() for k, v in inp.items()}
+        dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+        moe_loss(dist, speeds, dev["control"], dev["target_speed"], [0.7, 0.3]).backward()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if "conv1.layer1" in k})
+    for k in grads[0]:
+        e = ((grads[0][k] - grads[1][k]).norm() / (grads[1][k].norm() + 1e-20)).item()
+        assert e <= 1e-4, (k, e)
