@@ -108,9 +108,11 @@ int pmoe_pack_bias(const void* const* src_ptrs, float* dst, int32_t E, int32_t c
 
 /* ---- BatchNorm2d, training mode (nn.BatchNorm2d at basics.py:101,121; torchvision bn1/bn2/downsample.1)
  * rows = N*H*W activations of C channels; expert e owns rows [e*rows_per_expert, ...).            */
-/* per-(expert,channel) partial sums: part [E][nparts][2][C] f32 */
+/* per-(expert,channel) partial sums: part [E][nparts][2][C] f32 of (x - c) and (x - c)^2, where c = the channel's
+ * value in the expert's first row, written to shiftc [E][C] (null: c = 0, plain sums).  Summing deviations from a
+ * sample keeps the variance exact-to-rounding even when |mean| >> std. */
 int pmoe_colstats(const void* x, int64_t rows_per_expert, int32_t E, int32_t C, int32_t ld, int32_t coff,
-                  float* part, int32_t nparts, int32_t dtype, void* stream);
+                  float* part, int32_t nparts, float* shiftc, int32_t dtype, void* stream);
 /* deterministic tree step: part_in [E][nin][W] -> part_out [E][nout][W] (W = 2*C floats) */
 int pmoe_reduce_partials(const float* part_in, float* part_out, int32_t E, int32_t nin, int32_t nout, int32_t width,
                          void* stream);
@@ -120,7 +122,7 @@ int pmoe_reduce_partials(const float* part_in, float* part_out, int32_t E, int32
 int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const void* const* gamma_ptrs,
                      const void* const* beta_ptrs, void* const* rmean_ptrs, void* const* rvar_ptrs, float momentum,
                      float eps, int32_t training, float* scale, float* shift, float* mean, float* invstd, int32_t E,
-                     int32_t C, void* stream);
+                     int32_t C, const float* shiftc, void* stream);
 /* y = [relu]( x*scale + shift [+ res] ) */
 int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,
                   int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream);
@@ -159,8 +161,8 @@ int pmoe_gap_bwd(const void* g, void* dx, int32_t N, int64_t HW, int32_t C, int3
  * The two intermediate activations and their gradients are re-derived from z2 in registers, never stored.
  * All per-channel arrays are [E][C] f32.  part: [E][nparts][2][C] partial sums (finish with pmoe_bn_finalize /
  * pmoe_bn_bwd_finalize). */
-int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, float* part, int32_t nparts, int32_t E,
-                         int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, float* part, int32_t nparts, float* shiftc,
+                         int32_t E, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* sc2, const float* sh2, const float* sc1,
                         const float* sh1, int32_t N, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype,
                         void* stream);

@@ -22,7 +22,8 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
                                                       const T* __restrict__ y, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, long long rpe, int C, int ld,
-                                                      int coff, int relu, float* __restrict__ part, int nparts) {
+                                                      int coff, int relu, float* __restrict__ part, int nparts,
+                                                      float* __restrict__ shiftc) {
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE, RL = 256 / CV;
     const int tid = threadIdx.x, cv = tid % CV, rl = tid / CV;
@@ -41,13 +42,26 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
         sh[i] = remask ? shift[e * C + cv * VE + i] : 0.f;
     }
     const size_t ebase = (size_t)e * rpe;
+    // MODE 0 accumulates DEVIATIONS from one sample of the channel (row 0 of the expert): sum(x-c), sum(x-c)^2.
+    // var = E[(x-c)^2] - E[x-c]^2 then has no catastrophic cancellation even for a near-constant channel
+    // (|mean| >> std), where the textbook E[x^2]-mean^2 in f32 loses all digits of the variance.
+    float c0v[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) c0v[i] = 0.f;
+    if (MODE == 0 && shiftc) {
+        unpack16<T>(ldg16(x + ebase * ld + coff + cv * VE), c0v);
+        if (pi == 0 && rl == 0) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) shiftc[e * C + cv * VE + i] = c0v[i];
+        }
+    }
     for (long long r = r0 + rl; r < r1; r += RL) {
         const size_t off = (ebase + r) * ld + coff + cv * VE;
         float xv[VE];
         unpack16<T>(ldg16(x + off), xv);
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < VE; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
+            for (int i = 0; i < VE; ++i) { const float d = xv[i] - c0v[i]; s1[i] += d; s2[i] += d * d; }
         } else {
             float gv[VE], yv[VE];
             unpack16<T>(ldg16(dy + off), gv);
@@ -81,16 +95,16 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
 template <typename T>
 static int colstats_launch(const void* x, const void* dy, const void* y, const float* mean, const float* invstd,
                            const float* scale, const float* shift, long long rpe, int E, int C, int ld, int coff, int relu, float* part, int nparts, int mode,
-                           hipStream_t st) {
+                           float* shiftc, hipStream_t st) {
     constexpr int VE = 16 / (int)sizeof(T);
     if (C % VE || !pow2(C / VE) || C / VE > 256 || nparts < 1) return PMOE_ERR_ARG;
     dim3 grid(nparts, E), block(256);
     if (mode == 0)
         hipLaunchKernelGGL((colstats_kernel<T, 0>), grid, block, 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, rpe, C, ld, coff, 0, part, nparts);
+                           nullptr, nullptr, rpe, C, ld, coff, 0, part, nparts, shiftc);
     else
         hipLaunchKernelGGL((colstats_kernel<T, 1>), grid, block, 0, st, (const T*)x, (const T*)dy, (const T*)y, mean,
-                           invstd, scale, shift, rpe, C, ld, coff, relu, part, nparts);
+                           invstd, scale, shift, rpe, C, ld, coff, relu, part, nparts, nullptr);
     return (int)hipGetLastError();
 }
 
@@ -112,7 +126,8 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
                                                          const float* const* gamma, const float* const* beta,
                                                          float* const* rmean, float* const* rvar, float momentum,
                                                          float eps, int training, float* scale, float* shift,
-                                                         float* mean_o, float* invstd_o, int C) {
+                                                         float* mean_o, float* invstd_o, int C,
+                                                         const float* __restrict__ shiftc) {
     const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     __shared__ float red[2][4][64];
     float s1 = 0.f, s2 = 0.f;
@@ -129,9 +144,10 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
         if (training) {
             const float t1 = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
             const float t2 = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
-            const double m = (double)t1 / (double)count;
-            double v = (double)t2 / (double)count - m * m;
+            const double md = (double)t1 / (double)count;          // mean of the deviations x - c
+            double v = (double)t2 / (double)count - md * md;
             if (v < 0.0) v = 0.0;
+            const double m = md + (shiftc ? (double)shiftc[e * C + c] : 0.0);
             mean = (float)m;
             var = (float)v;
             if (rmean && rmean[e]) {
@@ -428,7 +444,7 @@ __global__ void __launch_bounds__(256) eca_gate_kernel(const float* __restrict__
             const int cc = c + j - pad;
             if (cc >= 0 && cc < creal) z += we[j] * gm[cc];
         }
-        gate[(size_t)n * C + c] = c < creal ? 1.f / (1.f + __expf(-z)) : 0.f;
+        gate[(size_t)n * C + c] = c < creal ? 1.f / (1.f + expf(-z)) : 0.f;
         gapmean[(size_t)n * C + c] = gm[c];
     }
 }
@@ -561,9 +577,9 @@ static inline int grid_for(long long nvec, int cap = 4096) {
 extern "C" {
 
 int pmoe_colstats(const void* x, int64_t rows_per_expert, int32_t E, int32_t C, int32_t ld, int32_t coff, float* part,
-                  int32_t nparts, int32_t dtype, void* stream) {
+                  int32_t nparts, float* shiftc, int32_t dtype, void* stream) {
     DISPATCH_DT(dtype, return colstats_launch<T>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows_per_expert, E, C, ld, coff,
-                                                 0, part, nparts, 0, (hipStream_t)stream));
+                                                 0, part, nparts, 0, shiftc, (hipStream_t)stream));
 }
 
 int pmoe_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
@@ -571,7 +587,7 @@ int pmoe_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float
                        int32_t dtype, void* stream) {
     if (relu && !y && (!scale || !shift)) return PMOE_ERR_ARG;
     DISPATCH_DT(dtype, return colstats_launch<T>(x, dy, y, mean, invstd, scale, shift, rows_per_expert, E, C, C, 0, relu, part,
-                                                 nparts, 1, (hipStream_t)stream));
+                                                 nparts, 1, nullptr, (hipStream_t)stream));
 }
 
 int pmoe_reduce_partials(const float* part_in, float* part_out, int32_t E, int32_t nin, int32_t nout, int32_t width,
@@ -585,12 +601,12 @@ int pmoe_reduce_partials(const float* part_in, float* part_out, int32_t E, int32
 int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const void* const* gamma_ptrs,
                      const void* const* beta_ptrs, void* const* rmean_ptrs, void* const* rvar_ptrs, float momentum,
                      float eps, int32_t training, float* scale, float* shift, float* mean, float* invstd, int32_t E,
-                     int32_t C, void* stream) {
+                     int32_t C, const float* shiftc, void* stream) {
     if (!training && (!rmean_ptrs || !rvar_ptrs)) return PMOE_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, E), dim3(256), 0, (hipStream_t)stream, part, nparts,
                        (long long)count, (const float* const*)gamma_ptrs, (const float* const*)beta_ptrs,
                        (float* const*)rmean_ptrs, (float* const*)rvar_ptrs, momentum, eps, training, scale, shift, mean,
-                       invstd, C);
+                       invstd, C, shiftc);
     return (int)hipGetLastError();
 }
 

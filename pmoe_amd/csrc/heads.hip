@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) gate_fwd_kernel(const T* __restrict__ hea
     if (!live) a = -INFINITY;
     float m = a;
     for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
-    const float ex = live ? __expf(a - m) : 0.f;
+    const float ex = live ? expf(a - m) : 0.f;
     float s = ex;
     for (int off = 1; off < G; off <<= 1) s += __shfl_xor(s, off);
     if (live) {
@@ -116,8 +116,8 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const T* __restrict__ hea
         T* drow = dhead + ((size_t)e * B + b) * head_ld;
         drow[0] = from_f32<T>(dmean ? dmean[o * 2 + 0] : 0.f);
         drow[1] = from_f32<T>(dmean ? dmean[o * 2 + 1] : 0.f);
-        drow[2] = from_f32<T>(dstd ? dstd[o * 2 + 0] * (r2 > 0.f ? 1.f : __expf(r2)) : 0.f);
-        drow[3] = from_f32<T>(dstd ? dstd[o * 2 + 1] * (r3 > 0.f ? 1.f : __expf(r3)) : 0.f);
+        drow[2] = from_f32<T>(dstd ? dstd[o * 2 + 0] * (r2 > 0.f ? 1.f : expf(r2)) : 0.f);
+        drow[3] = from_f32<T>(dstd ? dstd[o * 2 + 1] * (r3 > 0.f ? 1.f : expf(r3)) : 0.f);
         drow[4] = from_f32<T>(da);
         for (int i = 5; i < head_ld; ++i) drow[i] = from_f32<T>(0.f);
         T* srow = dspd + ((size_t)e * B + b) * spd_ld;
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) moe_loss_kernel(const float* __restrict__
                 sg[d] = sd[o * 2 + d];
                 a[d] = act[b * 2 + d];
                 const float z = (a[d] - mu[d]) / sg[d];
-                comp += -0.5f * z * z - __logf(sg[d]) - HALF_LOG_2PI;
+                comp += -0.5f * z * z - logf(sg[d]) - HALF_LOG_2PI;
             }
             spv = speeds[o];
             tg = tgt[b];
@@ -164,22 +164,22 @@ __global__ void __launch_bounds__(256) moe_loss_kernel(const float* __restrict__
         for (int off = 1; off < G; off <<= 1) ps += __shfl_xor(ps, off);
         const float pn = live ? p / ps : 0.f;
         const bool clamped = pn < EPS || pn > 1.f - EPS;
-        const float l = live ? __logf(fminf(fmaxf(pn, EPS), 1.f - EPS)) : -INFINITY;
+        const float l = live ? logf(fminf(fmaxf(pn, EPS), 1.f - EPS)) : -INFINITY;
         float lm = l;
         for (int off = 1; off < G; off <<= 1) lm = fmaxf(lm, __shfl_xor(lm, off));
-        float ls = live ? __expf(l - lm) : 0.f;
+        float ls = live ? expf(l - lm) : 0.f;
         for (int off = 1; off < G; off <<= 1) ls += __shfl_xor(ls, off);
-        const float lsm = l - (lm + __logf(ls));                 // log_softmax of the logits
+        const float lsm = l - (lm + logf(ls));                 // log_softmax of the logits
         const float t = live ? comp + lsm : -INFINITY;
         float tm = t;
         for (int off = 1; off < G; off <<= 1) tm = fmaxf(tm, __shfl_xor(tm, off));
-        float ts = live ? __expf(t - tm) : 0.f;
+        float ts = live ? expf(t - tm) : 0.f;
         for (int off = 1; off < G; off <<= 1) ts += __shfl_xor(ts, off);
-        const float ll = tm + __logf(ts);
+        const float ll = tm + logf(ts);
         if (live) {
             const size_t o = (size_t)b * E + e;
-            const float r = __expf(t - ll);                       // responsibility of expert e
-            const float q = __expf(lsm);
+            const float r = expf(t - ll);                       // responsibility of expert e
+            const float q = expf(lsm);
             const float gs = -c0 / (float)B;                      // d loss / d ll_b
             if (e == 0) { nll_acc += -ll; if (loglik) loglik[b] = ll; }
             // d ll / d p_j = (r_j - q_j)/p_j  (normalisation terms cancel because sum r = sum q = 1)

@@ -27,7 +27,7 @@ template <typename T, int MODE>
 __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2, const T* __restrict__ dpool,
                                                        const uint8_t* __restrict__ amax, T* __restrict__ dz2,
                                                        TailConsts k, float* __restrict__ part, int nparts, int ipe,
-                                                       int H, int W, int C) {
+                                                       int H, int W, int C, float* __restrict__ shiftc) {
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE, RL = 256 / CV;
     const int tid = threadIdx.x, cv = tid % CV, rl = tid / CV;
@@ -65,6 +65,20 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
     float s1[VE], s2[VE];
 #pragma unroll
     for (int i = 0; i < VE; ++i) s1[i] = s2[i] = 0.f;
+    // MODE 0: deviations from the channel's value at the expert's first pixel (see colstats_kernel)
+    float c0v[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) c0v[i] = 0.f;
+    if (MODE == 0 && shiftc) {
+        float z0[VE];
+        unpack16<T>(ldg16(z2 + (size_t)e * ipe * H * W * C + cv * VE), z0);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) c0v[i] = fmaxf(z0[i] * sc2[i] + sh2[i], 0.f);
+        if (pi == 0 && rl == 0) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) shiftc[e * C + cv * VE + i] = c0v[i];
+        }
+    }
 
     for (int row = r0; row < r1; ++row) {
       // wave-uniform row geometry: scalar base pointers, lanes add a small 32-bit offset
@@ -84,7 +98,7 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
         for (int i = 0; i < VE; ++i) a2[i] = fmaxf(zv[i] * sc2[i] + sh2[i], 0.f);
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < VE; ++i) { s1[i] += a2[i]; s2[i] += a2[i] * a2[i]; }
+            for (int i = 0; i < VE; ++i) { const float d = a2[i] - c0v[i]; s1[i] += d; s2[i] += d * d; }
             continue;
         }
         // gradient arriving at a3 through the max-pool: gather from the <= 4 windows that contain (yy,xx)
@@ -208,18 +222,18 @@ static inline bool pow2i(int v) { return v > 0 && !(v & (v - 1)); }
 
 extern "C" {
 
-int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, float* part, int32_t nparts, int32_t E,
-                         int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, float* part, int32_t nparts, float* shiftc,
+                         int32_t E, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
     TailConsts k{};
     k.sc2 = sc2; k.sh2 = sh2;
     const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
     if (C % ve || !pow2i(C / ve) || C / ve > 256 || nparts < 1) return PMOE_ERR_ARG;
     if (dtype == PMOE_DT_BF16)
         hipLaunchKernelGGL((stem_tail_kernel<bf16, 0>), dim3(nparts, E), dim3(256), 0, (hipStream_t)stream, (const bf16*)z2,
-                           nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C);
+                           nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C, shiftc);
     else if (dtype == PMOE_DT_F32)
         hipLaunchKernelGGL((stem_tail_kernel<float, 0>), dim3(nparts, E), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)z2, nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C);
+                           (const float*)z2, nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C, shiftc);
     else
         return PMOE_ERR_ARG;
     return (int)hipGetLastError();
@@ -257,7 +271,7 @@ int pmoe_stem_tail_bwd(int32_t phase, const void* z2, const void* dpool, const u
     hipStream_t st = (hipStream_t)stream;
 #define TAIL_LAUNCH(TT, M)                                                                                           \
     hipLaunchKernelGGL((stem_tail_kernel<TT, M>), grid, block, 0, st, (const TT*)z2, (const TT*)dpool, argmax, (TT*)dz2, k, \
-                       part, nparts, ipe, H, W, C)
+                       part, nparts, ipe, H, W, C, nullptr)
     if (dtype == PMOE_DT_BF16) {
         if (phase == 1) TAIL_LAUNCH(bf16, 1); else if (phase == 2) TAIL_LAUNCH(bf16, 2); else TAIL_LAUNCH(bf16, 3);
     } else if (dtype == PMOE_DT_F32) {

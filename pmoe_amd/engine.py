@@ -126,6 +126,7 @@ class ExpertGroupEngine:
         self.fuse_conv_stats = True
         self.fuse_stem_tail = True
         self.fold_stem_input = True
+        self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tools/probe_layers.py)
         self._collect()
 
     # ------------------------------------------------------------------ structure
@@ -397,7 +398,7 @@ class ExpertGroupEngine:
         ops.reduce_partials(part, small, self.E, nparts, 128, width)
         return small, 128
 
-    def _bn_coeffs(self, layer, rpe, part=None, nparts=0, z=None):
+    def _bn_coeffs(self, layer, rpe, part=None, nparts=0, z=None, shiftc=None):
         """scale/shift/mean/invstd [E,C] of a BatchNorm: batch statistics from partial sums (train) or the
         running buffers (eval); updates the running statistics in train mode (momentum, unbiased var)."""
         E, C_ = self.E, layer.C
@@ -406,11 +407,12 @@ class ExpertGroupEngine:
             if part is None:
                 nparts = self._nparts(rpe)
                 part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
-                ops.colstats(rpe, z.t, E, C_, part, nparts)
+                shiftc = torch.empty(E, C_, dtype=F32, device=self.dev)
+                ops.colstats(rpe, z.t, E, C_, part, nparts, shiftc=shiftc)
             part, nparts = self._fold_parts(part, nparts, 2 * C_)
             ops.bn_finalize(part, nparts, rpe, self._tab("gamma", layer), self._tab("beta", layer),
                             self._tab("rm", layer), self._tab("rv", layer), layer.momentum, layer.eps, True, scale,
-                            shift, mean, invstd, E, C_)
+                            shift, mean, invstd, E, C_, shiftc)
             self._bn_touched.append(layer)
         else:
             ops.bn_finalize(scale, 0, rpe, self._tab("gamma", layer), self._tab("beta", layer), self._tab("rm", layer),
@@ -435,6 +437,8 @@ class ExpertGroupEngine:
 
     def _bn_bwd(self, z, layer, y, res, relu, scale, shift, mean, invstd, rpe, train):
         dy = y.grad
+        if self.debug_grads is not None and dy is not None:
+            self.debug_grads[layer.name] = dy.detach().clone()      # gradient w.r.t. this BN's (post-activation) output
         # without a residual the ReLU mask is a function of z alone: skip reading the saved output
         ysrc = y.t if (res is not None or not relu) else None
         if dy is None:
@@ -478,8 +482,9 @@ class ExpertGroupEngine:
         part = None
         if self.training:
             part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
-            ops.stem_tail_stats(z2.t, sc2, sh2, part, nparts, E, self.B)
-        sc1, sh1, mu1, is1 = self._bn_coeffs(self.bn1, rpe, part, nparts)
+            shc = torch.empty(E, C_, dtype=F32, device=self.dev)
+            ops.stem_tail_stats(z2.t, sc2, sh2, part, nparts, E, self.B, shiftc=shc)
+        sc1, sh1, mu1, is1 = self._bn_coeffs(self.bn1, rpe, part, nparts, shiftc=shc if self.training else None)
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         y = Var(self._new(n, ho, wo, C_))
         am = torch.empty(n, ho, wo, C_, dtype=torch.uint8, device=self.dev)
@@ -734,7 +739,9 @@ class ExpertGroupEngine:
         return probs, mean, std, speeds, state
 
     def _conv_stats(self, x, layer, tape=True):
-        if self.training and self.fuse_conv_stats:
+        # conv-epilogue statistics are plain sums (no sample to centre on before the conv has run): fine under
+        # bf16 storage noise, not for the exact-f32 parity mode, which takes the centred colstats pass instead
+        if self.training and self.fuse_conv_stats and self.dtype == torch.bfloat16:
             return self._conv(x, layer, bias=False, want_stats=True, tape=tape)
         return self._conv(x, layer, bias=False, tape=tape), None
 

@@ -103,9 +103,11 @@ def pack_bias(ptr_tab, dst, E, cout, coutp):
                                 stream_ptr()), "pmoe_pack_bias")
 
 
-def colstats(x2d_rows_per_expert, x, E, C_, part, nparts, ld=None, coff=0):
+def colstats(x2d_rows_per_expert, x, E, C_, part, nparts, ld=None, coff=0, shiftc=None):
+    """partial sums of (x - c), (x - c)^2 with c = row 0 of each expert (stored to shiftc [E,C]); c = 0 if None."""
     check(load().pmoe_colstats(ptr(x, "x"), x2d_rows_per_expert, E, C_, ld if ld is not None else x.shape[-1], coff,
-                               ptr(part, "part", torch.float32), nparts, dt(x), stream_ptr()), "pmoe_colstats")
+                               ptr(part, "part", torch.float32), nparts, ptr(shiftc, "shiftc", torch.float32), dt(x),
+                               stream_ptr()), "pmoe_colstats")
 
 
 def reduce_partials(part_in, part_out, E, nin, nout, width):
@@ -114,12 +116,12 @@ def reduce_partials(part_in, part_out, E, nin, nout, width):
 
 
 def bn_finalize(part, nparts, count, gamma_tab, beta_tab, rmean_tab, rvar_tab, momentum, eps, training, scale, shift,
-                mean, invstd, E, C_):
+                mean, invstd, E, C_, shiftc=None):
     f32 = torch.float32
     check(load().pmoe_bn_finalize(ptr(part, "part", f32), nparts, count, ptr(gamma_tab), ptr(beta_tab), ptr(rmean_tab),
                                   ptr(rvar_tab), momentum, eps, int(training), ptr(scale, "scale", f32),
                                   ptr(shift, "shift", f32), ptr(mean, "mean", f32), ptr(invstd, "invstd", f32), E, C_,
-                                  stream_ptr()), "pmoe_bn_finalize")
+                                  ptr(shiftc, "shiftc", f32), stream_ptr()), "pmoe_bn_finalize")
 
 
 def bn_apply(x, res, y, scale, shift, rpe, E, C_, relu):
@@ -145,9 +147,10 @@ def bn_bwd_apply(dy, y, x, mean, invstd, scale, shift, c1, c2, dx, gmask, rpe, E
                                    rpe, E, C_, int(relu), dt(dy), stream_ptr()), "pmoe_bn_bwd_apply")
 
 
-def stem_tail_stats(z2, sc2, sh2, part, nparts, E, ipe):
+def stem_tail_stats(z2, sc2, sh2, part, nparts, E, ipe, shiftc=None):
     n, h, w_, c = _nhwc(z2, "z2")
-    check(load().pmoe_stem_tail_stats(ptr(z2, "z2"), ptr(sc2), ptr(sh2), ptr(part, "part", torch.float32), nparts, E, ipe,
+    check(load().pmoe_stem_tail_stats(ptr(z2, "z2"), ptr(sc2), ptr(sh2), ptr(part, "part", torch.float32), nparts,
+                                      ptr(shiftc, "shiftc", torch.float32), E, ipe,
                                       h, w_, c, dt(z2), stream_ptr()), "pmoe_stem_tail_stats")
 
 

@@ -227,11 +227,12 @@ def test_batchnorm_fwd_bwd(shape, dtype):
     rpe = ipe * H * W
     nparts = 4
     part = torch.empty(E, nparts, 2, C_, device=DEV)
-    ops.colstats(rpe, xd, E, C_, part, nparts)
+    shiftc = torch.empty(E, C_, device=DEV)
+    ops.colstats(rpe, xd, E, C_, part, nparts, shiftc=shiftc)
     part2 = torch.empty(E, 2, 2, C_, device=DEV)
     ops.reduce_partials(part, part2, E, nparts, 2, 2 * C_)
     scale, shift, mean, invstd = (torch.empty(E, C_, device=DEV) for _ in range(4))
-    ops.bn_finalize(part2, 2, rpe, tabs[0], tabs[1], tabs[2], tabs[3], 0.1, 1e-5, True, scale, shift, mean, invstd, E, C_)
+    ops.bn_finalize(part2, 2, rpe, tabs[0], tabs[1], tabs[2], tabs[3], 0.1, 1e-5, True, scale, shift, mean, invstd, E, C_, shiftc)
     y = torch.empty_like(xd)
     ops.bn_apply(xd, resd, y, scale, shift, rpe, E, C_, True)
     close(from_nhwc(y, C_), yr.detach(), dtype, "bn fwd")
@@ -420,3 +421,24 @@ def test_gate_mixture_and_loss(E, alpha_relu, dtype):
     tol_dt = torch.float32 if dtype == torch.float32 else dtype
     close(dhead, hr.grad, tol_dt, "dhead")
     close(dspd, sr.grad, tol_dt, "dspd")
+
+
+def test_batchnorm_statistics_are_centred():
+    """|mean| >> std (a near-constant channel): one-pass E[x^2]-mean^2 in f32 loses the variance; the centred sums
+    (deviations from a sample of the channel) must reproduce the float64 statistics."""
+    g = torch.Generator().manual_seed(0)
+    E, ipe, C_, H, W = 2, 4, 64, 16, 16
+    x = torch.randn(E * ipe, C_, H, W, generator=g)
+    x[:, 0] = 100.0 + 1e-3 * x[:, 0]                 # mean^2 / var = 1e10
+    x[:, 1] = -7.0 + 1e-2 * x[:, 1]
+    xd = nhwc(x, C_, torch.float32)
+    rpe = ipe * H * W
+    part = torch.empty(E, 8, 2, C_, device=DEV)
+    shiftc = torch.empty(E, C_, device=DEV)
+    ops.colstats(rpe, xd, E, C_, part, 8, shiftc=shiftc)
+    scale, shift, mean, invstd = (torch.empty(E, C_, device=DEV) for _ in range(4))
+    ops.bn_finalize(part, 8, rpe, None, None, None, None, 0.1, 1e-5, True, scale, shift, mean, invstd, E, C_, shiftc)
+    xe = x.double().view(E, ipe, C_, H * W).permute(0, 2, 1, 3).reshape(E, C_, -1)
+    ref_is = 1.0 / torch.sqrt(xe.var(dim=2, unbiased=False) + 1e-5)
+    assert ((invstd.cpu().double() - ref_is).abs() / ref_is).max().item() < 1e-5
+    assert ((mean.cpu().double() - xe.mean(dim=2)).abs().max().item()) < 1e-5
