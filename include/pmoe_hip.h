@@ -116,15 +116,16 @@ int pmoe_colstats(const void* x, int64_t rows_per_expert, int32_t E, int32_t C, 
 /* deterministic tree step: part_in [E][nin][W] -> part_out [E][nout][W] (W = 2*C floats) */
 int pmoe_reduce_partials(const float* part_in, float* part_out, int32_t E, int32_t nin, int32_t nout, int32_t width,
                          void* stream);
-/* finalize: mean/var from partials; writes scale = gamma*invstd, shift = beta - mean*scale, mean, invstd
+/* finalize: mean/var from partials; writes scale = gamma*invstd, shift = beta, mean, invstd; every consumer
+ * evaluates the centred form (x - mean)*scale + shift (no cancellation when |mean| >> std)
  * ([E][C] f32 each); updates running_mean / running_var in place (momentum, unbiased var) through
  * per-expert pointer tables when they are non-null.  training=0: stats come from the running buffers. */
 int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const void* const* gamma_ptrs,
                      const void* const* beta_ptrs, void* const* rmean_ptrs, void* const* rvar_ptrs, float momentum,
                      float eps, int32_t training, float* scale, float* shift, float* mean, float* invstd, int32_t E,
                      int32_t C, const float* shiftc, void* stream);
-/* y = [relu]( x*scale + shift [+ res] ) */
-int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,
+/* y = [relu]( (x - mean)*scale + shift [+ res] ) */
+int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, const float* mean,
                   int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream);
 /* backward reduce: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat -> part [E][nparts][2][C].
  * y may be NULL when relu is set and the forward had no residual: the mask is then recomputed as
@@ -161,10 +162,11 @@ int pmoe_gap_bwd(const void* g, void* dx, int32_t N, int64_t HW, int32_t C, int3
  * The two intermediate activations and their gradients are re-derived from z2 in registers, never stored.
  * All per-channel arrays are [E][C] f32.  part: [E][nparts][2][C] partial sums (finish with pmoe_bn_finalize /
  * pmoe_bn_bwd_finalize). */
-int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, float* part, int32_t nparts, float* shiftc,
-                         int32_t E, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, const float* mu2, float* part,
+                         int32_t nparts, float* shiftc, int32_t E, int32_t ipe, int32_t H, int32_t W, int32_t C,
+                         int32_t dtype, void* stream);
 int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* sc2, const float* sh2, const float* sc1,
-                        const float* sh1, int32_t N, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                        const float* sh1, const float* mu2, const float* mu1, int32_t N, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype,
                         void* stream);
 /* phase 1: sums for the bn1 backward; phase 2: sums for the conv2-BN backward; phase 3: writes dz2.
  * consts: HOST array of 12 device pointers: sc2 sh2 sc1 sh1 mu1 is1 mu2 is2 c11 c21 c12 c22 (later ones may be

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
             unpack16<T>(ldg16(dy + off), gv);
             if (remask) {
 #pragma unroll
-                for (int i = 0; i < VE; ++i) gv[i] = (xv[i] * sc[i] + sh[i]) > 0.f ? gv[i] : 0.f;
+                for (int i = 0; i < VE; ++i) gv[i] = ((xv[i] - mu[i]) * sc[i] + sh[i]) > 0.f ? gv[i] : 0.f;
             } else if (relu) {
                 unpack16<T>(ldg16(y + off), yv);
 #pragma unroll
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
         const float is = rsqrtf(var + eps);
         const float g = gamma ? gamma[e][c] : 1.f, b = beta ? beta[e][c] : 0.f;
         scale[e * C + c] = g * is;
-        shift[e * C + c] = b - mean * g * is;
+        shift[e * C + c] = b;                    // beta: consumers evaluate (x - mean)*scale + beta (no cancellation)
         mean_o[e * C + c] = mean;
         invstd_o[e * C + c] = is;
     }
@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
 template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                       T* __restrict__ y, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift, long long rpe, int C, int relu) {
+                                                      const float* __restrict__ shift, const float* __restrict__ mean,
+                                                      long long rpe, int C, int relu) {
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE;                       // power of two <= 256*gridDim.x: a thread keeps ONE channel vector
     const int e = blockIdx.y;
@@ -204,15 +205,17 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
     const size_t ebase = (size_t)e * rpe * C;
     const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
     const int cv = (int)(i0 % CV);
-    float sc[VE], sh[VE];
+    float sc[VE], sh[VE], mu[VE];
 #pragma unroll
-    for (int k = 0; k < VE; ++k) { sc[k] = scale[e * C + cv * VE + k]; sh[k] = shift[e * C + cv * VE + k]; }
+    for (int k = 0; k < VE; ++k) {
+        sc[k] = scale[e * C + cv * VE + k]; sh[k] = shift[e * C + cv * VE + k]; mu[k] = mean[e * C + cv * VE + k];
+    }
     for (long long i = i0; i < nvec; i += (long long)gridDim.x * 256) {
         float xv[VE];
         const size_t off = ebase + (size_t)i * VE;
         unpack16<T>(ldg16(x + off), xv);
 #pragma unroll
-        for (int k = 0; k < VE; ++k) xv[k] = xv[k] * sc[k] + sh[k];
+        for (int k = 0; k < VE; ++k) xv[k] = (xv[k] - mu[k]) * sc[k] + sh[k];      // centred: no cancellation
         if (res) {
             float rv[VE];
             unpack16<T>(ldg16(res + off), rv);
@@ -242,16 +245,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     const size_t ebase = (size_t)e * rpe * C;
     const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
     const int cv = (int)(i0 % CV);               // constant per thread (grid stride is a multiple of CV)
-    // dx = scale*(g - c1 - xhat*c2) = g*A + x*Bx + K   with per-channel A, Bx, K
-    float A[VE], Bx[VE], K[VE], sc[VE], sh[VE];
+    // dx = scale*(g - c1 - xhat*c2) = g*A + (x - mean)*Bx + K   with per-channel A, Bx, K (centred x: stable)
+    float A[VE], Bx[VE], K[VE], sc[VE], sh[VE], mu[VE];
 #pragma unroll
     for (int k = 0; k < VE; ++k) {
         const int c = e * C + cv * VE + k;
         sc[k] = scale[c];
         sh[k] = shift ? shift[c] : 0.f;
+        mu[k] = mean[c];
         A[k] = sc[k];
         Bx[k] = -sc[k] * invstd[c] * c2[c];
-        K[k] = -sc[k] * (c1[c] - mean[c] * invstd[c] * c2[c]);
+        K[k] = -sc[k] * c1[c];
     }
     const bool remask = relu && !y;
     for (long long i = i0; i < nvec; i += (long long)gridDim.x * 256) {
@@ -261,7 +265,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
         unpack16<T>(ldg16(x + off), xv);
         if (remask) {
 #pragma unroll
-            for (int k = 0; k < VE; ++k) gv[k] = (xv[k] * sc[k] + sh[k]) > 0.f ? gv[k] : 0.f;
+            for (int k = 0; k < VE; ++k) gv[k] = ((xv[k] - mu[k]) * sc[k] + sh[k]) > 0.f ? gv[k] : 0.f;
         } else if (relu) {
             float yv[VE];
             unpack16<T>(ldg16(y + off), yv);
@@ -269,7 +273,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
             for (int k = 0; k < VE; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < VE; ++k) o[k] = gv[k] * A[k] + (xv[k] * Bx[k] + K[k]);
+        for (int k = 0; k < VE; ++k) o[k] = gv[k] * A[k] + ((xv[k] - mu[k]) * Bx[k] + K[k]);
         stg16(dx + off, pack16<T>(o));
         if (gm) stg16(gm + off, pack16<T>(gv));
     }
@@ -617,14 +621,14 @@ int pmoe_bn_bwd_finalize(const float* part, int32_t nparts, int64_t count, float
     return (int)hipGetLastError();
 }
 
-int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift,
+int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, const float* mean,
                   int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream) {
     DISPATCH_DT(dtype, {
         constexpr int VE = 16 / (int)sizeof(T);
         if (C % VE || !pow2(C / VE) || C / VE > 256) return PMOE_ERR_ARG;   // kernels keep one channel vector per thread
         const long long nvec = rows_per_expert * (C / VE);
         hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(nvec, 2048), E), dim3(256), 0, (hipStream_t)stream,
-                           (const T*)x, (const T*)res, (T*)y, scale, shift, (long long)rows_per_expert, C, relu);
+                           (const T*)x, (const T*)res, (T*)y, scale, shift, mean, (long long)rows_per_expert, C, relu);
         return (int)hipGetLastError();
     });
 }

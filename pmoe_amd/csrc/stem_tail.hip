@@ -39,27 +39,26 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
     int r0 = pi * rpp, r1 = r0 + rpp;
     if (r1 > rows_total) r1 = rows_total;
 
-    // per-channel constants, folded so that each phase keeps at most 8 of them live:
-    //   xhat1 = a2*is1 - m1                      da2 = g3*sc1 + a2*P + Q     (bn1 backward)
-    //   xhat2 = z *is2 - m2                      dz2 = g2*sc2 + z *R + S     (conv2-BN backward)
-    float sc2[VE], sh2[VE], sc1[VE], sh1[VE], is1[VE], m1[VE], P[VE], Q[VE], is2[VE], m2[VE], R[VE], S[VE];
+    // per-channel constants.  Everything is evaluated on CENTRED values ((z - mu2), (a2 - mu1)): no cancellation.
+    //   a2 = relu((z - mu2)*sc2 + b2)   a3 = (a2 - mu1)*sc1 + b1
+    //   xhat1 = (a2 - mu1)*is1          da2 = g3*sc1 + xhat1*P + Q     P = -sc1*c21, Q = -sc1*c11   (bn1 backward)
+    //   xhat2 = (z - mu2)*is2           dz2 = g2*sc2 + xhat2*R + S     R = -sc2*c22, S = -sc2*c12   (conv2-BN backward)
+    float sc2[VE], sh2[VE], mu2[VE], sc1[VE], sh1[VE], mu1[VE], is1[VE], P[VE], Q[VE], is2[VE], R[VE], S[VE];
 #pragma unroll
     for (int i = 0; i < VE; ++i) {
         const int c = e * C + cv * VE + i;
-        sc2[i] = k.sc2[c]; sh2[i] = k.sh2[c];
-        sc1[i] = MODE ? k.sc1[c] : 0.f; sh1[i] = MODE ? k.sh1[c] : 0.f;
-        is1[i] = MODE ? k.is1[c] : 0.f; m1[i] = MODE ? k.mu1[c] * k.is1[c] : 0.f;
-        P[i] = Q[i] = is2[i] = m2[i] = R[i] = S[i] = 0.f;
+        sc2[i] = k.sc2[c]; sh2[i] = k.sh2[c]; mu2[i] = k.mu2[c];
+        sc1[i] = MODE ? k.sc1[c] : 0.f; sh1[i] = MODE ? k.sh1[c] : 0.f; mu1[i] = MODE ? k.mu1[c] : 0.f;
+        is1[i] = MODE ? k.is1[c] : 0.f;
+        P[i] = Q[i] = is2[i] = R[i] = S[i] = 0.f;
         if (MODE >= 2) {
-            const float c11 = k.c11[c], c21 = k.c21[c];
-            P[i] = -is1[i] * sc1[i] * c21;
-            Q[i] = sc1[i] * (m1[i] * c21 - c11);
-            is2[i] = k.is2[c]; m2[i] = k.mu2[c] * k.is2[c];
+            P[i] = -sc1[i] * k.c21[c];
+            Q[i] = -sc1[i] * k.c11[c];
+            is2[i] = k.is2[c];
         }
         if (MODE == 3) {
-            const float c12 = k.c12[c], c22 = k.c22[c];
-            R[i] = -sc2[i] * is2[i] * c22;
-            S[i] = sc2[i] * (m2[i] * c22 - c12);
+            R[i] = -sc2[i] * k.c22[c];
+            S[i] = -sc2[i] * k.c12[c];
         }
     }
     float s1[VE], s2[VE];
@@ -73,7 +72,7 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
         float z0[VE];
         unpack16<T>(ldg16(z2 + (size_t)e * ipe * H * W * C + cv * VE), z0);
 #pragma unroll
-        for (int i = 0; i < VE; ++i) c0v[i] = fmaxf(z0[i] * sc2[i] + sh2[i], 0.f);
+        for (int i = 0; i < VE; ++i) c0v[i] = fmaxf((z0[i] - mu2[i]) * sc2[i] + sh2[i], 0.f);
         if (pi == 0 && rl == 0) {
 #pragma unroll
             for (int i = 0; i < VE; ++i) shiftc[e * C + cv * VE + i] = c0v[i];
@@ -95,7 +94,7 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
         float zv[VE], a2[VE];
         unpack16<T>(ldg16(zrow + voff), zv);
 #pragma unroll
-        for (int i = 0; i < VE; ++i) a2[i] = fmaxf(zv[i] * sc2[i] + sh2[i], 0.f);
+        for (int i = 0; i < VE; ++i) a2[i] = fmaxf((zv[i] - mu2[i]) * sc2[i] + sh2[i], 0.f);
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < VE; ++i) { const float d = a2[i] - c0v[i]; s1[i] += d; s2[i] += d * d; }
@@ -126,26 +125,26 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
             if (twoCols) gather(prB, oxB, tapB + tqB);
         }
 #pragma unroll
-        for (int i = 0; i < VE; ++i) g3[i] = (a2[i] * sc1[i] + sh1[i]) > 0.f ? g3[i] : 0.f;     // ReLU after bn1
+        for (int i = 0; i < VE; ++i) g3[i] = ((a2[i] - mu1[i]) * sc1[i] + sh1[i]) > 0.f ? g3[i] : 0.f;     // ReLU after bn1
         if (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < VE; ++i) { s1[i] += g3[i]; s2[i] += g3[i] * (a2[i] * is1[i] - m1[i]); }
+            for (int i = 0; i < VE; ++i) { s1[i] += g3[i]; s2[i] += g3[i] * ((a2[i] - mu1[i]) * is1[i]); }
             continue;
         }
         float g2[VE];
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
-            const float da2 = g3[i] * sc1[i] + (a2[i] * P[i] + Q[i]);                          // bn1 backward
+            const float da2 = g3[i] * sc1[i] + (((a2[i] - mu1[i]) * is1[i]) * P[i] + Q[i]);    // bn1 backward
             g2[i] = a2[i] > 0.f ? da2 : 0.f;                                                   // ReLU after BN(c2)
         }
         if (MODE == 2) {
 #pragma unroll
-            for (int i = 0; i < VE; ++i) { s1[i] += g2[i]; s2[i] += g2[i] * (zv[i] * is2[i] - m2[i]); }
+            for (int i = 0; i < VE; ++i) { s1[i] += g2[i]; s2[i] += g2[i] * ((zv[i] - mu2[i]) * is2[i]); }
             continue;
         }
         float o[VE];
 #pragma unroll
-        for (int i = 0; i < VE; ++i) o[i] = g2[i] * sc2[i] + (zv[i] * R[i] + S[i]);
+        for (int i = 0; i < VE; ++i) o[i] = g2[i] * sc2[i] + (((zv[i] - mu2[i]) * is2[i]) * R[i] + S[i]);
         stg16(dzrow + voff, pack16<T>(o));
       }
     }
@@ -170,7 +169,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) stem_tail_pool_kernel(const T* __restrict__ z2, T* __restrict__ y,
                                                             uint8_t* __restrict__ am, const float* __restrict__ sc2a,
                                                             const float* __restrict__ sh2a, const float* __restrict__ sc1a,
-                                                            const float* __restrict__ sh1a, int N, int ipe, int H, int W,
+                                                            const float* __restrict__ sh1a, const float* __restrict__ mu2a,
+                                                            const float* __restrict__ mu1a, int N, int ipe, int H, int W,
                                                             int C, int Ho, int Wo) {
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE;
@@ -182,11 +182,11 @@ __global__ void __launch_bounds__(256) stem_tail_pool_kernel(const T* __restrict
         const int oy = (int)(t % Ho);
         const int n = (int)(t / Ho);
         const int e = n / ipe;
-        float sc2[VE], sh2[VE], sc1[VE], sh1[VE];
+        float sc2[VE], sh2[VE], sc1[VE], sh1[VE], mu2[VE], mu1[VE];
 #pragma unroll
         for (int q = 0; q < VE; ++q) {
             const int c = e * C + cv * VE + q;
-            sc2[q] = sc2a[c]; sh2[q] = sh2a[c]; sc1[q] = sc1a[c]; sh1[q] = sh1a[c];
+            sc2[q] = sc2a[c]; sh2[q] = sh2a[c]; sc1[q] = sc1a[c]; sh1[q] = sh1a[c]; mu2[q] = mu2a[c]; mu1[q] = mu1a[c];
         }
         float best[VE];
         int bi[VE];
@@ -203,9 +203,9 @@ __global__ void __launch_bounds__(256) stem_tail_pool_kernel(const T* __restrict
                     unpack16<T>(ldg16(z2 + (((size_t)n * H + yy) * W + xx) * C + cv * VE), v);
 #pragma unroll
                     for (int q = 0; q < VE; ++q) {
-                        const float a2 = fmaxf(v[q] * sc2[q] + sh2[q], 0.f);
+                        const float a2 = fmaxf((v[q] - mu2[q]) * sc2[q] + sh2[q], 0.f);
                         // round like the unfused path stores a3 (T precision) so ties resolve identically
-                        const float a3 = to_f32(from_f32<T>(fmaxf(a2 * sc1[q] + sh1[q], 0.f)));
+                        const float a3 = to_f32(from_f32<T>(fmaxf((a2 - mu1[q]) * sc1[q] + sh1[q], 0.f)));
                         if (first || a3 > best[q]) { best[q] = a3; bi[q] = r * 3 + q3; }
                     }
                     first = false;
@@ -222,10 +222,11 @@ static inline bool pow2i(int v) { return v > 0 && !(v & (v - 1)); }
 
 extern "C" {
 
-int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, float* part, int32_t nparts, float* shiftc,
-                         int32_t E, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, const float* mu2, float* part,
+                         int32_t nparts, float* shiftc, int32_t E, int32_t ipe, int32_t H, int32_t W, int32_t C,
+                         int32_t dtype, void* stream) {
     TailConsts k{};
-    k.sc2 = sc2; k.sh2 = sh2;
+    k.sc2 = sc2; k.sh2 = sh2; k.mu2 = mu2;
     const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
     if (C % ve || !pow2i(C / ve) || C / ve > 256 || nparts < 1) return PMOE_ERR_ARG;
     if (dtype == PMOE_DT_BF16)
@@ -240,7 +241,7 @@ int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, flo
 }
 
 int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* sc2, const float* sh2, const float* sc1,
-                        const float* sh1, int32_t N, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                        const float* sh1, const float* mu2, const float* mu1, int32_t N, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype,
                         void* stream) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
@@ -249,10 +250,10 @@ int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* s
     if (g > 16384) g = 16384;
     if (dtype == PMOE_DT_BF16)
         hipLaunchKernelGGL((stem_tail_pool_kernel<bf16>), dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16*)z2,
-                           (bf16*)y, argmax, sc2, sh2, sc1, sh1, N, ipe, H, W, C, Ho, Wo);
+                           (bf16*)y, argmax, sc2, sh2, sc1, sh1, mu2, mu1, N, ipe, H, W, C, Ho, Wo);
     else if (dtype == PMOE_DT_F32)
         hipLaunchKernelGGL((stem_tail_pool_kernel<float>), dim3((int)g), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)z2, (float*)y, argmax, sc2, sh2, sc1, sh1, N, ipe, H, W, C, Ho, Wo);
+                           (const float*)z2, (float*)y, argmax, sc2, sh2, sc1, sh1, mu2, mu1, N, ipe, H, W, C, Ho, Wo);
     else
         return PMOE_ERR_ARG;
     return (int)hipGetLastError();

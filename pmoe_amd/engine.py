@@ -428,7 +428,7 @@ class ExpertGroupEngine:
             raise RuntimeError("fused stats width mismatch")
         scale, shift, mean, invstd = self._bn_coeffs(layer, rpe, stats, stats.shape[0] // E if stats is not None else 0, z)
         y = Var(torch.empty_like(z.t))
-        ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, rpe, E, C_, relu)
+        ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, mean, rpe, E, C_, relu)
         y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
         if self.taping and y.needs_grad:
             train = self.training
@@ -462,6 +462,9 @@ class ExpertGroupEngine:
         if dz is None:
             dz = torch.empty_like(z.t)
         ops.bn_bwd_apply(dy, ysrc, z.t, mean, invstd, scale, shift, c1, c2, dz, gm, rpe, E, C_, relu)
+        if self.debug_grads is not None:
+            self.debug_grads[layer.name + ":dz"] = dz.detach().clone()
+            self.debug_grads[layer.name + ":stats"] = (mean.clone(), invstd.clone(), c1.clone(), c2.clone())
         if z.needs_grad:
             if z.grad is not None:
                 raise RuntimeError("BN input consumed twice")
@@ -483,12 +486,12 @@ class ExpertGroupEngine:
         if self.training:
             part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
             shc = torch.empty(E, C_, dtype=F32, device=self.dev)
-            ops.stem_tail_stats(z2.t, sc2, sh2, part, nparts, E, self.B, shiftc=shc)
+            ops.stem_tail_stats(z2.t, sc2, sh2, mu2, part, nparts, E, self.B, shiftc=shc)
         sc1, sh1, mu1, is1 = self._bn_coeffs(self.bn1, rpe, part, nparts, shiftc=shc if self.training else None)
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         y = Var(self._new(n, ho, wo, C_))
         am = torch.empty(n, ho, wo, C_, dtype=torch.uint8, device=self.dev)
-        ops.stem_tail_pool(z2.t, y.t, am, sc2, sh2, sc1, sh1, self.B)
+        ops.stem_tail_pool(z2.t, y.t, am, sc2, sh2, sc1, sh1, mu2, mu1, self.B)
         y.needs_grad = z2.needs_grad or self.bn_c2.trainable or self.bn1.trainable
         if self.taping and y.needs_grad:
             train = self.training

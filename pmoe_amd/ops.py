@@ -124,8 +124,10 @@ def bn_finalize(part, nparts, count, gamma_tab, beta_tab, rmean_tab, rvar_tab, m
                                   ptr(shiftc, "shiftc", f32), stream_ptr()), "pmoe_bn_finalize")
 
 
-def bn_apply(x, res, y, scale, shift, rpe, E, C_, relu):
-    check(load().pmoe_bn_apply(ptr(x, "x"), ptr(res, "res", x.dtype), ptr(y, "y", x.dtype), ptr(scale), ptr(shift), rpe,
+def bn_apply(x, res, y, scale, shift, mean, rpe, E, C_, relu):
+    """y = [relu]((x - mean)*scale + shift [+ res]); shift is the BN beta (bn_finalize's output)."""
+    check(load().pmoe_bn_apply(ptr(x, "x"), ptr(res, "res", x.dtype), ptr(y, "y", x.dtype), ptr(scale), ptr(shift),
+                               ptr(mean, "mean", torch.float32), rpe,
                                E, C_, int(relu), dt(x), stream_ptr()), "pmoe_bn_apply")
 
 
@@ -147,17 +149,17 @@ def bn_bwd_apply(dy, y, x, mean, invstd, scale, shift, c1, c2, dx, gmask, rpe, E
                                    rpe, E, C_, int(relu), dt(dy), stream_ptr()), "pmoe_bn_bwd_apply")
 
 
-def stem_tail_stats(z2, sc2, sh2, part, nparts, E, ipe, shiftc=None):
+def stem_tail_stats(z2, sc2, sh2, mu2, part, nparts, E, ipe, shiftc=None):
     n, h, w_, c = _nhwc(z2, "z2")
-    check(load().pmoe_stem_tail_stats(ptr(z2, "z2"), ptr(sc2), ptr(sh2), ptr(part, "part", torch.float32), nparts,
+    check(load().pmoe_stem_tail_stats(ptr(z2, "z2"), ptr(sc2), ptr(sh2), ptr(mu2), ptr(part, "part", torch.float32), nparts,
                                       ptr(shiftc, "shiftc", torch.float32), E, ipe,
                                       h, w_, c, dt(z2), stream_ptr()), "pmoe_stem_tail_stats")
 
 
-def stem_tail_pool(z2, y, argmax, sc2, sh2, sc1, sh1, ipe):
+def stem_tail_pool(z2, y, argmax, sc2, sh2, sc1, sh1, mu2, mu1, ipe):
     n, h, w_, c = _nhwc(z2, "z2")
     check(load().pmoe_stem_tail_pool(ptr(z2, "z2"), ptr(y, "y", z2.dtype), ptr(argmax, "argmax", torch.uint8), ptr(sc2),
-                                     ptr(sh2), ptr(sc1), ptr(sh1), n, ipe, h, w_, c, dt(z2), stream_ptr()),
+                                     ptr(sh2), ptr(sc1), ptr(sh1), ptr(mu2), ptr(mu1), n, ipe, h, w_, c, dt(z2), stream_ptr()),
           "pmoe_stem_tail_pool")
 
 

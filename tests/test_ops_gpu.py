@@ -234,7 +234,7 @@ def test_batchnorm_fwd_bwd(shape, dtype):
     scale, shift, mean, invstd = (torch.empty(E, C_, device=DEV) for _ in range(4))
     ops.bn_finalize(part2, 2, rpe, tabs[0], tabs[1], tabs[2], tabs[3], 0.1, 1e-5, True, scale, shift, mean, invstd, E, C_, shiftc)
     y = torch.empty_like(xd)
-    ops.bn_apply(xd, resd, y, scale, shift, rpe, E, C_, True)
+    ops.bn_apply(xd, resd, y, scale, shift, mean, rpe, E, C_, True)
     close(from_nhwc(y, C_), yr.detach(), dtype, "bn fwd")
     for e in range(E):
         close(drm[e], rmr[e], torch.float32, "running_mean")
@@ -253,7 +253,7 @@ def test_batchnorm_fwd_bwd(shape, dtype):
         close(dbet[e], br[e].grad, dtype, "dbeta")
     # no-residual ReLU: the mask is recomputed from x (y = None) and must equal the y-based mask
     y2 = torch.empty_like(xd)
-    ops.bn_apply(xd, None, y2, scale, shift, rpe, E, C_, True)
+    ops.bn_apply(xd, None, y2, scale, shift, mean, rpe, E, C_, True)
     pa, pb = torch.empty_like(bpart), torch.empty_like(bpart)
     ops.bn_bwd_reduce(dyd, y2, xd, mean, invstd, scale, shift, rpe, E, C_, True, pa, nparts)
     ops.bn_bwd_reduce(dyd, None, xd, mean, invstd, scale, shift, rpe, E, C_, True, pb, nparts)
@@ -265,7 +265,7 @@ def test_batchnorm_fwd_bwd(shape, dtype):
     close(dxb, dxa.float().cpu(), dtype, "mask-from-x apply")
     # eval mode: scale/shift from running buffers
     ops.bn_finalize(part2, 2, rpe, tabs[0], tabs[1], tabs[2], tabs[3], 0.1, 1e-5, False, scale, shift, mean, invstd, E, C_)
-    ops.bn_apply(xd, None, y, scale, shift, rpe, E, C_, False)
+    ops.bn_apply(xd, None, y, scale, shift, mean, rpe, E, C_, False)
     yev = torch.cat([F.batch_norm(x[e * ipe:(e + 1) * ipe], rmr[e], rvr[e], gam[e], bet[e], False, 0.1, 1e-5)
                      for e in range(E)])
     close(from_nhwc(y, C_), yev, dtype, "bn eval")
