@@ -210,18 +210,23 @@ int pmoe_pad_rows(const float* src, void* dst, int32_t B, int32_t K, int32_t Kp,
 /* ---- gate softmax + Gaussian-mixture head (moe.py:98-100,150-153) and moe_loss (trainer/loss.py:121-132)
  * head [E*B][head_ld] T: cols 0..1 mean, 2..3 raw std, 4 raw alpha; spd [E*B][spd_ld] T col 0.
  * probs [B][E], mean/std [B][E][2], speeds [B][E][1] f32.  alpha_relu: BaseExpert (1) vs BaseExpertAlt (0).
- * One 64-lane wave handles 64/G samples, G = pow2 >= E lanes per sample, xor-shuffle reductions over E. */
+ * One 64-lane wave handles 64/G samples, G = pow2 >= E lanes per sample, xor-shuffle reductions over E.
+ * shared = 1 is MixtureOfExpertsShared (moe.py:180-233): head [B][head_ld] with cols 4e..4e+3 = mean/raw std of
+ * expert e and col 4E+e = its alpha (softmax without ReLU); spd [B][spd_ld] col 0; speeds is then [B][1]. */
 int pmoe_gate_mixture_fwd(const void* head, int32_t head_ld, const void* spd, int32_t spd_ld, float* probs,
                           float* mean, float* std_, float* speeds, int32_t B, int32_t E, int32_t alpha_relu,
-                          int32_t dtype, void* stream);
+                          int32_t shared, int32_t dtype, void* stream);
 int pmoe_gate_mixture_bwd(const void* head, int32_t head_ld, const float* probs, const float* dprobs,
                           const float* dmean, const float* dstd, const float* dspeeds, void* dhead, void* dspd,
-                          int32_t spd_ld, int32_t B, int32_t E, int32_t alpha_relu, int32_t dtype, void* stream);
+                          int32_t spd_ld, int32_t B, int32_t E, int32_t alpha_relu, int32_t shared, int32_t dtype,
+                          void* stream);
 /* loss = c0 * mean_b(-logsumexp_e(log p + sum_d logN)) + c1 * mean((speeds-target)^2)/E; also the
- * gradients of loss wrt probs/mean/std/speeds (scaled by gscale) for the backward pass. */
+ * gradients of loss wrt probs/mean/std/speeds for the backward pass.  shared_speed = 1: speeds is [B][1]
+ * (MixtureOfExpertsShared) and the speed term is plain mse(speeds, target) (loss.py:129-130). */
 int pmoe_moe_loss(const float* probs, const float* mean, const float* std_, const float* speeds,
                   const float* actions, const float* target_speed, float c0, float c1, float* loss, float* loglik,
-                  float* dprobs, float* dmean, float* dstd, float* dspeeds, int32_t B, int32_t E, void* stream);
+                  float* dprobs, float* dmean, float* dstd, float* dspeeds, int32_t B, int32_t E, int32_t shared_speed,
+                  void* stream);
 
 #ifdef __cplusplus
 }

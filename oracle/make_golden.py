@@ -62,6 +62,11 @@ GRAD_SLICES = [
     "moe.0.action_pred.weight",
     "moe.0.action_pred.bias",
     "moe.1.alpha.weight",
+    # moe_shared (no "moe.N." prefix)
+    "backbone.conv1.layer1.eca1.conv.weight", "backbone.conv1.layer1.conv1.0.weight", "backbone.conv1.layer2.conv2.0.weight",
+    "backbone.bn1.bias", "backbone.layer2.0.downsample.0.weight", "backbone.layer4.1.conv2.weight",
+    "backbone.layer4.1.bn2.weight", "speed_encoder.0.weight", "command_encoder.0.weight", "speed_pred.0.weight",
+    "action_features.0.weight", "action_pred.weight", "action_pred.bias", "alpha.weight", "alpha.bias",
 ]
 
 
@@ -93,11 +98,12 @@ def run_case(ref_moe, ref_loss, name, model_type, n_experts, batch, size, train=
                 sl[k] = named[k].grad.flatten()[:64].clone()
         out["grad_slices"] = sl
         sd = model.state_dict()
+        pre = "backbone." if model_type == "moe_shared" else "moe.0.backbone."
         out["bn_after_1"] = {k: sd[k].clone() for k in sd
-                             if k.startswith("moe.0.backbone") and
+                             if k.startswith(pre) and
                              (k.endswith("running_mean") or k.endswith("running_var")
                               or k.endswith("num_batches_tracked"))
-                             and ("conv1.layer1" in k or "bn1" in k.split(".")[3:4] or "layer4.1.bn2" in k
+                             and ("conv1.layer1" in k or k[len(pre):].startswith("bn1.") or "layer4.1.bn2" in k
                                   or "layer2.0.downsample" in k)}
     else:
         with torch.no_grad():
@@ -110,7 +116,7 @@ def run_case(ref_moe, ref_loss, name, model_type, n_experts, batch, size, train=
     # per-expert 1536-d feature slice (first 8 of each 512 block) via the reference's own modules
     with torch.no_grad():
         model.eval()
-        e0 = model.moe[0]
+        e0 = model if model_type == "moe_shared" else model.moe[0]
         x = inp["images"].view(batch, -1, size, size)
         out["feat_eval_e0"] = e0.backbone(x)[:, :16].clone()
         model.train(train)
@@ -168,6 +174,9 @@ def micro_cases(ref_basics, ref_loss):
     dist = D.MixtureSameFamily(D.Categorical(probs), D.Independent(D.Normal(mean, std), 1))
     out["loss_case"] = dict(probs=probs, mean=mean, std=std, speeds=speeds, act=act, tgt=tgt,
                             loss=ref_loss.moe_loss(dist, speeds, act, tgt.clone(), [0.7, 0.3]).detach())
+    sp2 = torch.randn(5, 1, generator=g)
+    out["loss_case_shared"] = dict(probs=probs, mean=mean, std=std, speeds=sp2, act=act, tgt=tgt,
+                                   loss=ref_loss.moe_loss(dist, sp2, act, tgt.clone(), [0.7, 0.3]).detach())
     return out
 
 
@@ -182,11 +191,19 @@ def main():
         ("g4_moealt_e4_b2_64", "moe_alt", 4, 2, 64, True, 0),
         ("g5_moe_e3_b3_96", "moe", 3, 3, 96, True, 0),
     ]
+    only = set(sys.argv[1:])          # optional: regenerate just the named cases
+    cases.append(("g6_moeshared_k4_b3_96", "moe_shared", 4, 3, 96, True, 3))
+    cases.append(("g7_moeshared_k6_b1_224_eval", "moe_shared", 6, 1, 224, False, 0))
+    cases.append(("g8_moeshared_k3_b2_128", "moe_shared", 3, 2, 128, True, 0))
+    cases.append(("g9_moeshared_k5_b4_64", "moe_shared", 5, 4, 64, True, 0))
     for name, t, e, b, s, train, steps in cases:
+        if only and name not in only:
+            continue
         res = run_case(ref_moe, ref_loss, name, t, e, b, s, train, steps)
         torch.save(res, gold / f"{name}.pt")
         print(name, "loss" in res and float(res["loss"]), res["probs"][0].tolist())
-    torch.save(micro_cases(ref_basics, ref_loss), gold / "micro.pt")
+    if not only or "micro" in only:
+        torch.save(micro_cases(ref_basics, ref_loss), gold / "micro.pt")
     print("wrote", sorted(p.name for p in gold.glob("*.pt")))
 
 

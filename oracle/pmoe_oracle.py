@@ -202,10 +202,49 @@ class MixtureOfExperts(nn.Module):
         return self.forward(images, speed, command)[0].sample()
 
 
+class MixtureOfExpertsShared(nn.Module):
+    """``model/moe.py:180-265``: one trunk, ``n_experts`` Gaussian components from the last layer."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.speed_encoder = make_mlp(**params.speed_encoder)
+        self.command_encoder = make_mlp(**params.command_encoder)
+        assert params.backbone.type == "rgb"
+        self.backbone = get_backbone(**{**params.backbone.rgb, "n_frames": params.backbone.n_frames})
+        self.speed_pred = make_mlp(**params.speed_prediction)
+        self.action_features = make_mlp(**params.action_head)
+        width = params.action_head.dims[-1]
+        self.n_experts = params.n_experts
+        self.alpha = nn.Linear(width, params.n_experts)
+        self.action_pred = nn.Linear(width, 4 * params.n_experts)
+
+    def mixture_params(self, images, speed, command):
+        s = self.speed_encoder(speed)
+        c = self.command_encoder(command)
+        x = images.reshape(images.shape[0], -1, images.shape[-2], images.shape[-1])
+        feats = torch.cat([self.backbone(x), s, c], dim=-1)
+        pred_speed = self.speed_pred(feats)                                  # [B,1]
+        af = self.action_features(feats)
+        mean, std = self.action_pred(af).view(images.shape[0], self.n_experts, -1).split(2, dim=-1)
+        std = F.elu(std) + 1
+        probs = F.softmax(self.alpha(af), dim=1)                             # no ReLU here (moe.py:226)
+        return probs, mean, std, pred_speed
+
+    def forward(self, images, speed, command):
+        probs, mean, std, pred_speed = self.mixture_params(images, speed, command)
+        dist = D.MixtureSameFamily(D.Categorical(probs), D.Independent(D.Normal(mean, std), 1))
+        return dist, pred_speed
+
+    def sample(self, images, speed, command):
+        return self.forward(images, speed, command)[0].sample()
+
+
 def get_model(cfg):
     """``model/moe.py:25-47`` (MoE families only in the oracle so far)."""
     if cfg.type in ("moe", "moe_alt"):
         return MixtureOfExperts(cfg)
+    if cfg.type == "moe_shared":
+        return MixtureOfExpertsShared(cfg)
     raise ValueError(f"{cfg.type} is UNKNOWN or not restated by the oracle yet")
 
 

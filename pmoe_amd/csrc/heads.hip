@@ -56,21 +56,37 @@ __global__ void __launch_bounds__(256) pack_bias_kernel(const float* const* __re
 // ------------------------------------------------------------------------------------------------
 // Gate softmax + mixture parameters.  G = pow2 >= E lanes per sample; a wave covers 64/G samples and
 // reduces over the expert axis with xor-shuffles (no LDS, no atomics).
+// Two head layouts:
+//   shared = 0 (MixtureOfExperts, moe.py:131-158): head [E*B][ld], row (e*B + b) = {mean0, mean1, rawstd0, rawstd1, alpha};
+//                                                   spd [E*B][ld] col 0 -> speeds [B][E][1]
+//   shared = 1 (MixtureOfExpertsShared, moe.py:180-233): head [B][ld], cols 4e..4e+3 = expert e's mean/rawstd,
+//                                                   col 4E+e = its alpha;  spd [B][ld] col 0 -> speeds [B][1]
+struct GateIdx {
+    int shared, B, E, ld;
+    __device__ __forceinline__ size_t comp(int b, int e, int i) const {          // mean / rawstd element i of (b, e)
+        return shared ? (size_t)b * ld + 4 * e + i : ((size_t)e * B + b) * ld + i;
+    }
+    __device__ __forceinline__ size_t alpha(int b, int e) const {
+        return shared ? (size_t)b * ld + 4 * E + e : ((size_t)e * B + b) * ld + 4;
+    }
+};
+
 template <typename T>
 __global__ void __launch_bounds__(256) gate_fwd_kernel(const T* __restrict__ head, int head_ld, const T* __restrict__ spd,
                                                       int spd_ld, float* __restrict__ probs, float* __restrict__ mean,
                                                       float* __restrict__ sd, float* __restrict__ speeds, int B, int E,
-                                                      int G, int alpha_relu) {
+                                                      int G, int alpha_relu, int shared) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int b = gid / G, e = gid % G;
     const bool live = b < B && e < E;
+    const GateIdx ix{shared, B, E, head_ld};
     float hv[5] = {0, 0, 0, 0, 0};
     float sp = 0.f;
     if (live) {
-        const T* row = head + ((size_t)e * B + b) * head_ld;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) hv[i] = to_f32(row[i]);
-        sp = to_f32(spd[((size_t)e * B + b) * spd_ld]);
+        for (int i = 0; i < 4; ++i) hv[i] = to_f32(head[ix.comp(b, e, i)]);
+        hv[4] = to_f32(head[ix.alpha(b, e)]);
+        sp = to_f32(spd[(shared ? (size_t)b : (size_t)e * B + b) * spd_ld]);
     }
     float a = alpha_relu ? fmaxf(hv[4], 0.f) : hv[4];
     if (!live) a = -INFINITY;
@@ -86,7 +102,8 @@ __global__ void __launch_bounds__(256) gate_fwd_kernel(const T* __restrict__ hea
         mean[o * 2 + 1] = hv[1];
         sd[o * 2 + 0] = (hv[2] > 0.f ? hv[2] : expm1f(hv[2])) + 1.f;
         sd[o * 2 + 1] = (hv[3] > 0.f ? hv[3] : expm1f(hv[3])) + 1.f;
-        speeds[o] = sp;
+        if (!shared) speeds[o] = sp;
+        else if (e == 0) speeds[b] = sp;
     }
 }
 
@@ -96,10 +113,11 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const T* __restrict__ hea
                                                       const float* __restrict__ dmean, const float* __restrict__ dstd,
                                                       const float* __restrict__ dspeeds, T* __restrict__ dhead,
                                                       T* __restrict__ dspd, int spd_ld, int B, int E, int G,
-                                                      int alpha_relu) {
+                                                      int alpha_relu, int shared) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int b = gid / G, e = gid % G;
     const bool live = b < B && e < E;
+    const GateIdx ix{shared, B, E, head_ld};
     float p = 0.f, dp = 0.f;
     if (live) {
         p = probs[(size_t)b * E + e];
@@ -109,20 +127,28 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const T* __restrict__ hea
     for (int off = 1; off < G; off <<= 1) dot += __shfl_xor(dot, off);
     if (live) {
         const size_t o = (size_t)b * E + e;
-        const T* row = head + ((size_t)e * B + b) * head_ld;
-        const float r2 = to_f32(row[2]), r3 = to_f32(row[3]), r4 = to_f32(row[4]);
+        const float r2 = to_f32(head[ix.comp(b, e, 2)]), r3 = to_f32(head[ix.comp(b, e, 3)]);
+        const float r4 = to_f32(head[ix.alpha(b, e)]);
         float da = p * (dp - dot);
         if (alpha_relu && !(r4 > 0.f)) da = 0.f;
-        T* drow = dhead + ((size_t)e * B + b) * head_ld;
-        drow[0] = from_f32<T>(dmean ? dmean[o * 2 + 0] : 0.f);
-        drow[1] = from_f32<T>(dmean ? dmean[o * 2 + 1] : 0.f);
-        drow[2] = from_f32<T>(dstd ? dstd[o * 2 + 0] * (r2 > 0.f ? 1.f : expf(r2)) : 0.f);
-        drow[3] = from_f32<T>(dstd ? dstd[o * 2 + 1] * (r3 > 0.f ? 1.f : expf(r3)) : 0.f);
-        drow[4] = from_f32<T>(da);
-        for (int i = 5; i < head_ld; ++i) drow[i] = from_f32<T>(0.f);
-        T* srow = dspd + ((size_t)e * B + b) * spd_ld;
-        srow[0] = from_f32<T>(dspeeds ? dspeeds[o] : 0.f);
-        for (int i = 1; i < spd_ld; ++i) srow[i] = from_f32<T>(0.f);
+        dhead[ix.comp(b, e, 0)] = from_f32<T>(dmean ? dmean[o * 2 + 0] : 0.f);
+        dhead[ix.comp(b, e, 1)] = from_f32<T>(dmean ? dmean[o * 2 + 1] : 0.f);
+        dhead[ix.comp(b, e, 2)] = from_f32<T>(dstd ? dstd[o * 2 + 0] * (r2 > 0.f ? 1.f : expf(r2)) : 0.f);
+        dhead[ix.comp(b, e, 3)] = from_f32<T>(dstd ? dstd[o * 2 + 1] * (r3 > 0.f ? 1.f : expf(r3)) : 0.f);
+        dhead[ix.alpha(b, e)] = from_f32<T>(da);
+        if (!shared) {
+            T* drow = dhead + ((size_t)e * B + b) * head_ld;
+            for (int i = 5; i < head_ld; ++i) drow[i] = from_f32<T>(0.f);
+            T* srow = dspd + ((size_t)e * B + b) * spd_ld;
+            srow[0] = from_f32<T>(dspeeds ? dspeeds[o] : 0.f);
+            for (int i = 1; i < spd_ld; ++i) srow[i] = from_f32<T>(0.f);
+        } else if (e == 0) {
+            T* drow = dhead + (size_t)b * head_ld;
+            for (int i = 5 * E; i < head_ld; ++i) drow[i] = from_f32<T>(0.f);
+            T* srow = dspd + (size_t)b * spd_ld;
+            srow[0] = from_f32<T>(dspeeds ? dspeeds[b] : 0.f);
+            for (int i = 1; i < spd_ld; ++i) srow[i] = from_f32<T>(0.f);
+        }
     }
 }
 
@@ -138,7 +164,8 @@ __global__ void __launch_bounds__(256) moe_loss_kernel(const float* __restrict__
                                                       float c0, float c1, float* __restrict__ loss,
                                                       float* __restrict__ loglik, float* __restrict__ dprobs,
                                                       float* __restrict__ dmean, float* __restrict__ dstd,
-                                                      float* __restrict__ dspeeds, int B, int E, int G) {
+                                                      float* __restrict__ dspeeds, int B, int E, int G,
+                                                      int shared_speed) {
     const float EPS = 1.1920929e-07f, HALF_LOG_2PI = 0.9189385332046727f;
     const int e = threadIdx.x % G;
     float nll_acc = 0.f, mse_acc = 0.f;
@@ -157,7 +184,7 @@ __global__ void __launch_bounds__(256) moe_loss_kernel(const float* __restrict__
                 const float z = (a[d] - mu[d]) / sg[d];
                 comp += -0.5f * z * z - logf(sg[d]) - HALF_LOG_2PI;
             }
-            spv = speeds[o];
+            spv = shared_speed ? speeds[b] : speeds[o];
             tg = tgt[b];
         }
         float ps = p;
@@ -190,8 +217,13 @@ __global__ void __launch_bounds__(256) moe_loss_kernel(const float* __restrict__
                 dstd[o * 2 + d] = gs * r * (diff * diff * iv / sg[d] - 1.f / sg[d]);
             }
             const float ds = spv - tg;
-            mse_acc += ds * ds;
-            dspeeds[o] = c1 * 2.f * ds / ((float)B * (float)E * (float)E);
+            if (!shared_speed) {                      // mse over [B,E,1] then / E  (loss.py:126-128)
+                mse_acc += ds * ds;
+                dspeeds[o] = c1 * 2.f * ds / ((float)B * (float)E * (float)E);
+            } else if (e == 0) {                      // mse over [B,1]             (loss.py:129-130)
+                mse_acc += ds * ds;
+                dspeeds[b] = c1 * 2.f * ds / (float)B;
+            }
         }
     }
     __shared__ float r1[256], r2[256];
@@ -202,7 +234,8 @@ __global__ void __launch_bounds__(256) moe_loss_kernel(const float* __restrict__
         if (threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = c0 * r1[0] / (float)B + c1 * r2[0] / ((float)B * (float)E * (float)E);
+    if (threadIdx.x == 0)
+        loss[0] = c0 * r1[0] / (float)B + c1 * r2[0] / (shared_speed ? (float)B : (float)B * (float)E * (float)E);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,17 +339,17 @@ int pmoe_eca_stem_fold(const float* G, const float* gate, const void* const* w_p
 }
 
 int pmoe_gate_mixture_fwd(const void* head, int32_t head_ld, const void* spd, int32_t spd_ld, float* probs, float* mean,
-                          float* std_, float* speeds, int32_t B, int32_t E, int32_t alpha_relu, int32_t dtype,
-                          void* stream) {
-    if (E < 1 || E > 64 || head_ld < 5) return PMOE_ERR_ARG;
+                          float* std_, float* speeds, int32_t B, int32_t E, int32_t alpha_relu, int32_t shared,
+                          int32_t dtype, void* stream) {
+    if (E < 1 || E > 64 || head_ld < (shared ? 5 * E : 5)) return PMOE_ERR_ARG;
     const int G = pow2ceil(E);
     const int blocks = (B * G + 255) / 256;
     if (dtype == PMOE_DT_BF16)
         hipLaunchKernelGGL((gate_fwd_kernel<bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)head,
-                           head_ld, (const bf16*)spd, spd_ld, probs, mean, std_, speeds, B, E, G, alpha_relu);
+                           head_ld, (const bf16*)spd, spd_ld, probs, mean, std_, speeds, B, E, G, alpha_relu, shared);
     else if (dtype == PMOE_DT_F32)
         hipLaunchKernelGGL((gate_fwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)head,
-                           head_ld, (const float*)spd, spd_ld, probs, mean, std_, speeds, B, E, G, alpha_relu);
+                           head_ld, (const float*)spd, spd_ld, probs, mean, std_, speeds, B, E, G, alpha_relu, shared);
     else
         return PMOE_ERR_ARG;
     return (int)hipGetLastError();
@@ -324,18 +357,18 @@ int pmoe_gate_mixture_fwd(const void* head, int32_t head_ld, const void* spd, in
 
 int pmoe_gate_mixture_bwd(const void* head, int32_t head_ld, const float* probs, const float* dprobs, const float* dmean,
                           const float* dstd, const float* dspeeds, void* dhead, void* dspd, int32_t spd_ld, int32_t B,
-                          int32_t E, int32_t alpha_relu, int32_t dtype, void* stream) {
-    if (E < 1 || E > 64 || head_ld < 5) return PMOE_ERR_ARG;
+                          int32_t E, int32_t alpha_relu, int32_t shared, int32_t dtype, void* stream) {
+    if (E < 1 || E > 64 || head_ld < (shared ? 5 * E : 5)) return PMOE_ERR_ARG;
     const int G = pow2ceil(E);
     const int blocks = (B * G + 255) / 256;
     if (dtype == PMOE_DT_BF16)
         hipLaunchKernelGGL((gate_bwd_kernel<bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)head,
                            head_ld, probs, dprobs, dmean, dstd, dspeeds, (bf16*)dhead, (bf16*)dspd, spd_ld, B, E, G,
-                           alpha_relu);
+                           alpha_relu, shared);
     else if (dtype == PMOE_DT_F32)
         hipLaunchKernelGGL((gate_bwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)head,
                            head_ld, probs, dprobs, dmean, dstd, dspeeds, (float*)dhead, (float*)dspd, spd_ld, B, E, G,
-                           alpha_relu);
+                           alpha_relu, shared);
     else
         return PMOE_ERR_ARG;
     return (int)hipGetLastError();
@@ -343,10 +376,10 @@ int pmoe_gate_mixture_bwd(const void* head, int32_t head_ld, const float* probs,
 
 int pmoe_moe_loss(const float* probs, const float* mean, const float* std_, const float* speeds, const float* actions,
                   const float* target_speed, float c0, float c1, float* loss, float* loglik, float* dprobs, float* dmean,
-                  float* dstd, float* dspeeds, int32_t B, int32_t E, void* stream) {
+                  float* dstd, float* dspeeds, int32_t B, int32_t E, int32_t shared_speed, void* stream) {
     if (E < 1 || E > 64) return PMOE_ERR_ARG;
     hipLaunchKernelGGL(moe_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, probs, mean, std_, speeds, actions,
-                       target_speed, c0, c1, loss, loglik, dprobs, dmean, dstd, dspeeds, B, E, pow2ceil(E));
+                       target_speed, c0, c1, loss, loglik, dprobs, dmean, dstd, dspeeds, B, E, pow2ceil(E), shared_speed);
     return (int)hipGetLastError();
 }
 

@@ -114,10 +114,16 @@ class GroupedECA:
 class ExpertGroupEngine:
     """Executes ``experts`` (list of pmoe_amd.model.moe.BaseExpert[Alt]) as one grouped network."""
 
-    def __init__(self, experts, alt=False):
+    def __init__(self, experts, alt=False, shared_k=0):
+        """``shared_k`` > 0: MixtureOfExpertsShared (moe.py:180-233) -- ``experts`` is the one module that owns the
+        shared trunk (group of one) and its head emits ``shared_k`` mixture components per sample."""
         self.experts = list(experts)
         self.E = len(self.experts)
         self.alt = alt
+        self.shared = shared_k > 0
+        self.K = shared_k if self.shared else self.E       # mixture components per sample
+        if self.shared and (self.E != 1 or alt or 5 * self.K > 64):
+            raise ValueError("shared-trunk mixture: one trunk, plain alpha head, n_experts <= 12")
         self.dp_group = None          # torch.distributed process group for gradient all-reduce (None = WORLD)
         self.dp_enabled = False       # set by pmoe_amd.parallel-aware callers (bench.py, enable_data_parallel)
         self.dp_buckets = 6
@@ -216,9 +222,10 @@ class ExpertGroupEngine:
     def _fused_head(self, ex):
         class _Cat:  # weights of action_pred (rows 0..3) and alpha (row 4) as one 5-row layer
             pass
-        layer = GroupedConv(self, "head", None, None, ex[0].action_pred.in_features, 5, 1, 1, 0)
-        layer.parts = [([e.action_pred.weight for e in ex], [e.action_pred.bias for e in ex], 4),
-                       ([e.alpha.weight for e in ex], [e.alpha.bias for e in ex], 1)]
+        k = self.K if self.shared else 1      # shared trunk: rows 0..4K-1 action_pred, rows 4K..5K-1 alpha
+        layer = GroupedConv(self, "head", None, None, ex[0].action_pred.in_features, 5 * k, 1, 1, 0)
+        layer.parts = [([e.action_pred.weight for e in ex], [e.action_pred.bias for e in ex], 4 * k),
+                       ([e.alpha.weight for e in ex], [e.alpha.bias for e in ex], k)]
         layer.weights = layer.parts[0][0] + layer.parts[1][0]
         layer.biases = layer.parts[0][1] + layer.parts[1][1]
         for (ws, bs, _), nm in zip(layer.parts, ("action_pred", "alpha")):
@@ -278,7 +285,7 @@ class ExpertGroupEngine:
             h = self.head
             E = self.E
             # two packs into row windows of the fused 5-row head: rows 0..3 action_pred, row 4 alpha
-            for (ws, bs, rows), nm, r0 in ((h.parts[0], "action_pred", 0), (h.parts[1], "alpha", 4)):
+            for (ws, bs, rows), nm, r0 in ((h.parts[0], "action_pred", 0), (h.parts[1], "alpha", h.parts[0][2])):
                 self._pack_head_part(h, nm, rows, r0)
         self._packed_version = ver
 
@@ -286,9 +293,9 @@ class ExpertGroupEngine:
         # The pack kernel writes a whole [coutp] panel, so pack each part into scratch and copy its rows.
         E = self.E
         scratch_f = torch.empty(E, 64, 1, h.cinp, dtype=h.w_fwd.dtype, device=h.w_fwd.device)
-        scratch_d = torch.empty(E, h.dg_rows, 1, 16, dtype=h.w_fwd.dtype, device=h.w_fwd.device)
+        scratch_d = torch.empty(E, h.dg_rows, 1, h.dg_red, dtype=h.w_fwd.dtype, device=h.w_fwd.device)
         ops.pack_conv_weights(self._tab("w_part", (h, nm)), scratch_f, scratch_d, E, rows, h.cin, 1, 64, h.cinp,
-                              h.dg_rows, 16, h.w_fwd.dtype)
+                              h.dg_rows, h.dg_red, h.w_fwd.dtype)
         if r0 == 0:
             h.w_fwd.zero_()
             h.w_dg.zero_()
@@ -355,8 +362,9 @@ class ExpertGroupEngine:
             else:
                 full = torch.empty(E, layer.cout, layer.cin, dtype=F32, device=self.dev)
                 ops.unpack_conv_wgrad(ws, full, E, layer.cout, layer.cin, 1, cow, cpw)
-                self._grad_slot("w_part", (layer, "action_pred")).view(E, 4, layer.cin).copy_(full[:, 0:4])
-                self._grad_slot("w_part", (layer, "alpha")).view(E, 1, layer.cin).copy_(full[:, 4:5])
+                ra = parts[0][2]
+                self._grad_slot("w_part", (layer, "action_pred")).view(E, ra, layer.cin).copy_(full[:, 0:ra])
+                self._grad_slot("w_part", (layer, "alpha")).view(E, layer.cout - ra, layer.cin).copy_(full[:, ra:])
             if layer.biases is not None:
                 rpe = self.B * dy.shape[1] * dy.shape[2]
                 part = torch.empty(E, 1, 2, layer.cout_st, dtype=F32, device=self.dev)
@@ -365,8 +373,9 @@ class ExpertGroupEngine:
                 if parts is None:
                     self._grad_slot("b", layer).view(E, layer.cout).copy_(sums)
                 else:
-                    self._grad_slot("b_part", (layer, "action_pred")).view(E, 4).copy_(sums[:, 0:4])
-                    self._grad_slot("b_part", (layer, "alpha")).view(E, 1).copy_(sums[:, 4:5])
+                    ra = parts[0][2]
+                    self._grad_slot("b_part", (layer, "action_pred")).view(E, ra).copy_(sums[:, 0:ra])
+                    self._grad_slot("b_part", (layer, "alpha")).view(E, layer.cout - ra).copy_(sums[:, ra:])
         if x.needs_grad:
             prev = x.grad
             res, res_mode = None, hip.RES_NONE
@@ -651,7 +660,8 @@ class ExpertGroupEngine:
 
     # ------------------------------------------------------------------ network
     def forward(self, images, speed, command, training, taping, dtype, base_seed=0):
-        """Returns probs [B,E], mean [B,E,2], std [B,E,2], speeds [B,E,1] (f32) and the tape."""
+        """Returns probs [B,K], mean [B,K,2], std [B,K,2], speeds [B,K,1] ([B,1] for the shared trunk), f32, and
+        the tape."""
         if images.dim() != 5:
             raise ValueError(f"images: expected [B,T,C,H,W], got {tuple(images.shape)}")
         if not images.is_cuda:
@@ -729,12 +739,14 @@ class ExpertGroupEngine:
             head5 = self._merge_alt_head(head, al)
         else:
             head5 = self._conv(af, self.head)                    # cols 0..3 action_pred, col 4 alpha
-        probs = torch.empty(Bsz, E, dtype=F32, device=self.dev)
-        mean = torch.empty(Bsz, E, 2, dtype=F32, device=self.dev)
-        std = torch.empty(Bsz, E, 2, dtype=F32, device=self.dev)
-        speeds = torch.empty(Bsz, E, 1, dtype=F32, device=self.dev)
-        ops.gate_mixture_fwd(head5.t.view(self.N, 16), sp.t.view(self.N, 16), probs, mean, std, speeds, Bsz, E,
-                             not self.alt)
+        K = self.K
+        probs = torch.empty(Bsz, K, dtype=F32, device=self.dev)
+        mean = torch.empty(Bsz, K, 2, dtype=F32, device=self.dev)
+        std = torch.empty(Bsz, K, 2, dtype=F32, device=self.dev)
+        speeds = torch.empty((Bsz, 1) if self.shared else (Bsz, K, 1), dtype=F32, device=self.dev)
+        # BaseExpert applies ReLU to alpha (moe.py:97); BaseExpertAlt (moe.py:126) and the shared head (moe.py:226) do not
+        ops.gate_mixture_fwd(head5.t.view(self.N, -1), sp.t.view(self.N, 16), probs, mean, std, speeds, Bsz, K,
+                             not self.alt and not self.shared, self.shared)
         if training and self._bn_touched:
             torch._foreach_add_([m.num_batches_tracked for l in self._bn_touched for m in l.mods], 1)
         state = dict(tape=self.tape, tail=(head5, sp, probs), B=self.B, N=self.N, dev=self.dev, dtype=self.dtype)
@@ -805,8 +817,9 @@ class ExpertGroupEngine:
 
         def c(t):
             return t.contiguous().float() if t is not None else None
-        ops.gate_mixture_bwd(head5.t.view(self.N, 16), probs, c(dprobs), c(dmean), c(dstd), c(dspeeds),
-                             dhead.view(self.N, 16), dspd.view(self.N, 16), self.B, self.E, not self.alt)
+        ops.gate_mixture_bwd(head5.t.view(self.N, -1), probs, c(dprobs), c(dmean), c(dstd), c(dspeeds),
+                             dhead.view(self.N, -1), dspd.view(self.N, 16), self.B, self.K,
+                             not self.alt and not self.shared, self.shared)
         head5.set_grad(dhead)
         sp.set_grad(dspd)
         for fn in reversed(tape):

@@ -87,9 +87,9 @@ SIGNATURES = {
     "pmoe_eca_bwd_apply": [_P, _P, _P, _P, _I, _L, _I, _I, _P],
     "pmoe_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pad_rows": [_P, _P, _I, _I, _I, _I, _P],
-    "pmoe_gate_mixture_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "pmoe_gate_mixture_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "pmoe_moe_loss": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "pmoe_gate_mixture_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pmoe_gate_mixture_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_moe_loss": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
 }
 _RESTYPES = {"pmoe_error_string": C.c_char_p}
 

@@ -30,10 +30,12 @@ def get_model(cfg):
     assert model_type is not None, "Network type can not be None"
     if model_type in ["moe", "moe_alt"]:
         return MixtureOfExperts(cfg)
-    elif model_type in ["moe_shared", "punet", "punet_inter", "pmoe", "pmoe+pretrained"]:
+    elif model_type == "moe_shared":
+        return MixtureOfExpertsShared(cfg)
+    elif model_type in ["punet", "punet_inter", "pmoe", "pmoe+pretrained"]:
         raise NotImplementedError(
             f"model type {model_type!r} is a reference option that is not on the MI355X path yet "
-            "(SURVEY.md section 8: second tier / config 4); 'moe' and 'moe_alt' are")
+            "(SURVEY.md section 8: second tier / config 4); 'moe', 'moe_alt' and 'moe_shared' are")
     else:
         raise ValueError(
             f"{model_type} is UNKNOWN, model type should be one of 'moe', 'punet', "
@@ -66,9 +68,12 @@ class _Grouped(nn.Module):
     def _engine(self):
         eng = self.__dict__.get("_eng")
         if eng is None:
-            eng = ExpertGroupEngine(self._expert_list(), alt=self._alt())
+            eng = ExpertGroupEngine(self._expert_list(), alt=self._alt(), shared_k=self._shared_k())
             self.__dict__["_eng"] = eng          # not a submodule / not in state_dict / rebuilt after deepcopy
         return eng
+
+    def _shared_k(self):
+        return 0
 
     def __deepcopy__(self, memo):
         # AveragedModel(model) deep-copies (train_2.py:120): drop the engine (raw device buffers), copy the rest
@@ -167,6 +172,47 @@ class MixtureOfExperts(_Grouped):
         probs, mean, std, speeds = self._run(images, speed, command)
         dist = MixtureDistribution(probs, mean, std)
         return dist, speeds
+
+    def sample(self, images, speed, command):
+        probs, mean, std, _ = self._run(images, speed, command)
+        return MixtureDistribution(probs, mean, std).sample()
+
+
+class MixtureOfExpertsShared(_Grouped):
+    """``moe.py:180-265``: ONE trunk (encoders, backbone, speed / action-feature heads) whose last layer emits
+    ``n_experts`` Gaussian components: ``action_pred = Linear(512, 4*n_experts)`` viewed as [B, n_experts, 4] and
+    ``alpha = Linear(512, n_experts)`` (plain softmax).  ``forward`` returns (distribution, pred_speed [B,1])."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.speed_encoder = B.make_mlp(**params.speed_encoder)
+        self.command_encoder = B.make_mlp(**params.command_encoder)
+        if params.backbone.type != "rgb":
+            raise NotImplementedError("backbone.type 'segmentation' (get_unet) is not on the HIP path (SURVEY.md section 2 #3)")
+        self.backbone = B.get_backbone(**{**params.backbone.rgb, "n_frames": params.backbone.n_frames})
+        self.speed_pred = B.make_mlp(**params.speed_prediction)
+        self.action_features = B.make_mlp(**params.action_head)
+        width = params.action_head.dims[-1]
+        self.n_experts = params.n_experts
+        self.alpha = B.Linear(width, params.n_experts)
+        self.action_pred = B.Linear(width, 4 * params.n_experts)
+
+    def _expert_list(self):
+        return [self]
+
+    def _alt(self):
+        return False
+
+    def _shared_k(self):
+        return self.n_experts
+
+    def mixture_params(self, images, speed, command):
+        """probs [B,K], mean [B,K,2], std [B,K,2], pred_speed [B,1]."""
+        return self._run(images, speed, command)
+
+    def forward(self, images, speed, command):
+        probs, mean, std, speeds = self._run(images, speed, command)
+        return MixtureDistribution(probs, mean, std), speeds
 
     def sample(self, images, speed, command):
         probs, mean, std, _ = self._run(images, speed, command)

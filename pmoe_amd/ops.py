@@ -246,30 +246,31 @@ def pad_rows(src, dst):
                                stream_ptr()), "pmoe_pad_rows")
 
 
-def gate_mixture_fwd(head, spd, probs, mean, std, speeds, B, E, alpha_relu):
+def gate_mixture_fwd(head, spd, probs, mean, std, speeds, B, E, alpha_relu, shared=False):
     f32 = torch.float32
     check(load().pmoe_gate_mixture_fwd(ptr(head, "head"), head.shape[-1], ptr(spd, "spd", head.dtype), spd.shape[-1],
                                        ptr(probs, "probs", f32), ptr(mean, "mean", f32), ptr(std, "std", f32),
-                                       ptr(speeds, "speeds", f32), B, E, int(alpha_relu), dt(head), stream_ptr()),
-          "pmoe_gate_mixture_fwd")
+                                       ptr(speeds, "speeds", f32), B, E, int(alpha_relu), int(shared), dt(head),
+                                       stream_ptr()), "pmoe_gate_mixture_fwd")
 
 
-def gate_mixture_bwd(head, probs, dprobs, dmean, dstd, dspeeds, dhead, dspd, B, E, alpha_relu):
+def gate_mixture_bwd(head, probs, dprobs, dmean, dstd, dspeeds, dhead, dspd, B, E, alpha_relu, shared=False):
     f32 = torch.float32
     check(load().pmoe_gate_mixture_bwd(ptr(head, "head"), head.shape[-1], ptr(probs, "probs", f32),
                                        ptr(dprobs, "dprobs", f32), ptr(dmean, "dmean", f32), ptr(dstd, "dstd", f32),
                                        ptr(dspeeds, "dspeeds", f32), ptr(dhead, "dhead", head.dtype),
-                                       ptr(dspd, "dspd", head.dtype), dspd.shape[-1], B, E, int(alpha_relu), dt(head),
-                                       stream_ptr()), "pmoe_gate_mixture_bwd")
+                                       ptr(dspd, "dspd", head.dtype), dspd.shape[-1], B, E, int(alpha_relu), int(shared),
+                                       dt(head), stream_ptr()), "pmoe_gate_mixture_bwd")
 
 
-def moe_loss(probs, mean, std, speeds, actions, target, c0, c1, loss, loglik, dprobs, dmean, dstd, dspeeds, B, E):
+def moe_loss(probs, mean, std, speeds, actions, target, c0, c1, loss, loglik, dprobs, dmean, dstd, dspeeds, B, E,
+             shared_speed=False):
     f32 = torch.float32
     check(load().pmoe_moe_loss(ptr(probs, "probs", f32), ptr(mean, "mean", f32), ptr(std, "std", f32),
                                ptr(speeds, "speeds", f32), ptr(actions, "actions", f32), ptr(target, "target", f32),
                                float(c0), float(c1), ptr(loss, "loss", f32), ptr(loglik, "loglik", f32),
                                ptr(dprobs, "dprobs", f32), ptr(dmean, "dmean", f32), ptr(dstd, "dstd", f32),
-                               ptr(dspeeds, "dspeeds", f32), B, E, stream_ptr()), "pmoe_moe_loss")
+                               ptr(dspeeds, "dspeeds", f32), B, E, int(shared_speed), stream_ptr()), "pmoe_moe_loss")
 
 
 # ---------------------------------------------------------------------------------------------------

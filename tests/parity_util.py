@@ -126,17 +126,24 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
             # flip-free: at least half of the experts must meet the tight conditioning-aware bound on EVERY
             # tensor; the others may only deviate by what a flip explains (<= 0.15, median <= 3e-2).
             import re, statistics
+
+            def expert_of(k):       # "moe.<e>.…" for MixtureOfExperts; the shared-trunk model is one group
+                mt = re.match(r"moe\.(\d+)\.", k)
+                return int(mt.group(1)) if mt else 0
             per_expert = {}
             for k, p in named.items():
                 if g64[k].norm().item() < 1e-6 * total_ref:
                     continue
                 e_ref = rel_l2(onamed[k].grad, g64[k])
                 e_hip = rel_l2(p.grad, g64[k])
-                ex = int(re.match(r"moe\.(\d+)\.", k).group(1))
+                ex = expert_of(k)
                 per_expert.setdefault(ex, []).append((e_hip, e_hip <= max(5e-3, 4 * e_ref), k))
             tight = [ex for ex, rows in per_expert.items() if all(ok for _, ok, _ in rows)]
             report["experts_tight"] = f"{len(tight)}/{len(per_expert)}"
-            assert 2 * len(tight) >= len(per_expert), {ex: max(r for r, _, _ in rows) for ex, rows in per_expert.items()}
+            if len(per_expert) > 1:
+                assert 2 * len(tight) >= len(per_expert), {ex: max(r for r, _, _ in rows) for ex, rows in per_expert.items()}
+            # (a shared-trunk model is ONE group: the caller applies the same "at least half are flip-free" rule
+            #  over several golden cases instead -- tests/test_model_gpu.py::test_train_parity_f32_shared_trunk)
             for ex, rows in per_expert.items():
                 if ex in tight:
                     continue
@@ -146,13 +153,13 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
             assert abs(total - total_ref) <= 1e-2 * total_ref
             # golden slices produced by the reference itself (not just the oracle)
             for k, sl in g["grad_slices"].items():
-                if int(re.match(r"moe\.(\d+)\.", k).group(1)) not in tight:
+                if expert_of(k) not in tight:
                     continue
                 scale = max(sl.abs().max().item(), g["grad_norms"][k] / max(1, named[k].numel()) ** 0.5)
                 e = (named[k].grad.flatten()[:64].cpu() - sl).abs().max().item() / (scale + 1e-20)
                 assert e <= 4 * GRAD_TOL[dtype], f"{name} grad slice {k}: {e:.3e}"
             for k, nrm in g["grad_norms"].items():
-                if nrm > 1e-6 * total_ref and named[k].numel() >= 16 and int(re.match(r"moe\.(\d+)\.", k).group(1)) in tight:
+                if nrm > 1e-6 * total_ref and named[k].numel() >= 16 and expert_of(k) in tight:
                     assert abs(named[k].grad.norm().item() - nrm) <= GRAD_TOL[dtype] * nrm, k
         else:
             cosines.sort()

@@ -15,7 +15,9 @@ def _g(golden_dir, name):
 
 
 @pytest.mark.parametrize("name,typ,E", [("g1_moe_e4_b2_128", "moe", 4), ("g3_moe_e8_b2_128", "moe", 8),
-                                        ("g4_moealt_e4_b2_64", "moe_alt", 4), ("g5_moe_e3_b3_96", "moe", 3)])
+                                        ("g4_moealt_e4_b2_64", "moe_alt", 4), ("g5_moe_e3_b3_96", "moe", 3),
+                                        ("g6_moeshared_k4_b3_96", "moe_shared", 4),
+                                        ("g7_moeshared_k6_b1_224_eval", "moe_shared", 6)])
 def test_state_dict_keys_match_reference(golden_dir, name, typ, E):
     g = _g(golden_dir, name)
     m = get_model(stage2_model_cfg(typ, E, dropout=0.0))
@@ -58,6 +60,10 @@ def test_deepcopy_and_engine_grouping():
     assert m2._engine() is not eng
     swa = torch.optim.swa_utils.AveragedModel(m)
     assert isinstance(swa.module, MixtureOfExperts)
+    sh = get_model(stage2_model_cfg("moe_shared", 5, dropout=0.0))
+    eng = sh._engine()
+    assert (eng.E, eng.K, eng.shared) == (1, 5, True) and eng.head.cout == 25
+    assert len({id(p) for p in eng.flat_params}) == len(list(sh.parameters()))
 
 
 def test_cpu_inputs_fail_loudly():

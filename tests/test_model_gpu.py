@@ -15,19 +15,29 @@ def test_train_parity_f32(name):
     run_parity_case(name, torch.float32, check_grads=True)
 
 
-@pytest.mark.parametrize("name", ["g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g1_moe_e4_b2_128"])
+def test_train_parity_f32_shared_trunk():
+    """MixtureOfExpertsShared (moe.py:180-233).  One trunk = one group, so the flip-aware gradient rule of
+    parity_util (at least half of the independent groups tight on EVERY tensor, the rest within what one ReLU-mask
+    flip explains) is applied across three golden cases of different K / batch / image size."""
+    reports = [run_parity_case(n, torch.float32, check_grads=True)
+               for n in ("g6_moeshared_k4_b3_96", "g8_moeshared_k3_b2_128", "g9_moeshared_k5_b4_64")]
+    tight = sum(r["experts_tight"] == "1/1" for r in reports)
+    assert 2 * tight >= len(reports), [r["grad_worst"] for r in reports]
+
+
+@pytest.mark.parametrize("name", ["g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g1_moe_e4_b2_128", "g6_moeshared_k4_b3_96"])
 def test_train_parity_bf16(name):
     run_parity_case(name, torch.bfloat16, check_grads=True)
 
 
+@pytest.mark.parametrize("name", ["g2_moe_e4_b1_224_eval", "g7_moeshared_k6_b1_224_eval"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_eval_parity_agent_shape(dtype):
+def test_eval_parity_agent_shape(dtype, name):
     """image_agent.py:158-159: B=1, 224x224, eval mode, model.sample()."""
     # eval mode uses the (synthetic, mismatched) running statistics: activations are not re-normalised and the
     # outputs reach |8|; the bf16-emulating CPU oracle is off by 1.9e-2*(1+|ref|) here, the HIP path by 3.5e-2
-    run_parity_case("g2_moe_e4_b1_224_eval", dtype, check_grads=False,
-                    fwd_tol_mult=2.0 if dtype == torch.bfloat16 else 1.0)
-    g = torch.load(GOLDEN / "g2_moe_e4_b1_224_eval.pt", weights_only=False)
+    run_parity_case(name, dtype, check_grads=False, fwd_tol_mult=2.0 if dtype == torch.bfloat16 else 1.0)
+    g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
     _, _, model, inp = build_pair(g, dtype)
     with torch.no_grad():
         a = model.sample(inp["images"].cuda(), inp["speed"].cuda(), inp["command"].cuda())

@@ -423,6 +423,64 @@ def test_gate_mixture_and_loss(E, alpha_relu, dtype):
     close(dspd, sr.grad, tol_dt, "dspd")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K", [3, 4, 6, 12])
+def test_gate_mixture_and_loss_shared_trunk(K, dtype):
+    """MixtureOfExpertsShared head layout (moe.py:217-226) and the [B,1] speed branch of moe_loss (loss.py:129-130)."""
+    import torch.distributions as D
+    g = torch.Generator().manual_seed(K)
+    B = 29
+    ld = (5 * K + 15) // 16 * 16
+    head = rnd((B, ld), g, dtype)
+    spd = rnd((B, 16), g, dtype)
+    act = torch.rand(B, 2, generator=g) * 2 - 1
+    tgt = torch.rand(B, 1, generator=g)
+    hr = head.clone().requires_grad_(True)
+    sr = spd.clone().requires_grad_(True)
+    mean_r, raw = hr[:, :4 * K].view(B, K, 4).split(2, dim=-1)
+    std_r = F.elu(raw) + 1
+    probs_r = torch.softmax(hr[:, 4 * K:5 * K], dim=1)
+    speeds_r = sr[:, 0:1]
+    dist = D.MixtureSameFamily(D.Categorical(probs_r), D.Independent(D.Normal(mean_r, std_r), 1))
+    loss_r = 0.7 * -dist.log_prob(act).mean() + 0.3 * F.mse_loss(speeds_r, tgt)
+    loss_r.backward()
+
+    hd, sd_ = head.to(dtype).to(DEV), spd.to(dtype).to(DEV)
+    probs = torch.empty(B, K, device=DEV)
+    mean = torch.empty(B, K, 2, device=DEV)
+    std = torch.empty(B, K, 2, device=DEV)
+    speeds = torch.empty(B, 1, device=DEV)
+    ops.gate_mixture_fwd(hd, sd_, probs, mean, std, speeds, B, K, False, True)
+    close(probs, probs_r.detach(), torch.float32, "probs")
+    close(mean, mean_r.detach(), torch.float32, "mean")
+    close(std, std_r.detach(), torch.float32, "std")
+    close(speeds, speeds_r.detach(), torch.float32, "speeds")
+    loss = torch.empty(1, device=DEV)
+    ll = torch.empty(B, device=DEV)
+    dp, dm, ds, dsp = torch.empty_like(probs), torch.empty_like(mean), torch.empty_like(std), torch.empty_like(speeds)
+    ops.moe_loss(probs, mean, std, speeds, act.to(DEV), tgt.to(DEV), 0.7, 0.3, loss, ll, dp, dm, ds, dsp, B, K, True)
+    assert abs(loss.item() - loss_r.item()) <= 2e-5 * max(1, abs(loss_r.item()))
+    dhead = torch.full_like(hd, 7.0)
+    dspd = torch.full_like(sd_, 7.0)
+    ops.gate_mixture_bwd(hd, probs, dp, dm, ds, dsp, dhead, dspd, B, K, False, True)
+    tol_dt = torch.float32 if dtype == torch.float32 else dtype
+    close(dhead, hr.grad, tol_dt, "dhead")      # padding columns 5K.. must come back as zeros
+    close(dspd, sr.grad, tol_dt, "dspd")
+
+
+def test_loss_golden_vectors():
+    """moe_loss kernel against the values the imported reference produced (tests/golden/micro.pt)."""
+    from pathlib import Path
+    from pmoe_amd.loss import moe_loss
+    import torch.distributions as D
+    g = torch.load(Path(__file__).resolve().parent / "golden" / "micro.pt", weights_only=False)
+    for key in ("loss_case", "loss_case_shared"):
+        lc = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in g[key].items()}
+        dist = D.MixtureSameFamily(D.Categorical(lc["probs"]), D.Independent(D.Normal(lc["mean"], lc["std"]), 1))
+        got = moe_loss(dist, lc["speeds"], lc["act"], lc["tgt"], [0.7, 0.3])
+        assert abs(got.item() - lc["loss"].item()) <= 1e-5 * max(1.0, abs(lc["loss"].item())), key
+
+
 def test_batchnorm_statistics_are_centred():
     """|mean| >> std (a near-constant channel): one-pass E[x^2]-mean^2 in f32 loses the variance; the centred sums
     (deviations from a sample of the channel) must reproduce the float64 statistics."""

@@ -22,10 +22,11 @@ def _run(g):
     return cfg, model, inp
 
 
-CASES = ["g1_moe_e4_b2_128", "g3_moe_e8_b2_128", "g4_moealt_e4_b2_64", "g5_moe_e3_b3_96"]
+CASES = ["g1_moe_e4_b2_128", "g3_moe_e8_b2_128", "g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g6_moeshared_k4_b3_96",
+         "g8_moeshared_k3_b2_128", "g9_moeshared_k5_b4_64"]
 
 
-@pytest.mark.parametrize("name", CASES + ["g2_moe_e4_b1_224_eval"])
+@pytest.mark.parametrize("name", CASES + ["g2_moe_e4_b1_224_eval", "g7_moeshared_k6_b1_224_eval"])
 def test_state_dict_layout_matches_reference(golden_dir, name):
     g = _load(golden_dir, name)
     cfg, model, _ = _run(g)
@@ -61,8 +62,9 @@ def test_train_forward_backward_matches_reference(golden_dir, name):
     torch.testing.assert_close(ll.detach(), g["log_prob"], rtol=1e-5, atol=1e-5)
 
 
-def test_eval_forward_matches_reference(golden_dir):
-    g = _load(golden_dir, "g2_moe_e4_b1_224_eval")
+@pytest.mark.parametrize("name", ["g2_moe_e4_b1_224_eval", "g7_moeshared_k6_b1_224_eval"])
+def test_eval_forward_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
     cfg, model, inp = _run(g)
     with torch.no_grad():
         dist, speeds = model(inp["images"], inp["speed"], inp["command"])
@@ -72,9 +74,10 @@ def test_eval_forward_matches_reference(golden_dir):
     assert model.sample(inp["images"], inp["speed"], inp["command"]).shape == (1, 2)
 
 
-def test_h1_step_trajectory_matches_reference(golden_dir):
-    """Caller row H1 (train_2.py:149-165): 5 steps of fwd / moe_loss / backward / clip 1.0 / Adam(amsgrad)."""
-    g = _load(golden_dir, "g1_moe_e4_b2_128")
+@pytest.mark.parametrize("name", ["g1_moe_e4_b2_128", "g6_moeshared_k4_b3_96"])
+def test_h1_step_trajectory_matches_reference(golden_dir, name):
+    """Caller row H1 (train_2.py:149-165): steps of fwd / moe_loss / backward / clip 1.0 / Adam(amsgrad)."""
+    g = _load(golden_dir, name)
     cfg, model, inp = _run(g)
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
     for ref in g["h1"]["traj"]:
@@ -106,3 +109,5 @@ def test_micro_cases(golden_dir):
     import torch.distributions as D
     dist = D.MixtureSameFamily(D.Categorical(lc["probs"]), D.Independent(D.Normal(lc["mean"], lc["std"]), 1))
     torch.testing.assert_close(O.moe_loss(dist, lc["speeds"], lc["act"], lc["tgt"], [0.7, 0.3]), lc["loss"])
+    ls = g["loss_case_shared"]       # [B,1] speed prediction of MixtureOfExpertsShared (loss.py:129-130)
+    torch.testing.assert_close(O.moe_loss(dist, ls["speeds"], ls["act"], ls["tgt"], [0.7, 0.3]), ls["loss"])
