@@ -228,6 +228,38 @@ int pmoe_moe_loss(const float* probs, const float* mean, const float* std_, cons
                   float* dprobs, float* dmean, float* dstd, float* dspeeds, int32_t B, int32_t E, int32_t shared_speed,
                   void* stream);
 
+/* ---- PU-Net / PMoE model types.  The U-Nets are frozen on this path
+ * (moe.py:280): forward only.
+ * MaxPool2d(2,2) (blocks/unet.py:29): x is a channel window [x_coff, x_coff+C) of rows x_ld wide, y dense [N][H/2][W/2][C]. */
+int pmoe_maxpool2s2_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t x_ld,
+                        int32_t x_coff, int32_t dtype, void* stream);
+/* ConvTranspose2d(k=2, s=2) (unet.py:34-44) = one 1x1 GEMM with 4*C output rows (row (dy*2+dx)*C + c, packed by the
+ * host from the [Cin][Cout][2][2] parameter) followed by this interleave into dst[n][2y+dy][2x+dx][dst_coff + c]
+ * (a channel window of the skip-concatenation buffer, unet.py:71-84). */
+int pmoe_pixel_shuffle2(const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t src_ld,
+                        int32_t dst_ld, int32_t dst_coff, int32_t dtype, void* stream);
+/* torch.cat along channels (punet.py:104,113; unet.py:72) / view(B,-1,H,W) (moe.py:311-313): rows x C elements from one
+ * channel window to another; 16-byte accesses when every offset allows it, element-wise otherwise (23-class masks). */
+int pmoe_copy_window(const void* src, int32_t src_ld, int32_t src_coff, void* dst, int32_t dst_ld, int32_t dst_coff,
+                     int64_t rows, int32_t C, int32_t dtype, void* stream);
+/* PUNetExpert tail (moe.py:317): actions [B][2] = tanh(head[:, 0:2]), speeds [B] = spd[:, 0]; and its backward
+ * (all head_ld / spd_ld columns of dhead / dspd are written, padding with zeros). */
+int pmoe_action_head_fwd(const void* head, int32_t head_ld, const void* spd, int32_t spd_ld, float* actions,
+                         float* speeds, int32_t B, int32_t dtype, void* stream);
+int pmoe_action_head_bwd(const float* actions, const float* dactions, const float* dspeeds, void* dhead,
+                         int32_t head_ld, void* dspd, int32_t spd_ld, int32_t B, int32_t dtype, void* stream);
+/* punet_loss (loss.py:135-142): c0 * L1(actions, gt) + c1 * MSE(speeds, gt), with gradients; speeds = NULL gives
+ * pmoe_loss (loss.py:145-151) = c0 * L1 (pass c0 = 1). */
+int pmoe_action_loss(const float* actions, const float* speeds, const float* actions_gt, const float* speed_gt,
+                     float c0, float c1, float* loss, float* dactions, float* dspeeds, int32_t B, void* stream);
+/* PMoE blend (moe.py:353-356): out[b][j] = tanh(w_j . [moe[b][j], punet[b][j]] + bias_j), j = 0 lat_weights,
+ * j = 1 long_weights (each nn.Linear(2,1)); backward gives the six parameter gradients and d punet (NULL to skip). */
+int pmoe_blend_fwd(const float* moe_actions, const float* punet_actions, const float* lat_w, const float* lat_b,
+                   const float* long_w, const float* long_b, float* out, int32_t B, void* stream);
+int pmoe_blend_bwd(const float* moe_actions, const float* punet_actions, const float* lat_w, const float* long_w,
+                   const float* out, const float* dout, float* dlat_w, float* dlat_b, float* dlong_w, float* dlong_b,
+                   float* dpunet, int32_t B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,114 @@ def run_case(ref_moe, ref_loss, name, model_type, n_experts, batch, size, train=
     return out
 
 
+PUNET_SLICES = [
+    "backbone.conv1.layer1.eca1.conv.weight", "backbone.conv1.layer1.conv1.0.weight", "backbone.conv1.layer1.conv1.1.weight",
+    "backbone.conv1.layer2.conv2.0.weight", "backbone.bn1.bias", "backbone.layer2.0.downsample.0.weight",
+    "backbone.layer4.1.conv2.weight", "speed_encoder.0.weight", "command_encoder.0.weight", "speed_pred.0.weight",
+    "action_pred.0.0.weight", "action_pred.0.2.weight", "action_pred.1.weight", "action_pred.1.bias",
+]
+PUNET_BN = ["punet.unet.dwn_1.1", "punet.unet.dwn_5.4", "punet.unet.up_forw_1.1", "punet.unet.up_forw_4.4",
+            "punet.entry_block.layer1.conv1.1", "punet.entry_block.layer2.conv2.1", "punet.pred_unet.dwn_1.1",
+            "punet.pred_unet.up_forw_4.4", "backbone.conv1.layer1.conv1.1", "backbone.bn1", "backbone.layer4.1.bn2"]
+
+
+def _checkpoints(tmp, cfg_kw, model_type, n_experts):
+    """The reference constructors read three checkpoint files (punet.py:40, moe.py:278, moe.py:335); their CONTENT
+    is irrelevant here (every weight is overwritten by fill_state_dict afterwards), only the key sets must fit."""
+    from model.blocks.unet import UNet as RefUNet
+    from model.punet import PredictiveUnet as RefPU
+    tmp.mkdir(parents=True, exist_ok=True)
+    unet_path, punet_path, moe_dir = tmp / "unet.pth", tmp / "punet.pth", tmp / "moe.pth"
+    torch.save({"unet": RefUNet().state_dict()}, unet_path)
+    cfg = stage2_cfg(model_type, n_experts, dropout=0.0, unet_path=str(unet_path), **cfg_kw)
+    pu = RefPU(**{**cfg.punet, "inter_repr": model_type == "punet_inter"})
+    torch.save({"model": pu.state_dict()}, punet_path)
+    return unet_path, punet_path, moe_dir
+
+
+def run_punet_case(ref_moe, ref_loss, name, model_type, batch, size, future_frames, train=True):
+    tmp = REPO / "build" / "golden_tmp"
+    kw = dict(future_frames=future_frames)
+    unet_path, punet_path, _ = _checkpoints(tmp, kw, model_type, 2)
+    torch.manual_seed(0)
+    cfg = stage2_cfg(model_type, 2, dropout=0.0, unet_path=str(unet_path), punet_path=str(punet_path), **kw)
+    model = ref_moe.get_model(cfg)
+    weights.fill_state_dict(model, seed=0)
+    model.train(train)
+    inp = weights.make_inputs(batch, size, size, seed=1234)
+    out = {"meta": dict(name=name, type=model_type, n_experts=2, batch=batch, size=size, train=train, weight_seed=0,
+                        input_seed=1234, future_frames=future_frames),
+           "state_dict_keys": list(model.state_dict().keys()),
+           "state_dict_shapes": [tuple(v.shape) for v in model.state_dict().values()],
+           "requires_grad": {k: p.requires_grad for k, p in model.named_parameters()}}
+    if train:
+        actions, speeds = model(inp["images"], inp["speed"], inp["command"])
+        loss = ref_loss.punet_loss(actions, speeds, inp["control"], inp["target_speed"], cfg.loss_coefs)
+        loss.backward()
+        out["loss"] = loss.detach().clone()
+        named = dict(model.named_parameters())
+        out["grad_norms"] = {k: p.grad.norm().item() for k, p in named.items() if p.grad is not None}
+        out["grad_slices"] = {k: named[k].grad.flatten()[:64].clone() for k in PUNET_SLICES if k in named}
+        sd = model.state_dict()
+        out["bn_after_1"] = {f"{b}.{leaf}": sd[f"{b}.{leaf}"].clone() for b in PUNET_BN
+                             for leaf in ("running_mean", "running_var", "num_batches_tracked") if f"{b}.{leaf}" in sd}
+    else:
+        with torch.no_grad():
+            actions, speeds = model(inp["images"], inp["speed"], inp["command"])
+    out["actions"], out["speeds"] = actions.detach().clone(), speeds.detach().clone()
+    if model_type == "punet":                       # the frozen PU-Net's own output, sub-sampled, eval mode
+        with torch.no_grad():
+            model.eval()
+            out["punet_masks_eval"] = model.punet(inp["images"])[:, :, :, ::8, ::8].clone()
+            model.train(train)
+    return out
+
+
+def run_pmoe_case(ref_moe, ref_loss, name, batch, size, future_frames, n_experts):
+    """type 'pmoe' (moe.py:326-363) with exclude_freeze = [lat_weights, long_weights] (stage_2_pmoe.yaml:81) and no
+    pretrained PU-Net action model: the blend weights and the PU-Net expert's heads / backbone train."""
+    tmp = REPO / "build" / "golden_tmp"
+    kw = dict(future_frames=future_frames)
+    unet_path, punet_path, moe_dir = _checkpoints(tmp, kw, "punet", n_experts)
+    cfg0 = stage2_cfg("pmoe", n_experts, dropout=0.0)
+    torch.save(ref_moe.MixtureOfExperts(cfg0).state_dict(), moe_dir)
+    cfg = stage2_cfg("pmoe", n_experts, dropout=0.0, unet_path=str(unet_path), punet_path=str(punet_path),
+                     moe_dir=str(moe_dir), exclude_freeze=["lat_weights", "long_weights"], **kw)
+    model = ref_moe.get_model(cfg)
+    weights.fill_state_dict(model, seed=0)
+    model.train()
+    inp = weights.make_inputs(batch, size, size, seed=1234)
+    out = {"meta": dict(name=name, type="pmoe", n_experts=n_experts, batch=batch, size=size, train=True, weight_seed=0,
+                        input_seed=1234, future_frames=future_frames, sample_seed=77),
+           "state_dict_keys": list(model.state_dict().keys()),
+           "state_dict_shapes": [tuple(v.shape) for v in model.state_dict().values()],
+           "requires_grad": {k: p.requires_grad for k, p in model.named_parameters()}}
+    # one pass to learn what dists.sample() draws under the seed (BN buffers are restored afterwards)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(77)
+    with torch.no_grad():
+        pa, _ = model.punet(inp["images"], inp["speed"], inp["command"])
+        dists, _ = model.moe(inp["images"], inp["speed"], inp["command"])
+        out["moe_actions"] = dists.sample().clone()
+        out["punet_actions"] = pa.clone()
+        out["probs"] = dists.mixture_distribution.probs.clone()
+        out["mean"] = dists.component_distribution.base_dist.loc.clone()
+        out["std"] = dists.component_distribution.base_dist.scale.clone()
+    model.load_state_dict(sd0)
+    torch.manual_seed(77)
+    actions, dummy = model(inp["images"], inp["speed"], inp["command"])
+    assert dummy == -1
+    loss = ref_loss.pmoe_loss(actions, dummy, inp["control"], inp["target_speed"], cfg.loss_coefs)
+    loss.backward()
+    out["actions"], out["loss"] = actions.detach().clone(), loss.detach().clone()
+    named = dict(model.named_parameters())
+    out["grad_norms"] = {k: p.grad.norm().item() for k, p in named.items() if p.grad is not None}
+    out["grads_small"] = {k: named[k].grad.clone() for k in ("lat_weights.weight", "lat_weights.bias", "long_weights.weight",
+                                                             "long_weights.bias", "punet.action_pred.1.weight",
+                                                             "punet.action_pred.1.bias")}
+    return out
+
+
 def micro_cases(ref_basics, ref_loss):
     """Layer-level fixtures (G5): ECA kernel sizes, make_mlp layouts, ECA forward, moe_loss values."""
     out = {}
@@ -174,6 +282,11 @@ def micro_cases(ref_basics, ref_loss):
     dist = D.MixtureSameFamily(D.Categorical(probs), D.Independent(D.Normal(mean, std), 1))
     out["loss_case"] = dict(probs=probs, mean=mean, std=std, speeds=speeds, act=act, tgt=tgt,
                             loss=ref_loss.moe_loss(dist, speeds, act, tgt.clone(), [0.7, 0.3]).detach())
+    a2 = torch.tanh(torch.randn(5, 2, generator=g))
+    sp1 = torch.randn(5, 1, generator=g)
+    out["action_loss_case"] = dict(actions=a2, speeds=sp1, act=act, tgt=tgt,
+                                   punet_loss=ref_loss.punet_loss(a2, sp1, act, tgt, [0.7, 0.3]).detach(),
+                                   pmoe_loss=ref_loss.pmoe_loss(a2, -1, act, tgt, [0.7, 0.3]).detach())
     sp2 = torch.randn(5, 1, generator=g)
     out["loss_case_shared"] = dict(probs=probs, mean=mean, std=std, speeds=sp2, act=act, tgt=tgt,
                                    loss=ref_loss.moe_loss(dist, sp2, act, tgt.clone(), [0.7, 0.3]).detach())
@@ -202,8 +315,22 @@ def main():
         res = run_case(ref_moe, ref_loss, name, t, e, b, s, train, steps)
         torch.save(res, gold / f"{name}.pt")
         print(name, "loss" in res and float(res["loss"]), res["probs"][0].tolist())
+    pcases = [("p1_punet_b2_64_f2", "punet", 2, 64, 2, True), ("p2_punet_b1_64_f6_eval", "punet", 1, 64, 6, False),
+              ("p3_punetinter_b2_64_f2", "punet_inter", 2, 64, 2, True), ("p4_punet_b3_96_f3", "punet", 3, 96, 3, True)]
+    for name, t, b, sz, f, train in pcases:
+        if only and name not in only:
+            continue
+        res = run_punet_case(ref_moe, ref_loss, name, t, b, sz, f, train)
+        torch.save(res, gold / f"{name}.pt")
+        print(name, "loss" in res and float(res["loss"]), res["actions"].tolist())
+    if not only or "p5_pmoe_e2_b2_64_f2" in only:
+        res = run_pmoe_case(ref_moe, ref_loss, "p5_pmoe_e2_b2_64_f2", 2, 64, 2, 2)
+        torch.save(res, gold / "p5_pmoe_e2_b2_64_f2.pt")
+        print("p5_pmoe_e2_b2_64_f2", float(res["loss"]), res["actions"].tolist())
     if not only or "micro" in only:
         torch.save(micro_cases(ref_basics, ref_loss), gold / "micro.pt")
+    import shutil
+    shutil.rmtree(REPO / "build" / "golden_tmp", ignore_errors=True)
     print("wrote", sorted(p.name for p in gold.glob("*.pt")))
 
 

@@ -42,21 +42,25 @@ class Cfg(dict):
         return obj
 
 
-def stage2_cfg(model_type="moe", n_experts=4, dropout=0.0, n_commands=6, n_frames=4):
-    """The ``model:`` node of ``conf/stage_2_moe.yaml:76-133`` with the knobs the tests vary."""
+def stage2_cfg(model_type="moe", n_experts=4, dropout=0.0, n_commands=6, n_frames=4, future_frames=6,
+               unet_path="", punet_path="", moe_dir="", punet_dir="", exclude_freeze=()):
+    """The ``model:`` node of ``conf/stage_2_moe.yaml:76-133`` / ``stage_2_pmoe.yaml:76-133`` with the knobs the
+    tests vary."""
     def mlp(dims, act, l_act=False):
         return dict(dims=list(dims), act=act, l_act=l_act, bn=False, dropout=dropout)
 
     return Cfg.wrap(dict(
         verbose=False, type=model_type, n_experts=n_experts, loss_coefs=[0.7, 0.3],
-        exclude_freeze=[], device="cpu", punet_path="",
+        exclude_freeze=list(exclude_freeze), device="cpu", punet_path=punet_path,
         action_head=mlp([1536, 512, 512], "elu", True),
         speed_encoder=mlp([1, 512, 512], "relu"),
         command_encoder=mlp([n_commands, 512, 512], "relu"),
         speed_prediction=mlp([1536, 512, 512, 1], "relu"),
         backbone=dict(type="rgb", n_frames=n_frames,
                       rgb=dict(arch="resnet18", pretrained=False, gamma=2, b=1)),
-        pmoe=dict(moe_dir="", punet_dir=""),
+        punet=dict(past_frames=n_frames, future_frames=future_frames, in_features=3, num_classes=23, gamma=2, b=1,
+                   unet_inter_repr=False, model_name="unet", model_path=unet_path),
+        pmoe=dict(moe_dir=moe_dir, punet_dir=punet_dir),
     ))
 
 
@@ -239,12 +243,170 @@ class MixtureOfExpertsShared(nn.Module):
         return self.forward(images, speed, command)[0].sample()
 
 
+def conv3(in_ch, out_ch, stride=1):
+    """``blocks/basics.py:47-58``."""
+    return nn.Sequential(
+        nn.Conv2d(in_ch, out_ch, 3, stride, 1, bias=False), nn.BatchNorm2d(out_ch), nn.ReLU(inplace=True),
+        nn.Conv2d(out_ch, out_ch, 3, stride, 1, bias=False), nn.BatchNorm2d(out_ch), nn.ReLU(inplace=True))
+
+
+class UNet(nn.Module):
+    """``blocks/unet.py:8-95``: 5 conv3 blocks down (MaxPool2d(2) between), 4x [ConvTranspose2d(k2,s2) -> cat skip ->
+    conv3] up, 1x1 class conv.  ``Dropout2d(p=0)`` of the reference is the identity and is omitted."""
+
+    def __init__(self, in_features=3, out_features=23, gamma=2, b=1, dropout=0.0, inter_repr=False):
+        super().__init__()
+        assert dropout == 0.0
+        self.inter_repr = inter_repr
+        self.dwn_1, self.dwn_2, self.dwn_3 = conv3(in_features, 64), conv3(64, 128), conv3(128, 256)
+        self.dwn_4, self.dwn_5 = conv3(256, 512), conv3(512, 512)
+        self.up_1, self.up_forw_1 = nn.ConvTranspose2d(512, 512, 2, 2), conv3(1024, 512)
+        self.up_2, self.up_forw_2 = nn.ConvTranspose2d(512, 256, 2, 2), conv3(512, 256)
+        self.up_3, self.up_forw_3 = nn.ConvTranspose2d(256, 128, 2, 2), conv3(256, 128)
+        self.up_4, self.up_forw_4 = nn.ConvTranspose2d(128, 64, 2, 2), conv3(128, 64)
+        self.out = nn.Conv2d(64, out_features, 1)
+
+    def forward(self, image):
+        skips, x = [], image
+        for blk in (self.dwn_1, self.dwn_2, self.dwn_3, self.dwn_4):
+            x = blk(x)
+            skips.append(x)
+            x = F.max_pool2d(x, 2, 2)
+        x5 = x = self.dwn_5(x)
+        for up, fw in ((self.up_1, self.up_forw_1), (self.up_2, self.up_forw_2), (self.up_3, self.up_forw_3),
+                       (self.up_4, self.up_forw_4)):
+            skip = skips.pop()
+            x = fw(torch.cat([skip, up(x, output_size=skip.size())], 1))
+        x = self.out(x)
+        if self.inter_repr:
+            return torch.flatten(F.adaptive_avg_pool2d(x5, 1), 1), x
+        return x
+
+
+class PredictiveUnet(nn.Module):
+    """``model/punet.py:13-120``.  ``model_path=None`` skips the checkpoint read (the tests fill every weight from
+    ``oracle.weights``); otherwise it is loaded exactly like the reference (punet.py:40-55)."""
+
+    def __init__(self, past_frames=4, future_frames=4, in_features=3, num_classes=23, gamma=2, b=1, inter_repr=False,
+                 unet_inter_repr=False, model_name="unet-swa", model_path="unet.pth"):
+        super().__init__()
+        self.n_past_frames, self.n_future_frames = past_frames, future_frames
+        self.inter_repr, self.unet_inter_repr = inter_repr, unet_inter_repr
+        self.unet = UNet(in_features, num_classes, gamma, b, inter_repr=unet_inter_repr)
+        if model_path:
+            self.unet.load_state_dict(torch.load(model_path)[model_name], strict=False)
+        for p in self.unet.parameters():
+            p.requires_grad = False
+        self.unet.eval()
+        self.entry_block = EfficientConvBlock(past_frames * num_classes, in_features, gamma=gamma, b=b)
+        self.pred_unet = UNet(in_features, num_classes, gamma, b, inter_repr=inter_repr)
+
+    def forward(self, img_list):
+        assert img_list.shape[-4] == self.n_past_frames, "Number of images should match number of past frames"
+        masks = [self.unet(img_list[:, i]) for i in range(self.n_past_frames)]
+        assert self.n_future_frames > 0 and not self.unet_inter_repr
+        outs, inter = [], None
+        for _ in range(self.n_future_frames):
+            m = self.pred_unet(self.entry_block(torch.cat(masks[-self.n_past_frames:], dim=-3)))
+            if self.inter_repr:
+                inter, m = m
+            masks.append(m)
+            outs.append(m)
+        return inter if self.inter_repr else torch.stack(outs, dim=1)
+
+
+class PUNetExpert(nn.Module):
+    """``model/moe.py:268-323``."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.return_inter = params.type == "punet_inter"
+        params.punet.inter_repr = self.return_inter
+        self.speed_encoder = make_mlp(**params.speed_encoder)
+        self.command_encoder = make_mlp(**params.command_encoder)
+        self.punet = PredictiveUnet(**params.punet)
+        if params.punet_path:
+            self.punet.load_state_dict(torch.load(params.punet_path, map_location=params.device)["model"])
+        for p in self.punet.parameters():            # freeze(self.punet), utils/nn.py:22-58 with an empty exclude list
+            p.requires_grad_(False)
+        self.backbone = None if self.return_inter else get_backbone(
+            **{**params.backbone.rgb, "n_frames": params.punet.future_frames, "n_channels": params.punet.num_classes})
+        self.speed_pred = make_mlp(**params.speed_prediction)
+        self.action_pred = nn.Sequential(make_mlp(**params.action_head), nn.Linear(params.action_head.dims[-1], 2))
+
+    def forward(self, images, speed, command):
+        s = self.speed_encoder(speed)
+        c = self.command_encoder(command)
+        if self.return_inter:
+            img = self.punet(images)
+        else:
+            m = self.punet(images)
+            img = self.backbone(m.view(m.shape[0], -1, m.shape[-2], m.shape[-1]))
+        feats = torch.cat([img, s, c], dim=-1)
+        return torch.tanh(self.action_pred(feats)), self.speed_pred(feats)
+
+    def sample(self, images, speed, command):
+        return self.forward(images, speed, command)[0]
+
+
+def _freeze(model, exclude):
+    """``utils/nn.py:22-58``."""
+    for name, p in model.named_parameters():
+        if not exclude or not any(tag in name for tag in exclude):
+            p.requires_grad_(False)
+    return model
+
+
+class PMoE(nn.Module):
+    """``model/moe.py:326-363``; ``blend`` is the deterministic tail of ``forward`` (moe.py:353-356)."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.moe = MixtureOfExperts(params)
+        if params.pmoe.moe_dir:
+            self.moe.load_state_dict(torch.load(params.pmoe.moe_dir), strict=False)
+        self.moe = _freeze(self.moe, params.exclude_freeze)
+        self.punet = PUNetExpert(params)
+        if params.pmoe.punet_dir:
+            self.punet.load_state_dict(torch.load(params.pmoe.punet_dir), strict=False)
+            self.punet = _freeze(self.punet, params.exclude_freeze)
+        self.lat_weights = nn.Linear(2, 1)
+        self.long_weights = nn.Linear(2, 1)
+
+    def blend(self, moe_actions, punet_actions):
+        lat = self.lat_weights(torch.cat([moe_actions[:, 0:1], punet_actions[:, 0:1]], dim=-1))
+        lon = self.long_weights(torch.cat([moe_actions[:, 1:], punet_actions[:, 1:]], dim=-1))
+        return torch.tanh(torch.cat([lat, lon], dim=-1))
+
+    def forward(self, images, speed, command):
+        punet_actions, _ = self.punet(images.clone(), speed.clone(), command.clone())
+        dists, _ = self.moe(images, speed, command)
+        return self.blend(dists.sample(), punet_actions), -1
+
+    def sample(self, images, speed, command):
+        return self.forward(images, speed, command)[0]
+
+
+def punet_loss(actions, speed_pred, actions_gt, speed_gt, loss_coefs):
+    """``trainer/loss.py:135-142``."""
+    return loss_coefs[0] * F.l1_loss(actions, actions_gt) + loss_coefs[1] * F.mse_loss(speed_pred, speed_gt)
+
+
+def pmoe_loss(actions, speed_pred, actions_gt, speed_gt, loss_coefs):
+    """``trainer/loss.py:145-151``."""
+    return F.l1_loss(actions, actions_gt)
+
+
 def get_model(cfg):
-    """``model/moe.py:25-47`` (MoE families only in the oracle so far)."""
+    """``model/moe.py:25-47``."""
     if cfg.type in ("moe", "moe_alt"):
         return MixtureOfExperts(cfg)
     if cfg.type == "moe_shared":
         return MixtureOfExpertsShared(cfg)
+    if cfg.type in ("punet", "punet_inter"):
+        return PUNetExpert(cfg)
+    if cfg.type in ("pmoe", "pmoe+pretrained"):
+        return PMoE(cfg)
     raise ValueError(f"{cfg.type} is UNKNOWN or not restated by the oracle yet")
 
 

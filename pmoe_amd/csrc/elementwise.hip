@@ -371,6 +371,7 @@ __global__ void __launch_bounds__(256) gap_partial_kernel(const T* __restrict__ 
     float s[VE];
 #pragma unroll
     for (int i = 0; i < VE; ++i) s[i] = 0.f;
+    if (rl >= RL) r0 = r1;                 // channel-vector counts that do not divide 256 leave a few idle lanes
     for (long long r = r0 + rl; r < r1; r += RL) {
         float av[VE];
         unpack16<T>(ldg16(a + ((size_t)n * HW + r) * C + cv * VE), av);
@@ -386,7 +387,8 @@ __global__ void __launch_bounds__(256) gap_partial_kernel(const T* __restrict__ 
     }
     __shared__ float red[256 * 8];
 #pragma unroll
-    for (int i = 0; i < VE; ++i) red[rl * C + cv * VE + i] = s[i];
+    for (int i = 0; i < VE; ++i)
+        if (rl < RL) red[rl * C + cv * VE + i] = s[i];
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float t = 0.f;
@@ -677,7 +679,7 @@ int pmoe_gap_partial(const void* a, const void* b, float* part, int32_t N, int64
                      int32_t b_shared_ipe, int32_t dtype, void* stream) {
     DISPATCH_DT(dtype, {
         constexpr int VE = 16 / (int)sizeof(T);
-        if (C % VE || !pow2(C / VE) || C / VE > 256 || nparts < 1) return PMOE_ERR_ARG;
+        if (C % VE || C / VE > 256 || nparts < 1) return PMOE_ERR_ARG;
         hipLaunchKernelGGL((gap_partial_kernel<T>), dim3(nparts, N), dim3(256), 0, (hipStream_t)stream, (const T*)a,
                            (const T*)b, part, (long long)HW, C, nparts, b_shared_ipe);
         return (int)hipGetLastError();

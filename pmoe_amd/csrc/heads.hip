@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) eca_stem_fold_ds_kernel(const float* __re
     const int lanes_per_c = 256 / gld;
     const int c = threadIdx.x % gld, sl = threadIdx.x / gld;
     float s = 0.f;
-    if (c < cin)
+    if (c < cin && sl < lanes_per_c)       // row lengths that do not divide 256 (144 for the 138-ch stem) leave idle lanes
         for (int kt = sl; kt < cout * taps; kt += lanes_per_c) {
             const int k = kt / taps, t = kt % taps;
             s += we[((size_t)k * cin + c) * taps + t] * G[(((size_t)n * taps + t) * coutp + k) * cinp + c];
@@ -328,7 +328,7 @@ int pmoe_pack_bias(const void* const* src_ptrs, float* dst, int32_t E, int32_t c
 int pmoe_eca_stem_fold(const float* G, const float* gate, const void* const* w_ptrs, float* dw, float* ds, int32_t N,
                        int32_t ipe, int32_t cout, int32_t cin, int32_t ks, int32_t coutp, int32_t cinp, int32_t gate_ld,
                        void* stream) {
-    if (N % ipe || gate_ld > 256 || 256 % gate_ld || cin > cinp || cin > gate_ld || cout > coutp) return PMOE_ERR_ARG;
+    if (N % ipe || gate_ld > 256 || cin > cinp || cin > gate_ld || cout > coutp) return PMOE_ERR_ARG;
     const int taps = ks * ks, E = N / ipe;
     int g = (cout * cin * taps + 255) / 256;
     hipLaunchKernelGGL(eca_stem_fold_dw_kernel, dim3(g, E), dim3(256), 0, (hipStream_t)stream, G, gate, dw, ipe, cout, cin,

@@ -147,8 +147,9 @@ class ExpertGroupEngine:
                                     [m.bias for m in mods] if m0.bias is not None else None,
                                     m0.in_features, m0.out_features, 1, 1, 0)
             else:
-                layer = GroupedConv(self, name, [m.weight for m in mods], None, m0.in_channels, m0.out_channels,
-                                    m0.kernel_size, m0.stride, m0.padding)
+                layer = GroupedConv(self, name, [m.weight for m in mods],
+                                    [m.bias for m in mods] if getattr(m0, "bias", None) is not None else None,
+                                    m0.in_channels, m0.out_channels, m0.kernel_size, m0.stride, m0.padding)
             self.params.append(("w", layer, layer.weights))
             if layer.biases is not None:
                 self.params.append(("b", layer, layer.biases))
@@ -181,9 +182,27 @@ class ExpertGroupEngine:
             return dict(layers=layers, act=hip.ACT_RELU if spec["act"] == "relu" else hip.ACT_ELU,
                         l_act=spec["l_act"], dropout=spec["dropout"])
 
-        bbs = [e.backbone for e in ex]
+        self._mk = dict(conv=conv, bn=bn, eca=eca, mlp=mlp)
         self.speed_enc = mlp("speed_encoder", [e.speed_encoder for e in ex])
         self.cmd_enc = mlp("command_encoder", [e.command_encoder for e in ex])
+        self._collect_pre_backbone(ex)
+        self._collect_backbone([e.backbone for e in ex])
+        self._collect_heads(ex)
+        del self._mk
+        if self.conv1 is not None:
+            self.conv1.need_dgrad = self._stem_needs_dgrad()
+        self.all_convs = [p[1] for p in self.params if p[0] == "w"]
+        self.all_bns = [p[1] for p in self.params if p[0] == "gamma"]
+        self.flat_params = [p for _, _, plist in self.params for p in plist]
+
+    def _collect_pre_backbone(self, ex):
+        """hook: layers that run before the ResNet backbone (the frozen PU-Net of PUNetExpert)."""
+
+    def _stem_needs_dgrad(self):
+        return True
+
+    def _collect_backbone(self, bbs):
+        conv, bn, eca = self._mk["conv"], self._mk["bn"], self._mk["eca"]
         self.eca1 = eca("eca1", [b.conv1.layer1.eca1 for b in bbs])
         self.conv1 = conv("stem.conv1", [b.conv1.layer1.conv1[0] for b in bbs])
         self.bn_c1 = bn("stem.bn1", [b.conv1.layer1.conv1[1] for b in bbs])
@@ -204,6 +223,9 @@ class ExpertGroupEngine:
                     d["down"] = (conv(f"layer{li}.{bi}.down", [k.downsample[0] for k in blks]),
                                  bn(f"layer{li}.{bi}.downbn", [k.downsample[1] for k in blks]))
                 self.blocks.append(d)
+
+    def _collect_heads(self, ex):
+        conv, mlp = self._mk["conv"], self._mk["mlp"]
         self.speed_pred = mlp("speed_pred", [e.speed_pred for e in ex])
         self.action_feat = mlp("action_features", [e.action_features for e in ex])
         if self.alt:
@@ -214,10 +236,6 @@ class ExpertGroupEngine:
         else:
             # action_pred (4 rows) and alpha (1 row) read the same input: one GEMM with 5 output rows
             self.head = self._fused_head(ex)
-        self.conv1.need_dgrad = True
-        self.all_convs = [p[1] for p in self.params if p[0] == "w"]
-        self.all_bns = [p[1] for p in self.params if p[0] == "gamma"]
-        self.flat_params = [p for _, _, plist in self.params for p in plist]
 
     def _fused_head(self, ex):
         class _Cat:  # weights of action_pred (rows 0..3) and alpha (row 4) as one 5-row layer
@@ -238,7 +256,7 @@ class ExpertGroupEngine:
         key = (str(dev), dtype)
         if self._built_for == key:
             return
-        for layer in self.all_convs + ([self.head] if not self.alt else []):
+        for layer in self.all_convs + ([self.head] if getattr(self.head, "parts", None) else []):
             if layer.w_fwd is None or layer.w_fwd.dtype != dtype or layer.w_fwd.device != dev:
                 layer.alloc(dtype, dev)
         self._ptr_key = None
@@ -259,6 +277,8 @@ class ExpertGroupEngine:
         for bnl in self.all_bns:
             add(("rm", id(bnl)), [m.running_mean for m in bnl.mods])
             add(("rv", id(bnl)), [m.running_var for m in bnl.mods])
+        for key, lst in self._extra_tables():
+            add(key, lst)
         ptrs = tuple(t.data_ptr() for t in tensors)
         if ptrs != self._ptr_key:
             for t in tensors:
@@ -269,6 +289,10 @@ class ExpertGroupEngine:
             self._ptr_key = ptrs
             self._ptr_index = index
             self._packed_version = None
+
+    def _extra_tables(self):
+        """hook: additional (key, [tensors]) pointer-table rows (padded BatchNorm shadows of the PU-Net engine)."""
+        return []
 
     def _tab(self, kind, layer):
         k = (kind, id(layer) if not isinstance(layer, tuple) else (id(layer[0]), layer[1]))
@@ -281,7 +305,7 @@ class ExpertGroupEngine:
             return
         for layer in self.all_convs:
             layer.pack(self._tab("w", layer), self._tab("b", layer) if layer.biases is not None else None)
-        if not self.alt:
+        if getattr(self.head, "parts", None):
             h = self.head
             E = self.E
             # two packs into row windows of the fused 5-row head: rows 0..3 action_pred, row 4 alpha
@@ -659,9 +683,7 @@ class ExpertGroupEngine:
         return self._slots[self._order[self._cursor]][0]
 
     # ------------------------------------------------------------------ network
-    def forward(self, images, speed, command, training, taping, dtype, base_seed=0):
-        """Returns probs [B,K], mean [B,K,2], std [B,K,2], speeds [B,K,1] ([B,1] for the shared trunk), f32, and
-        the tape."""
+    def _begin(self, images, training, taping, dtype, base_seed):
         if images.dim() != 5:
             raise ValueError(f"images: expected [B,T,C,H,W], got {tuple(images.shape)}")
         if not images.is_cuda:
@@ -672,7 +694,6 @@ class ExpertGroupEngine:
         self.base_seed = int(base_seed)
         Bsz = images.shape[0]
         self.B, self.N = Bsz, Bsz * self.E
-        E = self.E
         self._ensure_built(self.dev, dtype)
         self._refresh_tables(self.dev)
         self._pack_all()
@@ -682,22 +703,26 @@ class ExpertGroupEngine:
         if self._ws is not None and self._ws.device != self.dev:
             self._ws = None
 
-        H, W = images.shape[-2:]
-        cin = images.shape[1] * images.shape[2]
-        if cin != self.conv1.cin:
-            raise ValueError(f"images carry {cin} channels (T*C), the backbone stem expects {self.conv1.cin}")
-        if speed.shape != (Bsz, self.speed_enc["layers"][0].cin) or command.shape != (Bsz, self.cmd_enc["layers"][0].cin):
-            raise ValueError("speed / command shapes do not match the encoders")
-        img = images.reshape(Bsz, cin, H, W).contiguous().float()
-        x0 = Var(self._new(Bsz, H, W, r16(cin)))
-        ops.nchw_to_nhwc(img, x0.t)
-        spd = Var(self._new(Bsz, 1, 1, 16))
-        ops.pad_rows(speed.contiguous().float(), spd.t.view(Bsz, 16))
-        cmd = Var(self._new(Bsz, 1, 1, 16))
-        ops.pad_rows(command.contiguous().float(), cmd.t.view(Bsz, 16))
+        return Bsz
+
+    def forward(self, images, speed, command, training, taping, dtype, base_seed=0):
+        """Returns probs [B,K], mean [B,K,2], std [B,K,2], speeds [B,K,1] ([B,1] for the shared trunk), f32, and
+        the tape."""
+        Bsz = self._begin(images, training, taping, dtype, base_seed)
+        x0 = self._image_input(images)
+        spd, cmd = self._measurement_inputs(speed, command)
 
         feat = Var(self._new(self.N, 1, 1, 1536))
-        # ---- perception stack: ResNet18 body with the ECA stem (backbone.py:63-70, basics.py:79-134)
+        self._backbone_fwd(x0, feat)
+        # ---- measurement encoders write straight into their slots of the 1536-d feature (moe.py:88-95)
+        self._mlp(spd, self.speed_enc, out=feat, out_coff=512, in_shared=True)
+        self._mlp(cmd, self.cmd_enc, out=feat, out_coff=1024, in_shared=True)
+        return self._heads_fwd(feat, Bsz, training)
+
+    def _backbone_fwd(self, x0, feat):
+        """x0 [B,H,W,Cp] (shared by all experts) -> feat[:, 0:512]: ResNet18 body with the ECA stem
+        (backbone.py:63-70, basics.py:79-134)."""
+        H, W = x0.t.shape[1], x0.t.shape[2]
         hw_ok = H * W >= 256                                 # per-image filter gradients need one tile <= one image
         if self.fold_stem_input and self.taping and hw_ok and (self.conv1.trainable or self.eca1.trainable):
             # backward of (ECA gate -> conv1) from per-image filter gradients: no data-gradient conv (heads.hip)
@@ -727,10 +752,9 @@ class ExpertGroupEngine:
                 idn = self._bn(zD, blk["down"][1], relu=False, stats=std_)
             o = self._bn(zB, blk["bn2"], relu=True, res=idn, stats=st)
         self._gap_to(o, feat, 0)
-        # ---- measurement encoders write straight into their slots of the 1536-d feature (moe.py:88-95)
-        self._mlp(spd, self.speed_enc, out=feat, out_coff=512, in_shared=True)
-        self._mlp(cmd, self.cmd_enc, out=feat, out_coff=1024, in_shared=True)
-        # ---- heads
+
+    def _heads_fwd(self, feat, Bsz, training):
+        E = self.E
         sp = self._mlp(feat, self.speed_pred)
         af = self._mlp(feat, self.action_feat)
         if self.alt:
@@ -747,11 +771,42 @@ class ExpertGroupEngine:
         # BaseExpert applies ReLU to alpha (moe.py:97); BaseExpertAlt (moe.py:126) and the shared head (moe.py:226) do not
         ops.gate_mixture_fwd(head5.t.view(self.N, -1), sp.t.view(self.N, 16), probs, mean, std, speeds, Bsz, K,
                              not self.alt and not self.shared, self.shared)
-        if training and self._bn_touched:
-            torch._foreach_add_([m.num_batches_tracked for l in self._bn_touched for m in l.mods], 1)
+        self._bump_batch_counters()
         state = dict(tape=self.tape, tail=(head5, sp, probs), B=self.B, N=self.N, dev=self.dev, dtype=self.dtype)
         self.tape = None
         return probs, mean, std, speeds, state
+
+    def _measurement_inputs(self, speed, command):
+        Bsz = self.B
+        if speed.shape != (Bsz, self.speed_enc["layers"][0].cin) or command.shape != (Bsz, self.cmd_enc["layers"][0].cin):
+            raise ValueError("speed / command shapes do not match the encoders")
+        spd = Var(self._new(Bsz, 1, 1, 16))
+        ops.pad_rows(speed.contiguous().float(), spd.t.view(Bsz, 16))
+        cmd = Var(self._new(Bsz, 1, 1, 16))
+        ops.pad_rows(command.contiguous().float(), cmd.t.view(Bsz, 16))
+        return spd, cmd
+
+    def _bump_batch_counters(self):
+        """num_batches_tracked += (train-mode passes through that BatchNorm during this forward)."""
+        if not self._bn_touched:
+            return
+        count, layers = {}, {}
+        for l in self._bn_touched:
+            count[id(l)] = count.get(id(l), 0) + 1
+            layers[id(l)] = l
+        tensors = [m.num_batches_tracked for k, l in layers.items() for m in l.mods]
+        steps = [count[k] for k, l in layers.items() for _ in l.mods]
+        torch._foreach_add_(tensors, steps)
+
+    def _image_input(self, images):
+        """[B,T,C,H,W] f32 -> NHWC [B,H,W,r16(T*C)] in the compute dtype (frames concatenated along channels, moe.py:90-92)."""
+        Bsz, (H, W) = images.shape[0], images.shape[-2:]
+        cin = images.shape[1] * images.shape[2]
+        if cin != self.conv1.cin:
+            raise ValueError(f"images carry {cin} channels (T*C), the backbone stem expects {self.conv1.cin}")
+        x0 = Var(self._new(Bsz, H, W, r16(cin)))
+        ops.nchw_to_nhwc(images.reshape(Bsz, cin, H, W).contiguous().float(), x0.t)
+        return x0
 
     def _conv_stats(self, x, layer, tape=True):
         # conv-epilogue statistics are plain sums (no sample to centre on before the conv has run): fine under
@@ -801,17 +856,8 @@ class ExpertGroupEngine:
             self.tape.append(bwd)
         return merged
 
-    def backward(self, tape_state, dprobs, dmean, dstd, dspeeds):
-        """Run the recorded tape in reverse; returns the flat gradient arena and per-parameter views."""
-        tape, (head5, sp, probs) = tape_state["tape"], tape_state["tail"]
-        self.B, self.N, self.dev, self.dtype = (tape_state[k] for k in ("B", "N", "dev", "dtype"))
-        self._layout_arena()
-        self._arena = torch.zeros(self._arena_numel, dtype=F32, device=self.dev)
-        self._filled, self._cursor = set(), 0
-        reducer = None
-        if self.dp_group is not None or (dist.is_initialized() and self.dp_enabled):
-            reducer = BucketedAllReduce(self.dp_group, self.dp_buckets)
-            reducer.begin(self._arena)
+    def _tail_bwd(self, tail, dprobs, dmean, dstd, dspeeds):
+        head5, sp, probs = tail
         dhead = torch.empty_like(head5.t)
         dspd = torch.empty_like(sp.t)
 
@@ -820,8 +866,23 @@ class ExpertGroupEngine:
         ops.gate_mixture_bwd(head5.t.view(self.N, -1), probs, c(dprobs), c(dmean), c(dstd), c(dspeeds),
                              dhead.view(self.N, -1), dspd.view(self.N, 16), self.B, self.K,
                              not self.alt and not self.shared, self.shared)
-        head5.set_grad(dhead)
-        sp.set_grad(dspd)
+        if dprobs is not None or dmean is not None or dstd is not None:
+            head5.set_grad(dhead)
+        if dspeeds is not None:
+            sp.set_grad(dspd)
+
+    def backward(self, tape_state, *douts):
+        """Run the recorded tape in reverse; returns the flat gradient arena and per-parameter views."""
+        tape = tape_state["tape"]
+        self.B, self.N, self.dev, self.dtype = (tape_state[k] for k in ("B", "N", "dev", "dtype"))
+        self._layout_arena()
+        self._arena = torch.zeros(self._arena_numel, dtype=F32, device=self.dev)
+        self._filled, self._cursor = set(), 0
+        reducer = None
+        if self.dp_group is not None or (dist.is_initialized() and self.dp_enabled):
+            reducer = BucketedAllReduce(self.dp_group, self.dp_buckets)
+            reducer.begin(self._arena)
+        self._tail_bwd(tape_state["tail"], *douts)
         for fn in reversed(tape):
             fn()
             if reducer is not None:

@@ -1,0 +1,291 @@
+"""Engine for ``PUNetExpert`` (``PMoE/model/moe.py:268-323``): frozen PU-Net -> ResNet18-ECA backbone -> tanh head.
+
+Built from the same primitive launches as :class:`pmoe_amd.engine.ExpertGroupEngine` (group of one):
+
+* the PU-Net (``model/punet.py:75-120``) is FORWARD ONLY -- ``freeze(self.punet)`` (moe.py:280) removes every one of
+  its parameters from training, so nothing is taped for it and the 138-channel stem needs no data gradient
+  (``eca1`` / ``conv1`` gradients come from the per-image filter-gradient fold, as in the MoE path);
+* train-mode BatchNorm inside the frozen U-Nets still uses batch statistics and updates its running buffers
+  (``model.train()`` in train_2.py:130 reaches them), exactly like the reference: the four past frames go through
+  ``unet`` one after the other, each with its own statistics;
+* ``ConvTranspose2d(k=2,s=2)`` is one 1x1 GEMM with 4*Cout rows + ``pmoe_pixel_shuffle2`` into the second half of
+  the skip-concatenation buffer; ``torch.cat`` / ``view`` of 23-class masks are ``pmoe_copy_window`` launches.
+"""
+import torch
+
+from . import hip, ops
+from .engine import ExpertGroupEngine, GroupedBN, GroupedConv, Var, r16, F32
+
+
+class _UpConv(GroupedConv):
+    """ConvTranspose2d(cin, cout, 2, 2) as a 1x1 layer with 4*cout rows (row (dy*2+dx)*cout + c)."""
+
+    def __init__(self, eng, name, mod):
+        super().__init__(eng, name, None, None, mod.in_channels, 4 * mod.out_channels, 1, 1, 0)
+        self.mod, self.c_up = mod, mod.out_channels
+        self.need_dgrad = False
+        self.biases = [mod.bias]          # marks "has bias" for alloc(); packed from the derived tensor below
+        self._derived_version = None
+
+    @property
+    def trainable(self):
+        return False
+
+    def pack_derived(self, dev):
+        m = self.mod
+        ver = (m.weight._version, m.bias._version, m.weight.data_ptr())
+        if ver == self._derived_version and self.w_fwd is not None:
+            return
+        # [cin, cout, 2, 2] -> [(dy, dx, cout), cin, 1, 1]: parameter re-layout of a frozen weight (host-side plumbing)
+        w = m.weight.detach().permute(2, 3, 1, 0).reshape(self.cout, self.cin, 1, 1).contiguous()
+        b = m.bias.detach().repeat(4).contiguous()
+        ops.pack_conv_weights(hip.ptr_table([w], dev), self.w_fwd, None, 1, self.cout, self.cin, 1, self.coutp, self.cinp,
+                              self.dg_rows, self.dg_red, self.w_fwd.dtype)
+        ops.pack_bias(hip.ptr_table([b], dev), self.bias_packed, 1, self.cout, self.coutp)
+        self._derived_version = ver
+
+
+class PUNetEngine(ExpertGroupEngine):
+    def __init__(self, expert):
+        self.return_inter = expert.return_inter
+        super().__init__([expert], alt=False)
+
+    # ------------------------------------------------------------------ structure
+    def _collect_pre_backbone(self, ex):
+        pu = ex[0].punet
+        self.pu = pu
+        self.up_layers = []
+        self.shadow_bns = []
+        self.unet = self._collect_unet("punet.unet", pu.unet)
+        conv, bn, eca = self._mk["conv"], self._mk["bn"], self._mk["eca"]
+        eb = pu.entry_block
+        self.entry = dict(eca1=eca("punet.entry.eca1", [eb.layer1.eca1]),
+                          conv1=conv("punet.entry.conv1", [eb.layer1.conv1[0]]),
+                          bn1=bn("punet.entry.bn1", [eb.layer1.conv1[1]]),
+                          eca2=eca("punet.entry.eca2", [eb.layer2.eca2]),
+                          conv2=conv("punet.entry.conv2", [eb.layer2.conv2[0]]),
+                          bn2=self._padded_bn("punet.entry.bn2", eb.layer2.conv2[1]))
+        self.pred_unet = self._collect_unet("punet.pred_unet", pu.pred_unet)
+        for layer in self._punet_convs():
+            layer.need_dgrad = False
+
+    def _punet_convs(self):
+        out = []
+        for U in (self.unet, self.pred_unet):
+            for blk in U["dwn"] + U["up_forw"]:
+                out += [blk["c1"], blk["c2"]]
+            out.append(U["out"])
+        return out + [self.entry["conv1"], self.entry["conv2"]]
+
+    def _padded_bn(self, name, mod):
+        """BatchNorm over C channels stored in r16(C)-wide rows (C = 3 after the entry block): the kernels index
+        whole rows, so gamma/beta/running stats are mirrored in zero-padded device buffers around each forward."""
+        layer = GroupedBN(name, [mod])
+        if mod.num_features % 16 == 0:
+            self.params.append(("gamma", layer, [mod.weight]))
+            self.params.append(("beta", layer, [mod.bias]))
+            return layer
+        layer.C = r16(mod.num_features)
+        layer.creal = mod.num_features
+        layer.shadow = None
+        self.shadow_bns.append(layer)
+        self.params.append(("gamma_real", layer, [mod.weight]))     # kept in the flat parameter list (frozen: no slot use)
+        self.params.append(("beta_real", layer, [mod.bias]))
+        return layer
+
+    def _collect_unet(self, name, U):
+        conv, bn = self._mk["conv"], self._mk["bn"]
+
+        def block(nm, seq):
+            return dict(c1=conv(f"{nm}.0", [seq[0]]), bn1=bn(f"{nm}.1", [seq[1]]),
+                        c2=conv(f"{nm}.3", [seq[3]]), bn2=bn(f"{nm}.4", [seq[4]]))
+
+        d = dict(mod=U, dwn=[block(f"{name}.dwn_{i}", getattr(U, f"dwn_{i}")) for i in range(1, 6)], up=[], up_forw=[])
+        for i in range(1, 5):
+            up = _UpConv(self, f"{name}.up_{i}", getattr(U, f"up_{i}"))
+            self.params.append(("wT", up, [up.mod.weight]))
+            self.params.append(("bT", up, [up.mod.bias]))
+            self.up_layers.append(up)
+            d["up"].append(up)
+            d["up_forw"].append(block(f"{name}.up_forw_{i}", getattr(U, f"up_forw_{i}")))
+        d["out"] = conv(f"{name}.out", [U.out])
+        return d
+
+    def _collect_backbone(self, bbs):
+        if self.return_inter:          # punet_inter: the PU-Net bottleneck vector is the image feature (moe.py:282-284)
+            self.blocks = []
+            self.conv1 = self.eca1 = None
+            return
+        super()._collect_backbone(bbs)
+
+    def _collect_heads(self, ex):
+        conv, mlp = self._mk["conv"], self._mk["mlp"]
+        e = ex[0]
+        self.speed_pred = mlp("speed_pred", [e.speed_pred])
+        # action_pred = Sequential(make_mlp(action_head), Linear(512, 2))  (moe.py:296-301)
+        self.action_feat = mlp("action_pred.0", [e.action_pred[0]])
+        self.head = conv("action_pred.1", [e.action_pred[1]])
+
+    def _ensure_built(self, dev, dtype):
+        key = (str(dev), dtype)
+        if self._built_for != key:
+            for up in self.up_layers:
+                up.alloc(dtype, dev)
+                up._derived_version = None
+            for l in self.shadow_bns:
+                l.shadow = {k: torch.zeros(l.C, dtype=F32, device=dev) for k in ("gamma", "beta", "rm", "rv")}
+        super()._ensure_built(dev, dtype)
+
+    def _extra_tables(self):
+        return [((kind, id(l)), [l.shadow[kind]]) for l in self.shadow_bns for kind in ("gamma", "beta", "rm", "rv")]
+
+    def _pack_all(self):
+        for up in self.up_layers:
+            up.pack_derived(self.dev)
+        super()._pack_all()
+
+    # ------------------------------------------------------------------ shadows of padded BatchNorms
+    def _shadows_in(self):
+        for l in self.shadow_bns:
+            m, c = l.mods[0], l.creal
+            l.shadow["gamma"][:c].copy_(m.weight.detach())
+            l.shadow["beta"][:c].copy_(m.bias.detach())
+            l.shadow["rm"][:c].copy_(m.running_mean)
+            l.shadow["rv"].fill_(1.0)
+            l.shadow["rv"][:c].copy_(m.running_var)
+
+    def _shadows_out(self):
+        for l in self.shadow_bns:
+            m, c = l.mods[0], l.creal
+            if m.training:
+                m.running_mean.copy_(l.shadow["rm"][:c])
+                m.running_var.copy_(l.shadow["rv"][:c])
+
+    # ------------------------------------------------------------------ PU-Net forward
+    def _conv3(self, x, blk):
+        z, st = self._conv_stats(x, blk["c1"])
+        a = self._bn(z, blk["bn1"], relu=True, stats=st)
+        z, st = self._conv_stats(a, blk["c2"])
+        return self._bn(z, blk["bn2"], relu=True, stats=st)
+
+    def _maxpool2(self, x):
+        n, h, w, c = x.t.shape
+        y = Var(self._new(n, h // 2, w // 2, c))
+        ops.maxpool2_fwd(x.t, y.t)
+        return y
+
+    def _unet_fwd(self, U, x):
+        """blocks/unet.py:49-95.  x [B,H,W,16] (3 real channels) -> masks [B,H,W,r16(num_classes)] (+ bottleneck)."""
+        self.training = U["mod"].training
+        n, H, W, _ = x.t.shape
+        if H % 16 or W % 16:
+            raise NotImplementedError("UNet on the HIP path needs H and W divisible by 16 (no output_padding rows in "
+                                      "the transposed convolutions); the reference configs use 224/256")
+        cats, h = [], x
+        for i in range(4):
+            a = self._conv3(h, U["dwn"][i])
+            c = a.t.shape[-1]
+            cat = Var(self._new(n, a.t.shape[1], a.t.shape[2], 2 * c))      # torch.cat([x_k, up], 1) buffer (unet.py:72)
+            ops.copy_window(a.t, 0, cat.t, 0, c)
+            cats.append(cat)
+            h = self._maxpool2(a)
+        x5 = h = self._conv3(h, U["dwn"][4])
+        for j in range(4):
+            cat, up = cats[3 - j], U["up"][j]
+            t = self._conv(h, up, bias=True)                                  # [n, h, w, 4*Cout]
+            ops.pixel_shuffle2(t.t, cat.t, up.c_up, dst_coff=up.c_up)
+            h = self._conv3(cat, U["up_forw"][j])
+        return self._conv(h, U["out"], bias=True), x5
+
+    def _entry_fwd(self, masks):
+        eb = self.entry
+        self.training = self.pu.entry_block.training
+        a = self._eca(masks, eb["eca1"], shared=False)
+        z, st = self._conv_stats(a, eb["conv1"])
+        a = self._bn(z, eb["bn1"], relu=True, stats=st)
+        a = self._eca(a, eb["eca2"], shared=False)
+        z = self._conv(a, eb["conv2"], bias=False)       # 3 real channels: centred colstats pass (no fused epilogue stats)
+        return self._bn(z, eb["bn2"], relu=True)
+
+    def _punet_fwd(self, images):
+        """punet.py:75-120: T past frames through ``unet``, then F autoregressive steps of
+        cat(4 masks) -> entry_block -> pred_unet.  Returns x0 [B,H,W,r16(F*classes)] or the bottleneck feature."""
+        pu = self.pu
+        Bsz, T = images.shape[0], images.shape[1]
+        if T != pu.n_past_frames:
+            raise AssertionError("Number of images should match number of past frames")      # punet.py:84-86
+        if pu.n_future_frames == 0:
+            raise NotImplementedError("PU-Net with future_frames=0 (plain segmentation output) is not on the HIP path")
+        H, W = images.shape[-2:]
+        nc, cpad = pu.num_classes, r16(pu.in_features)
+        masks = []
+        for i in range(T):
+            xi = Var(self._new(Bsz, H, W, cpad))
+            ops.nchw_to_nhwc(images[:, i].contiguous().float(), xi.t)
+            out = self._unet_fwd(self.unet, xi)[0]
+            masks.append(out)
+        F_ = pu.n_future_frames
+        x0 = None
+        if not self.return_inter:
+            x0 = Var(torch.zeros(Bsz, H, W, r16(F_ * nc), dtype=self.dtype, device=self.dev))
+        inter = None
+        for f in range(F_):
+            cat = Var(torch.zeros(Bsz, H, W, r16(T * nc), dtype=self.dtype, device=self.dev))
+            for k, m in enumerate(masks[-T:]):
+                ops.copy_window(m.t, 0, cat.t, k * nc, nc)
+            e = self._entry_fwd(cat)
+            m, inter = self._unet_fwd(self.pred_unet, e)
+            masks.append(m)
+            if x0 is not None:
+                ops.copy_window(m.t, 0, x0.t, f * nc, nc)         # torch.stack(outs,1).view(B,-1,H,W)  (punet.py:120, moe.py:311)
+        return x0, inter
+
+    # ------------------------------------------------------------------ network
+    def forward(self, images, speed, command, training, taping, dtype, base_seed=0):
+        """-> actions [B,2] (tanh), pred_speed [B,1], state."""
+        for p in self.pu.parameters():
+            if p.requires_grad:
+                raise NotImplementedError("PU-Net parameters must stay frozen on the HIP path (PUNetExpert freezes them, "
+                                          "moe.py:280); stage-1 PU-Net training is SURVEY.md section 8f N4")
+        Bsz = self._begin(images, training, taping, dtype, base_seed)
+        self._shadows_in()
+        e = self.experts[0]
+        top_training = training
+        spd, cmd = self._measurement_inputs(speed, command)
+        taping_saved, self.taping = self.taping, False          # nothing inside the frozen PU-Net is taped
+        x0, inter = self._punet_fwd(images)
+        self.taping = taping_saved
+        self.training = top_training
+        feat = Var(self._new(self.N, 1, 1, 1536))
+        if self.return_inter:
+            self._gap_to(inter, feat, 0)
+        else:
+            self.training = e.backbone.training
+            self._backbone_fwd(x0, feat)
+        self.training = e.speed_encoder.training
+        self._mlp(spd, self.speed_enc, out=feat, out_coff=512, in_shared=True)
+        self._mlp(cmd, self.cmd_enc, out=feat, out_coff=1024, in_shared=True)
+        sp = self._mlp(feat, self.speed_pred)
+        af = self._mlp(feat, self.action_feat)
+        head = self._conv(af, self.head)
+        actions = torch.empty(Bsz, 2, dtype=F32, device=self.dev)
+        speeds = torch.empty(Bsz, 1, dtype=F32, device=self.dev)
+        ops.action_head_fwd(head.t.view(Bsz, -1), sp.t.view(Bsz, -1), actions, speeds, Bsz)
+        self._shadows_out()
+        self._bump_batch_counters()
+        state = dict(tape=self.tape, tail=(head, sp, actions), B=self.B, N=self.N, dev=self.dev, dtype=self.dtype)
+        self.tape = None
+        return actions, speeds, state
+
+    def _tail_bwd(self, tail, dactions, dspeeds):
+        head, sp, actions = tail
+        dhead = torch.empty_like(head.t)
+        dspd = torch.empty_like(sp.t)
+
+        def c(t):
+            return t.contiguous().float() if t is not None else None
+        ops.action_head_bwd(actions, c(dactions), c(dspeeds), dhead.view(self.B, -1), dspd.view(self.B, -1), self.B)
+        if dactions is not None:
+            head.set_grad(dhead)
+        if dspeeds is not None:
+            sp.set_grad(dspd)

@@ -90,6 +90,14 @@ SIGNATURES = {
     "pmoe_gate_mixture_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pmoe_gate_mixture_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_moe_loss": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "pmoe_maxpool2s2_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_pixel_shuffle2": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_copy_window": [_P, _I, _I, _P, _I, _I, _L, _I, _I, _P],
+    "pmoe_action_head_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _P],
+    "pmoe_action_head_bwd": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
+    "pmoe_action_loss": [_P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P],
+    "pmoe_blend_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "pmoe_blend_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
 }
 _RESTYPES = {"pmoe_error_string": C.c_char_p}
 

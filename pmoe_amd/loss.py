@@ -44,3 +44,40 @@ def moe_loss(action_dists, speed_pred, actions_gt, speed_gt, loss_coefs):
     probs, mean, std = hp
     return _MoeLossFn.apply(probs, mean, std, speed_pred, actions_gt, speed_gt, float(loss_coefs[0]),
                             float(loss_coefs[1]))
+
+
+class _ActionLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, actions, speeds, actions_gt, speed_gt, c0, c1):
+        B = actions.shape[0]
+        dev = actions.device
+        loss = torch.empty(1, dtype=F32, device=dev)
+        da = torch.empty(B, 2, dtype=F32, device=dev)
+        dsp = torch.empty(B, 1, dtype=F32, device=dev) if speeds is not None else None
+        ops.action_loss(actions.contiguous().float(), speeds.contiguous().float() if speeds is not None else None,
+                        actions_gt.contiguous().float(),
+                        speed_gt.contiguous().float().view(B) if speeds is not None else None, c0, c1, loss, da, dsp, B)
+        ctx.has_speed = speeds is not None
+        ctx.save_for_backward(da, dsp if dsp is not None else da)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        da, dsp = ctx.saved_tensors
+        return g * da, (g * dsp if ctx.has_speed else None), None, None, None, None
+
+
+def punet_loss(actions, speed_pred, actions_gt, speed_gt, loss_coefs):
+    """``loss.py:135-142``: ``c0 * L1(actions, gt) + c1 * MSE(speed_pred, speed_gt)`` (fused HIP kernel)."""
+    if actions.shape != actions_gt.shape or actions.dim() != 2 or actions.shape[1] != 2:
+        raise ValueError("punet_loss: actions and actions_gt must both be [B,2]")
+    if speed_pred.numel() != actions.shape[0] or speed_gt.numel() != actions.shape[0]:
+        raise ValueError("punet_loss: one predicted / target speed per sample expected")
+    return _ActionLossFn.apply(actions, speed_pred, actions_gt, speed_gt, float(loss_coefs[0]), float(loss_coefs[1]))
+
+
+def pmoe_loss(actions, speed_pred, actions_gt, speed_gt, loss_coefs):
+    """``loss.py:145-151``: plain L1 imitation loss; the other arguments are dummies (interface consistency)."""
+    if actions.shape != actions_gt.shape or actions.dim() != 2 or actions.shape[1] != 2:
+        raise ValueError("pmoe_loss: actions and actions_gt must both be [B,2]")
+    return _ActionLossFn.apply(actions, None, actions_gt, None, 1.0, 0.0)

@@ -9,9 +9,11 @@ import torch
 import torch.nn as nn
 import torch.distributions as D
 
+from .. import ops
 from ..engine import ExpertGroupEngine
 from ..utils import freeze  # noqa: F401  (re-exported: the reference imports it from utils.nn)
 from . import blocks as B
+from .punet import PredictiveUnet
 
 _DEFAULT_DTYPE = torch.bfloat16
 
@@ -32,10 +34,13 @@ def get_model(cfg):
         return MixtureOfExperts(cfg)
     elif model_type == "moe_shared":
         return MixtureOfExpertsShared(cfg)
-    elif model_type in ["punet", "punet_inter", "pmoe", "pmoe+pretrained"]:
-        raise NotImplementedError(
-            f"model type {model_type!r} is a reference option that is not on the MI355X path yet "
-            "(SURVEY.md section 8: second tier / config 4); 'moe', 'moe_alt' and 'moe_shared' are")
+    elif model_type in ["punet", "punet_inter"]:
+        return PUNetExpert(cfg)
+    elif model_type in ["pmoe", "pmoe+pretrained"]:
+        assert cfg.pmoe.moe_dir != "", "MoE pretrained weights directory should be specified"
+        if model_type == "pmoe+pretrained":
+            assert cfg.pmoe.punet_dir != "", "PU-Net pretrained weights directory should be specified"
+        return PMoE(cfg)
     else:
         raise ValueError(
             f"{model_type} is UNKNOWN, model type should be one of 'moe', 'punet', "
@@ -47,14 +52,15 @@ class _GroupFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, images, speed, command, training, dtype, seed, taping, *params):
-        probs, mean, std, speeds, state = engine.forward(images, speed, command, training, taping, dtype, seed)
+        *outs, state = engine.forward(images, speed, command, training, taping, dtype, seed)
         ctx.engine, ctx.state = engine, state
+        ctx.set_materialize_grads(False)      # an unused output (e.g. pred_speed under pmoe_loss) leaves its head's .grad None
         ctx.param_ids = [id(p) for p in params]
-        return probs, mean, std, speeds
+        return tuple(outs)       # (probs, mean, std, speeds) for the mixtures; (actions, pred_speed) for PUNetExpert
 
     @staticmethod
-    def backward(ctx, dprobs, dmean, dstd, dspeeds):
-        grads = ctx.engine.backward(ctx.state, dprobs, dmean, dstd, dspeeds)
+    def backward(ctx, *douts):
+        grads = ctx.engine.backward(ctx.state, *douts)
         ctx.state = None
         out = [grads.get(i) if need else None for i, need in zip(ctx.param_ids, ctx.needs_input_grad[8:])]
         return (None,) * 8 + tuple(out)
@@ -68,12 +74,15 @@ class _Grouped(nn.Module):
     def _engine(self):
         eng = self.__dict__.get("_eng")
         if eng is None:
-            eng = ExpertGroupEngine(self._expert_list(), alt=self._alt(), shared_k=self._shared_k())
+            eng = self._make_engine()
             self.__dict__["_eng"] = eng          # not a submodule / not in state_dict / rebuilt after deepcopy
         return eng
 
     def _shared_k(self):
         return 0
+
+    def _make_engine(self):
+        return ExpertGroupEngine(self._expert_list(), alt=self._alt(), shared_k=self._shared_k())
 
     def __deepcopy__(self, memo):
         # AveragedModel(model) deep-copies (train_2.py:120): drop the engine (raw device buffers), copy the rest
@@ -217,6 +226,107 @@ class MixtureOfExpertsShared(_Grouped):
     def sample(self, images, speed, command):
         probs, mean, std, _ = self._run(images, speed, command)
         return MixtureDistribution(probs, mean, std).sample()
+
+
+class PUNetExpert(_Grouped):
+    """``moe.py:268-323``: frozen PU-Net (future segmentation masks) -> ResNet18-ECA backbone over the
+    ``future_frames * num_classes`` mask channels -> ``tanh`` action head; ``punet_inter`` feeds the PU-Net bottleneck
+    vector instead of a backbone.  Loads ``params.punet_path`` (key ``"model"``) exactly like the reference."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.return_inter = True if params.type == "punet_inter" else False
+        params.punet.inter_repr = self.return_inter
+        self.speed_encoder = B.make_mlp(**params.speed_encoder)
+        self.command_encoder = B.make_mlp(**params.command_encoder)
+        self.punet = PredictiveUnet(**params.punet)
+        punet_weights = torch.load(params.punet_path, map_location=params.device)
+        self.punet.load_state_dict(punet_weights["model"])
+        self.punet = freeze(self.punet)
+        self.backbone = None if self.return_inter else B.get_backbone(
+            **{**params.backbone.rgb, "n_frames": params.punet.future_frames, "n_channels": params.punet.num_classes})
+        self.speed_pred = B.make_mlp(**params.speed_prediction)
+        self.action_pred = B._Seq(B.make_mlp(**params.action_head), B.Linear(params.action_head.dims[-1], 2))
+
+    def _make_engine(self):
+        from ..engine_punet import PUNetEngine
+        return PUNetEngine(self)
+
+    def forward(self, images, speed, command):
+        """-> (actions [B,2] in (-1,1), pred_speed [B,1])."""
+        return self._run(images, speed, command)
+
+    def sample(self, images, speed, command):
+        return self.forward(images, speed, command)[0]
+
+
+class _BlendFn(torch.autograd.Function):
+    """``tanh(cat(lat_weights([moe_x, punet_x]), long_weights([moe_y, punet_y])))`` (moe.py:353-356)."""
+
+    @staticmethod
+    def forward(ctx, moe_act, pu_act, lat_w, lat_b, long_w, long_b):
+        Bsz = moe_act.shape[0]
+        moe_act, pu_act = moe_act.contiguous().float(), pu_act.contiguous().float()
+        out = torch.empty(Bsz, 2, dtype=torch.float32, device=moe_act.device)
+        ops.blend_fwd(moe_act, pu_act, lat_w.contiguous(), lat_b.contiguous(), long_w.contiguous(), long_b.contiguous(),
+                      out, Bsz)
+        ctx.save_for_backward(moe_act, pu_act, lat_w, long_w, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        moe_act, pu_act, lat_w, long_w, out = ctx.saved_tensors
+        Bsz = moe_act.shape[0]
+        dlw, dgw = torch.empty_like(lat_w), torch.empty_like(long_w)
+        dlb = torch.empty(1, dtype=torch.float32, device=out.device)
+        dgb = torch.empty(1, dtype=torch.float32, device=out.device)
+        dpu = torch.empty_like(pu_act) if ctx.needs_input_grad[1] else None
+        ops.blend_bwd(moe_act, pu_act, lat_w.contiguous(), long_w.contiguous(), out, dout.contiguous().float(),
+                      dlw, dlb, dgw, dgb, dpu, Bsz)
+        return None, dpu, dlw, dlb, dgw, dgb
+
+
+class PMoE(nn.Module):
+    """``moe.py:326-363``: frozen mixture of experts + PU-Net expert, blended per axis by two ``Linear(2,1)``.
+    ``forward`` returns ``(actions [B,2], -1)`` and is stochastic (``dists.sample()``), like the reference."""
+
+    def __init__(self, params):
+        super().__init__()
+        assert params.pmoe.moe_dir is not None, "MoE weights should be provided"
+        self.moe = MixtureOfExperts(params)
+        # SWA checkpoints carry extra keys, therefore strict=False (moe.py:336-337)
+        self.moe.load_state_dict(torch.load(params.pmoe.moe_dir, map_location="cpu"), strict=False)
+        self.moe = freeze(self.moe, params.exclude_freeze, params.verbose)
+        self.punet = PUNetExpert(params)
+        if params.pmoe.punet_dir:
+            self.punet.load_state_dict(torch.load(params.pmoe.punet_dir, map_location="cpu"), strict=False)
+            self.punet = freeze(self.punet, params.exclude_freeze, params.verbose)
+        self.lat_weights = B.Linear(2, 1)
+        self.long_weights = B.Linear(2, 1)
+
+    @property
+    def compute_dtype(self):
+        return self.moe.compute_dtype
+
+    @compute_dtype.setter
+    def compute_dtype(self, dtype):
+        self.moe.compute_dtype = dtype
+        self.punet.compute_dtype = dtype
+
+    def blend(self, moe_actions, punet_actions):
+        """the deterministic tail of ``forward`` (moe.py:353-356) on given per-model actions."""
+        return _BlendFn.apply(moe_actions, punet_actions, self.lat_weights.weight, self.lat_weights.bias,
+                              self.long_weights.weight, self.long_weights.bias)
+
+    def forward(self, images, speed, command):
+        punet_actions, _ = self.punet(images, speed, command)
+        dists, _ = self.moe(images, speed, command)
+        moe_actions = dists.sample()
+        # -1 is the reference's dummy speed prediction (interface consistency)
+        return self.blend(moe_actions, punet_actions), -1
+
+    def sample(self, images, speed, command):
+        return self.forward(images, speed, command)[0]
 
 
 class MixtureDistribution(D.MixtureSameFamily):

@@ -324,3 +324,73 @@ for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "conv2d", "conv
            "eca_bwd_small", "eca_bwd_apply", "eca_stem_fold", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",
            "moe_loss"):
     globals()[_n] = _timed(globals()[_n])
+
+
+# ---------------------------------------------------------------------------------------------- PU-Net / PMoE
+def maxpool2_fwd(x, y, c=None, x_coff=0):
+    """MaxPool2d(2,2) of the channel window [x_coff, x_coff+c) of ``x`` into dense ``y`` [N,H/2,W/2,c]."""
+    n, h, w_, ld = _nhwc(x, "x")
+    c = ld if c is None else c
+    if tuple(y.shape) != (n, h // 2, w_ // 2, c):
+        raise ValueError(f"maxpool2_fwd: y must be {(n, h // 2, w_ // 2, c)}, got {tuple(y.shape)}")
+    check(load().pmoe_maxpool2s2_fwd(ptr(x, "x"), ptr(y, "y", x.dtype), n, h, w_, c, ld, x_coff, dt(x), stream_ptr()),
+          "pmoe_maxpool2s2_fwd")
+
+
+def pixel_shuffle2(src, dst, c, dst_coff=0):
+    """src [N,H,W,>=4c] (channel (dy*2+dx)*c + k) -> dst[n, 2y+dy, 2x+dx, dst_coff + k]."""
+    n, h, w_, sld = _nhwc(src, "src")
+    n2, h2, w2, dld = _nhwc(dst, "dst")
+    if (n2, h2, w2) != (n, 2 * h, 2 * w_):
+        raise ValueError(f"pixel_shuffle2: dst must be [{n},{2 * h},{2 * w_},*], got {tuple(dst.shape)}")
+    check(load().pmoe_pixel_shuffle2(ptr(src, "src"), ptr(dst, "dst", src.dtype), n, h, w_, c, sld, dld, dst_coff, dt(src),
+                                     stream_ptr()), "pmoe_pixel_shuffle2")
+
+
+def copy_window(src, src_coff, dst, dst_coff, c):
+    """dst[..., dst_coff:dst_coff+c] = src[..., src_coff:src_coff+c] over all leading rows."""
+    rows = src.numel() // src.shape[-1]
+    if dst.numel() // dst.shape[-1] != rows:
+        raise ValueError("copy_window: row counts differ")
+    check(load().pmoe_copy_window(ptr(src, "src"), src.shape[-1], src_coff, ptr(dst, "dst", src.dtype), dst.shape[-1],
+                                  dst_coff, rows, c, dt(src), stream_ptr()), "pmoe_copy_window")
+
+
+def action_head_fwd(head, spd, actions, speeds, B):
+    f32 = torch.float32
+    check(load().pmoe_action_head_fwd(ptr(head, "head"), head.shape[-1], ptr(spd, "spd", head.dtype), spd.shape[-1],
+                                      ptr(actions, "actions", f32), ptr(speeds, "speeds", f32), B, dt(head), stream_ptr()),
+          "pmoe_action_head_fwd")
+
+
+def action_head_bwd(actions, dactions, dspeeds, dhead, dspd, B):
+    f32 = torch.float32
+    check(load().pmoe_action_head_bwd(ptr(actions, "actions", f32),
+                                      ptr(dactions, "dactions", f32) if dactions is not None else None,
+                                      ptr(dspeeds, "dspeeds", f32) if dspeeds is not None else None,
+                                      ptr(dhead, "dhead"), dhead.shape[-1], ptr(dspd, "dspd", dhead.dtype), dspd.shape[-1],
+                                      B, dt(dhead), stream_ptr()), "pmoe_action_head_bwd")
+
+
+def action_loss(actions, speeds, actions_gt, speed_gt, c0, c1, loss, dactions, dspeeds, B):
+    f32 = torch.float32
+    o = lambda t, n: ptr(t, n, f32) if t is not None else None   # noqa: E731
+    check(load().pmoe_action_loss(ptr(actions, "actions", f32), o(speeds, "speeds"), ptr(actions_gt, "actions_gt", f32),
+                                  o(speed_gt, "speed_gt"), float(c0), float(c1), ptr(loss, "loss", f32),
+                                  ptr(dactions, "dactions", f32), o(dspeeds, "dspeeds"), B, stream_ptr()), "pmoe_action_loss")
+
+
+def blend_fwd(moe_act, pu_act, lat_w, lat_b, long_w, long_b, out, B):
+    f32 = torch.float32
+    check(load().pmoe_blend_fwd(ptr(moe_act, "moe_actions", f32), ptr(pu_act, "punet_actions", f32), ptr(lat_w, "lat_w", f32),
+                                ptr(lat_b, "lat_b", f32), ptr(long_w, "long_w", f32), ptr(long_b, "long_b", f32),
+                                ptr(out, "out", f32), B, stream_ptr()), "pmoe_blend_fwd")
+
+
+def blend_bwd(moe_act, pu_act, lat_w, long_w, out, dout, dlat_w, dlat_b, dlong_w, dlong_b, dpu, B):
+    f32 = torch.float32
+    check(load().pmoe_blend_bwd(ptr(moe_act, "moe_actions", f32), ptr(pu_act, "punet_actions", f32), ptr(lat_w, "lat_w", f32),
+                                ptr(long_w, "long_w", f32), ptr(out, "out", f32), ptr(dout, "dout", f32),
+                                ptr(dlat_w, "dlat_w", f32), ptr(dlat_b, "dlat_b", f32), ptr(dlong_w, "dlong_w", f32),
+                                ptr(dlong_b, "dlong_b", f32), ptr(dpu, "dpunet", f32) if dpu is not None else None, B,
+                                stream_ptr()), "pmoe_blend_bwd")

@@ -49,17 +49,23 @@ def get_conf(name: str):
         return AttrDict.wrap(yaml.safe_load(f))
 
 
-def stage2_model_cfg(model_type="moe", n_experts=4, dropout=0.3, n_commands=6, n_frames=4):
-    """The ``model:`` node of ``conf/stage_2_moe.yaml:76-133`` (defaults as shipped by the reference)."""
+def stage2_model_cfg(model_type="moe", n_experts=4, dropout=0.3, n_commands=6, n_frames=4, future_frames=6,
+                     unet_path="", punet_path="", moe_dir="", punet_dir="", exclude_freeze=(), device="cpu"):
+    """The ``model:`` node of ``conf/stage_2_moe.yaml:76-133`` / ``stage_2_pmoe.yaml:76-133`` (defaults as shipped by
+    the reference; the checkpoint paths are the reference's ``punet.model_path``, ``punet_path``, ``pmoe.moe_dir`` and
+    ``pmoe.punet_dir``)."""
     def mlp(dims, act, l_act=False):
         return dict(dims=list(dims), act=act, l_act=l_act, bn=False, dropout=dropout)
 
     return AttrDict.wrap(dict(
-        verbose=False, type=model_type, n_experts=n_experts, loss_coefs=[0.7, 0.3], exclude_freeze=[],
+        verbose=False, type=model_type, n_experts=n_experts, loss_coefs=[0.7, 0.3], exclude_freeze=list(exclude_freeze),
+        device=device, punet_path=punet_path,
         action_head=mlp([1536, 512, 512], "elu", True),
         speed_encoder=mlp([1, 512, 512], "relu"),
         command_encoder=mlp([n_commands, 512, 512], "relu"),
         speed_prediction=mlp([1536, 512, 512, 1], "relu"),
         backbone=dict(type="rgb", n_frames=n_frames, rgb=dict(arch="resnet18", pretrained=False, gamma=2, b=1)),
-        pmoe=dict(moe_dir="", punet_dir=""),
+        punet=dict(past_frames=n_frames, future_frames=future_frames, in_features=3, num_classes=23, gamma=2, b=1,
+                   unet_inter_repr=False, model_name="unet", model_path=unet_path),
+        pmoe=dict(moe_dir=moe_dir, punet_dir=punet_dir),
     ))

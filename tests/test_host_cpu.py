@@ -26,6 +26,21 @@ def test_state_dict_keys_match_reference(golden_dir, name, typ, E):
     assert [tuple(v.shape) for v in sd.values()] == g["state_dict_shapes"]
 
 
+@pytest.mark.parametrize("name", ["p1_punet_b2_64_f2", "p3_punetinter_b2_64_f2", "p5_pmoe_e2_b2_64_f2"])
+def test_punet_state_dict_and_freeze_match_reference(golden_dir, tmp_path, name):
+    """PUNetExpert / PMoE containers: checkpoint files are read like the reference does (punet.py:40, moe.py:278,335),
+    key order, shapes and the requires_grad pattern after the constructor's freeze() calls."""
+    from tests.punet_util import build_product
+    g = _g(golden_dir, name)
+    m = build_product(tmp_path, g["meta"], exclude_freeze=["lat_weights", "long_weights"] if g["meta"]["type"] == "pmoe" else ())
+    sd = m.state_dict()
+    assert list(sd.keys()) == g["state_dict_keys"]
+    assert [tuple(v.shape) for v in sd.values()] == g["state_dict_shapes"]
+    assert {k: p.requires_grad for k, p in m.named_parameters()} == g["requires_grad"]
+    eng = (m.punet if g["meta"]["type"] == "pmoe" else m)._engine()
+    assert {id(p) for p in eng.flat_params} == {id(p) for p in (m.punet if g["meta"]["type"] == "pmoe" else m).parameters()}
+
+
 def test_mlp_layouts_match_reference(golden_dir):
     g = _g(golden_dir, "micro")
     for (bn, p, dims), keys in g["mlp_layouts"].items():
@@ -37,8 +52,10 @@ def test_mlp_layouts_match_reference(golden_dir):
 def test_get_model_errors_like_reference():
     with pytest.raises(ValueError, match="UNKNOWN"):
         get_model(AttrDict(type="nope"))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match="MoE pretrained"):
         get_model(stage2_model_cfg("pmoe", 4))
+    with pytest.raises(FileNotFoundError):
+        get_model(stage2_model_cfg("punet", 4, unet_path="/nonexistent/unet.pth"))
 
 
 def test_freeze_semantics():

@@ -481,6 +481,93 @@ def test_loss_golden_vectors():
         assert abs(got.item() - lc["loss"].item()) <= 1e-5 * max(1.0, abs(lc["loss"].item())), key
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_unet_pool_upconv_concat_kernels(dtype):
+    """MaxPool2d(2), ConvTranspose2d(k2,s2) = 1x1 GEMM + pixel shuffle into a concat window, channel-window copies."""
+    g = torch.Generator().manual_seed(11)
+    n, h, w_, cin, cout = 2, 6, 10, 32, 16
+    x = rnd((n, cin, h, w_), g, dtype)
+    # maxpool
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+    y = torch.empty(n, h // 2, w_ // 2, cin, dtype=dtype, device=DEV)
+    ops.maxpool2_fwd(xh, y)
+    close(y.permute(0, 3, 1, 2), F.max_pool2d(x, 2, 2), torch.float32, "maxpool2")
+    # transposed conv: weight [cin, cout, 2, 2]
+    wt = rnd((cin, cout, 2, 2), g, dtype) * 0.2
+    bias = rnd((cout,), g, torch.float32)
+    ref = F.conv_transpose2d(x, wt, bias, stride=2)
+    w1 = wt.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1).contiguous().to(DEV)
+    coutp = 64
+    wf = torch.empty(1, coutp, 1, cin, dtype=dtype, device=DEV)
+    ops.pack_conv_weights(hip.ptr_table([w1], DEV), wf, None, 1, 4 * cout, cin, 1, coutp, cin, 64, 64, dtype)
+    bp = torch.empty(1, coutp, device=DEV)
+    ops.pack_bias(hip.ptr_table([bias.repeat(4).contiguous().to(DEV)], DEV), bp, 1, 4 * cout, coutp)
+    t = torch.empty(n, h, w_, 4 * cout, dtype=dtype, device=DEV)
+    ops.conv2d(xh, wf, t, cin=cin, cout=4 * cout, coutp=coutp, ipe=n, ks=1, stride=1, pad=0, bias=bp)
+    skip = rnd((n, 2 * h, 2 * w_, cout), g, dtype).to(dtype).to(DEV)
+    cat = torch.zeros(n, 2 * h, 2 * w_, 2 * cout, dtype=dtype, device=DEV)
+    ops.copy_window(skip, 0, cat, 0, cout)
+    ops.pixel_shuffle2(t, cat, cout, dst_coff=cout)
+    assert torch.equal(cat[..., :cout], skip)
+    close(cat[..., cout:].permute(0, 3, 1, 2), ref, dtype, "conv_transpose2d")
+    # unaligned channel windows (23-class masks packed 4 x 23 -> 96)
+    m = rnd((n, h, w_, 32), g, dtype).to(dtype).to(DEV)
+    packed = torch.zeros(n, h, w_, 96, dtype=dtype, device=DEV)
+    for k in range(4):
+        ops.copy_window(m, 0, packed, 23 * k, 23)
+    for k in range(4):
+        assert torch.equal(packed[..., 23 * k:23 * k + 23], m[..., :23])
+    assert packed[..., 92:].abs().max() == 0
+
+
+def test_action_head_loss_and_blend_kernels():
+    """tanh action head, punet_loss / pmoe_loss (golden values of the imported reference) and the PMoE blend."""
+    from pathlib import Path
+    from pmoe_amd.loss import pmoe_loss, punet_loss
+    g = torch.Generator().manual_seed(5)
+    B = 19
+    head = torch.randn(B, 16, generator=g)
+    spd = torch.randn(B, 16, generator=g)
+    act = torch.rand(B, 2, generator=g) * 2 - 1
+    tgt = torch.rand(B, 1, generator=g)
+    hr, sr = head.clone().requires_grad_(True), spd.clone().requires_grad_(True)
+    a_ref, s_ref = torch.tanh(hr[:, :2]), sr[:, :1]
+    loss_ref = 0.7 * F.l1_loss(a_ref, act) + 0.3 * F.mse_loss(s_ref, tgt)
+    loss_ref.backward()
+    a = torch.empty(B, 2, device=DEV)
+    s = torch.empty(B, 1, device=DEV)
+    ops.action_head_fwd(head.to(DEV), spd.to(DEV), a, s, B)
+    close(a, a_ref.detach(), torch.float32, "actions")
+    a.requires_grad_(True); s.requires_grad_(True)
+    loss = punet_loss(a, s, act.to(DEV), tgt.to(DEV), [0.7, 0.3])
+    assert abs(loss.item() - loss_ref.item()) < 1e-6
+    loss.backward()
+    dhead, dspd = torch.full((B, 16), 3.0, device=DEV), torch.full((B, 16), 3.0, device=DEV)
+    ops.action_head_bwd(a.detach(), a.grad, s.grad, dhead, dspd, B)
+    close(dhead, hr.grad, torch.float32, "dhead")
+    close(dspd, sr.grad, torch.float32, "dspd")
+    mic = torch.load(Path(__file__).resolve().parent / "golden" / "micro.pt", weights_only=False)["action_loss_case"]
+    c = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in mic.items()}
+    assert abs(punet_loss(c["actions"], c["speeds"], c["act"], c["tgt"], [0.7, 0.3]).item() - mic["punet_loss"].item()) < 1e-6
+    assert abs(pmoe_loss(c["actions"], -1, c["act"], c["tgt"], [0.7, 0.3]).item() - mic["pmoe_loss"].item()) < 1e-6
+    # blend
+    from pmoe_amd.model.moe import _BlendFn
+    moe_a, pu_a = torch.randn(B, 2, generator=g), torch.tanh(torch.randn(B, 2, generator=g))
+    lw, lb = torch.randn(1, 2, generator=g), torch.randn(1, generator=g)
+    gw, gb = torch.randn(1, 2, generator=g), torch.randn(1, generator=g)
+    ps = [t.clone().requires_grad_(True) for t in (pu_a, lw, lb, gw, gb)]
+    lat = F.linear(torch.cat([moe_a[:, 0:1], ps[0][:, 0:1]], -1), ps[1], ps[2])
+    lon = F.linear(torch.cat([moe_a[:, 1:], ps[0][:, 1:]], -1), ps[3], ps[4])
+    out_ref = torch.tanh(torch.cat([lat, lon], -1))
+    F.l1_loss(out_ref, act).backward()
+    pd = [t.detach().to(DEV).requires_grad_(True) for t in (pu_a, lw, lb, gw, gb)]
+    out = _BlendFn.apply(moe_a.to(DEV), *pd)
+    close(out, out_ref.detach(), torch.float32, "blend")
+    F.l1_loss(out, act.to(DEV)).backward()
+    for got, ref, nm in zip(pd, ps, ("dpunet", "dlat_w", "dlat_b", "dlong_w", "dlong_b")):
+        close(got.grad, ref.grad, torch.float32, nm)
+
+
 def test_batchnorm_statistics_are_centred():
     """|mean| >> std (a near-constant channel): one-pass E[x^2]-mean^2 in f32 loses the variance; the centred sums
     (deviations from a sample of the channel) must reproduce the float64 statistics."""

@@ -111,3 +111,78 @@ def test_micro_cases(golden_dir):
     torch.testing.assert_close(O.moe_loss(dist, lc["speeds"], lc["act"], lc["tgt"], [0.7, 0.3]), lc["loss"])
     ls = g["loss_case_shared"]       # [B,1] speed prediction of MixtureOfExpertsShared (loss.py:129-130)
     torch.testing.assert_close(O.moe_loss(dist, ls["speeds"], ls["act"], ls["tgt"], [0.7, 0.3]), ls["loss"])
+
+
+PUNET_CASES = ["p1_punet_b2_64_f2", "p3_punetinter_b2_64_f2"]
+
+
+def _punet_oracle(g):
+    m = g["meta"]
+    cfg = O.stage2_cfg(m["type"], m["n_experts"], dropout=0.0, future_frames=m["future_frames"],
+                       exclude_freeze=["lat_weights", "long_weights"] if m["type"] == "pmoe" else [])
+    model = O.get_model(cfg)
+    W.fill_state_dict(model, seed=m["weight_seed"])
+    model.train(m["train"])
+    return cfg, model, W.make_inputs(m["batch"], m["size"], m["size"], seed=m["input_seed"])
+
+
+@pytest.mark.parametrize("name", PUNET_CASES + ["p2_punet_b1_64_f6_eval", "p4_punet_b3_96_f3", "p5_pmoe_e2_b2_64_f2"])
+def test_punet_state_dict_layout_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    _, model, _ = _punet_oracle(g)
+    sd = model.state_dict()
+    assert list(sd.keys()) == g["state_dict_keys"]
+    assert [tuple(v.shape) for v in sd.values()] == g["state_dict_shapes"]
+    assert {k: p.requires_grad for k, p in model.named_parameters()} == g["requires_grad"]
+
+
+@pytest.mark.parametrize("name", PUNET_CASES)
+def test_punet_train_matches_reference(golden_dir, name):
+    """PredictiveUnet / PUNetExpert restatement (punet.py:75-120, moe.py:268-323) vs the imported reference."""
+    g = _load(golden_dir, name)
+    cfg, model, inp = _punet_oracle(g)
+    a, s = model(inp["images"], inp["speed"], inp["command"])
+    loss = O.punet_loss(a, s, inp["control"], inp["target_speed"], cfg.loss_coefs)
+    loss.backward()
+    tol = dict(rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a, g["actions"], **tol)
+    torch.testing.assert_close(s, g["speeds"], **tol)
+    torch.testing.assert_close(loss.detach(), g["loss"], **tol)
+    named = dict(model.named_parameters())
+    for k, sl in g["grad_slices"].items():
+        torch.testing.assert_close(named[k].grad.flatten()[:64], sl, rtol=1e-4, atol=1e-6)
+    assert {k for k, p in named.items() if p.grad is not None} == set(g["grad_norms"])
+    sd = model.state_dict()
+    for k, v in g["bn_after_1"].items():
+        torch.testing.assert_close(sd[k], v, rtol=1e-5, atol=1e-6)
+
+
+def test_punet_eval_matches_reference(golden_dir):
+    g = _load(golden_dir, "p2_punet_b1_64_f6_eval")
+    _, model, inp = _punet_oracle(g)
+    with torch.no_grad():
+        a, s = model(inp["images"], inp["speed"], inp["command"])
+        masks = model.punet(inp["images"])[:, :, :, ::8, ::8]
+    torch.testing.assert_close(a, g["actions"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(s, g["speeds"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(masks, g["punet_masks_eval"], rtol=1e-4, atol=1e-5)
+
+
+def test_pmoe_matches_reference(golden_dir):
+    """PMoE (moe.py:326-363) under the reference's sampling seed: same draw, same blended actions, same gradients."""
+    g = _load(golden_dir, "p5_pmoe_e2_b2_64_f2")
+    cfg, model, inp = _punet_oracle(g)
+    torch.manual_seed(g["meta"]["sample_seed"])
+    actions, dummy = model(inp["images"], inp["speed"], inp["command"])
+    assert dummy == -1
+    loss = O.pmoe_loss(actions, dummy, inp["control"], inp["target_speed"], cfg.loss_coefs)
+    loss.backward()
+    torch.testing.assert_close(actions, g["actions"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss.detach(), g["loss"], rtol=1e-5, atol=1e-6)
+    named = dict(model.named_parameters())
+    for k, ref in g["grads_small"].items():
+        torch.testing.assert_close(named[k].grad, ref, rtol=1e-4, atol=1e-6)
+    assert {k for k, p in named.items() if p.grad is not None} == set(g["grad_norms"])
+    ac = _load(golden_dir, "micro")["action_loss_case"]
+    torch.testing.assert_close(O.punet_loss(ac["actions"], ac["speeds"], ac["act"], ac["tgt"], [0.7, 0.3]), ac["punet_loss"])
+    torch.testing.assert_close(O.pmoe_loss(ac["actions"], -1, ac["act"], ac["tgt"], [0.7, 0.3]), ac["pmoe_loss"])
