@@ -226,27 +226,46 @@ def main():
         if wg and wg["ms"] > 0:
             out["wgrad_tflops"] = round(wg["flop"] / (wg["ms"] * 1e-3) / 1e12, 2)
 
-    # ---- reference step recipe H1 (train_2.py:157-165): + clip_grad_norm_(1.0) + Adam(amsgrad)
+    # ---- reference step recipe H1 (train_2.py:157-165): + clip_grad_norm_(1.0) + grad-norm + Adam(amsgrad), with the
+    # fused optimizer tail (pmoe_amd.optim) and, for comparison, torch's own per-tensor kernels
     if rank == 0 or world > 1:
+        from pmoe_amd import optim as fused_optim
+
+        def time_h1(step_fn, label):
+            step_fn()
+            fence()
+            t0 = time.perf_counter()
+            n_h1 = max(2, min(5, args.steps))
+            for _ in range(n_h1):
+                step_fn()
+            fence()
+            return {"ms_per_step": round((time.perf_counter() - t0) / n_h1 * 1e3, 3), "what": label}
+
+        fopt = fused_optim.FusedAdam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
+
+        def h1_fused():
+            d, s = model(images, speed, command)
+            loss = moe_loss(d, s, control, target, coefs)
+            fopt.zero_grad()
+            loss.backward()
+            gn = fused_optim.clip_grad_norm_(model.parameters(), 1.0, scale=False)
+            fopt.step(clip=gn)
+        log("kernel profile done; H1 step (fused optimizer tail)")
+        out["h1_step"] = time_h1(h1_fused, "fwd+moe_loss+bwd+clip_grad_norm_(1.0)+Adam(amsgrad), fused multi-tensor HIP "
+                                           "optimizer tail (pmoe_amd.optim)")
+        del fopt
         opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
 
-        def h1():
+        def h1_torch():
             d, s = model(images, speed, command)
             loss = moe_loss(d, s, control, target, coefs)
             opt.zero_grad()
             loss.backward()
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
             opt.step()
-        log("kernel profile done; H1 step")
-        h1()
-        fence()
-        t0 = time.perf_counter()
-        n_h1 = max(2, min(5, args.steps))
-        for _ in range(n_h1):
-            h1()
-        fence()
-        out["h1_step"] = {"ms_per_step": round((time.perf_counter() - t0) / n_h1 * 1e3, 3),
-                          "what": "fwd+moe_loss+bwd+clip_grad_norm_(1.0)+Adam(amsgrad) (torch optimizer kernels)"}
+        log("H1 step (torch optimizer kernels)")
+        out["h1_step_torch_optim"] = time_h1(h1_torch, "same step with torch.nn.utils.clip_grad_norm_ + torch.optim.Adam")
+        del opt
 
     log("H1 done; CPU baseline")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -42,7 +42,7 @@ int pmoe_version(void);
 const char* pmoe_error_string(int code);
 /* sizeof() of the descriptor structs as compiled (which: 0 = pmoe_conv_desc, 1 = pmoe_wgrad_desc);
  * lets a foreign-language binding verify its struct layout without launching anything */
-int pmoe_abi_sizeof(int which);
+int pmoe_abi_sizeof(int which); /* 0: pmoe_conv_desc, 1: pmoe_wgrad_desc, 2: pmoe_opt_tensor */
 
 /* ---- convolution / grouped GEMM -------------------------------------------------------------
  * Replaces nn.Conv2d in model/blocks/basics.py:93-100,113-120 (stem), the torchvision ResNet body
@@ -259,6 +259,36 @@ int pmoe_blend_fwd(const float* moe_actions, const float* punet_actions, const f
 int pmoe_blend_bwd(const float* moe_actions, const float* punet_actions, const float* lat_w, const float* long_w,
                    const float* out, const float* dout, float* dlat_w, float* dlat_b, float* dlong_w, float* dlong_b,
                    float* dpunet, int32_t B, void* stream);
+
+/* ---- fused optimizer tail of the stage-2 step (reference caller trainer/train_2.py:157-165,184 + conf
+ * stage_2_pmoe.yaml:11,137-144): torch.nn.utils.clip_grad_norm_, torch.optim.Adam(amsgrad=True).step() and
+ * torch.optim.swa_utils.AveragedModel.update_parameters, each as ONE launch over a chunk table instead of a few
+ * launches (and a host sync) per parameter tensor.  `table` is a device array of pmoe_opt_tensor (all f32);
+ * workgroup i handles elements [chunk_index[i]*PMOE_OPT_CHUNK, +PMOE_OPT_CHUNK) of tensor chunk_tensor[i]. */
+#define PMOE_OPT_CHUNK 16384
+typedef struct pmoe_opt_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* max_exp_avg_sq; /* amsgrad only */
+    float* swa;            /* averaged copy (pmoe_mt_swa_update only) */
+    int64_t numel;
+    float bc1;             /* 1 - beta1^step of THIS tensor */
+    float bc2_sqrt;        /* sqrt(1 - beta2^step) */
+} pmoe_opt_tensor;
+/* norm[0] = global L2 norm of all gradients, norm[1] = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: 1);
+ * scale_grads != 0 also multiplies the gradients by norm[1] in place (= clip_grad_norm_).  partial: n_chunks floats. */
+int pmoe_mt_grad_norm(const pmoe_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index,
+                      int32_t n_chunks, float max_norm, float* partial, float* norm, int32_t scale_grads, void* stream);
+/* Adam / AMSGrad update (torch/optim/adam.py single-tensor formulas); norm != NULL applies the clip coefficient
+ * norm[1] to the gradient on the fly (clip + step fused: the gradients themselves stay unscaled). */
+int pmoe_mt_adam(const pmoe_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index, int32_t n_chunks,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int32_t amsgrad, const float* norm,
+                 void* stream);
+/* swa = param (n_averaged == 0) or swa + (param - swa) / (n_averaged + 1) */
+int pmoe_mt_swa_update(const pmoe_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index,
+                       int32_t n_chunks, int64_t n_averaged, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,8 @@ extern "C" {
 int pmoe_version(void) { return 100; }
 
 int pmoe_abi_sizeof(int which) {
-    return which == 0 ? (int)sizeof(pmoe_conv_desc) : which == 1 ? (int)sizeof(pmoe_wgrad_desc) : PMOE_ERR_ARG;
+    return which == 0 ? (int)sizeof(pmoe_conv_desc) : which == 1 ? (int)sizeof(pmoe_wgrad_desc)
+           : which == 2 ? (int)sizeof(pmoe_opt_tensor) : PMOE_ERR_ARG;
 }
 
 const char* pmoe_error_string(int code) {

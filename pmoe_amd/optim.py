@@ -1,0 +1,189 @@
+"""Fused optimizer tail of the stage-2 step -- drop-ins for the three torch calls of the
+reference trainer (``trainer/train_2.py:157-165,184``; hyper-parameters ``conf/stage_2_pmoe.yaml:11,137-144``):
+
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)   ->  pmoe_amd.optim.clip_grad_norm_
+    torch.optim.Adam(params, lr, betas, eps, wd, amsgrad=True) ->  pmoe_amd.optim.FusedAdam   (same constructor)
+    torch.optim.swa_utils.AveragedModel(model)                 ->  pmoe_amd.optim.FusedAveragedModel
+
+Each call is one or two HIP launches over a chunk table (``csrc/optim.hip``) instead of several launches -- and, in
+``check_grad_norm`` (utils/nn.py:10-19), one ``.item()`` host sync -- per parameter tensor (620 for E=4).  The
+returned gradient norm is a device tensor; nothing here synchronises with the host.  ``FusedAdam.step(clip=norm)``
+consumes the clip coefficient straight from device memory, so clip + step is: 2 launches for the norm, 1 for Adam.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+from .hip import check, load, stream_ptr
+
+CHUNK = 16384                      # PMOE_OPT_CHUNK (include/pmoe_hip.h)
+F32 = torch.float32
+
+
+class OptTensor(C.Structure):      # pmoe_opt_tensor
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("max_exp_avg_sq", C.c_void_p), ("swa", C.c_void_p), ("numel", C.c_int64), ("bc1", C.c_float),
+                ("bc2_sqrt", C.c_float)]
+
+
+_ROW = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("max_exp_avg_sq", "<u8"),
+                 ("swa", "<u8"), ("numel", "<i8"), ("bc1", "<f4"), ("bc2_sqrt", "<f4")])
+assert _ROW.itemsize == C.sizeof(OptTensor) == 64
+
+
+def _f32_cuda(t, what):
+    if not t.is_cuda or t.dtype != F32 or not t.is_contiguous():
+        raise RuntimeError(f"pmoe_amd.optim: {what} must be a contiguous float32 tensor on the MI355X (cuda) device; "
+                           f"got {t.dtype} on {t.device} (there is no CPU path)")
+    return t.data_ptr()
+
+
+class _Table:
+    """Device copy of a pmoe_opt_tensor array + its chunk lists (the chunk lists are cached per shape signature)."""
+
+    _chunk_cache = {}
+
+    def __init__(self, rows, device):
+        self.n = len(rows)
+        raw = torch.from_numpy(rows.view(np.uint8).reshape(-1))
+        self.table = raw.to(device, non_blocking=False)
+        key = (str(device), tuple(int(r) for r in rows["numel"]))
+        cached = _Table._chunk_cache.get(key)
+        if cached is None:
+            ct, ci = [], []
+            for t, n in enumerate(rows["numel"]):
+                k = (int(n) + CHUNK - 1) // CHUNK
+                ct.extend([t] * k)
+                ci.extend(range(k))
+            cached = (torch.tensor(ct, dtype=torch.int32, device=device), torch.tensor(ci, dtype=torch.int32, device=device))
+            if len(_Table._chunk_cache) > 16:
+                _Table._chunk_cache.clear()
+            _Table._chunk_cache[key] = cached
+        self.chunk_tensor, self.chunk_index = cached
+        self.n_chunks = int(self.chunk_tensor.numel())
+
+    def args(self):
+        return (C.c_void_p(self.table.data_ptr()), C.c_void_p(self.chunk_tensor.data_ptr()),
+                C.c_void_p(self.chunk_index.data_ptr()), self.n_chunks)
+
+
+def _rows(n):
+    return np.zeros(n, dtype=_ROW)
+
+
+def _grad_table(params):
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return None, ps
+    rows = _rows(len(ps))
+    for i, p in enumerate(ps):
+        rows["grad"][i] = _f32_cuda(p.grad, "gradient")
+        rows["numel"][i] = p.numel()
+    return _Table(rows, ps[0].device), ps
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0, scale=True):
+    """``torch.nn.utils.clip_grad_norm_`` (L2 only): returns the total norm as a 0-d DEVICE tensor and scales the
+    gradients in place by ``min(1, max_norm / (norm + 1e-6))``.  ``scale=False`` only measures (the reference's
+    ``check_grad_norm``, utils/nn.py:10-19, without its per-tensor ``.item()`` syncs); the returned tensor carries
+    ``.clip_state`` for ``FusedAdam.step(clip=...)``."""
+    if float(norm_type) != 2.0:
+        raise NotImplementedError("pmoe_amd.optim.clip_grad_norm_: only the L2 norm (the reference's default) is fused")
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    tab, ps = _grad_table(list(parameters))
+    if tab is None:
+        return torch.zeros((), dtype=F32, device="cuda")
+    dev = ps[0].device
+    partial = torch.empty(tab.n_chunks, dtype=F32, device=dev)
+    norm = torch.empty(2, dtype=F32, device=dev)
+    check(load().pmoe_mt_grad_norm(*tab.args(), float(max_norm), C.c_void_p(partial.data_ptr()), C.c_void_p(norm.data_ptr()),
+                                   int(bool(scale)), stream_ptr()), "pmoe_mt_grad_norm")
+    if scale:
+        torch.autograd.graph.increment_version([p.grad for p in ps])
+    total = norm[0]
+    total.clip_state = norm
+    return total
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` semantics (same arguments, same per-parameter ``state`` keys ``step`` / ``exp_avg`` /
+    ``exp_avg_sq`` / ``max_exp_avg_sq``, so ``state_dict()`` checkpoints interchange with the reference's optimizer,
+    train_2.py:300-310), updated by one multi-tensor HIP launch per parameter group."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("FusedAdam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+
+    @torch.no_grad()
+    def step(self, closure=None, clip=None):
+        """``clip``: the tensor returned by ``clip_grad_norm_(..., scale=False)`` -- its coefficient is applied to the
+        gradients inside the update kernel (gradients stay unscaled in memory)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        clip_state = getattr(clip, "clip_state", None) if clip is not None else None
+        if clip is not None and clip_state is None:
+            raise ValueError("FusedAdam.step(clip=...): pass the tensor returned by pmoe_amd.optim.clip_grad_norm_")
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            b1, b2 = group["betas"]
+            rows = _rows(len(ps))
+            for i, p in enumerate(ps):
+                if p.grad.is_sparse:
+                    raise RuntimeError("FusedAdam does not support sparse gradients")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0, dtype=F32)      # torch keeps `step` as a CPU f32 scalar tensor
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if group["amsgrad"]:
+                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                k = float(st["step"])
+                rows["param"][i] = _f32_cuda(p, "parameter")
+                rows["grad"][i] = _f32_cuda(p.grad, "gradient")
+                rows["exp_avg"][i] = _f32_cuda(st["exp_avg"], "exp_avg")
+                rows["exp_avg_sq"][i] = _f32_cuda(st["exp_avg_sq"], "exp_avg_sq")
+                if group["amsgrad"]:
+                    rows["max_exp_avg_sq"][i] = _f32_cuda(st["max_exp_avg_sq"], "max_exp_avg_sq")
+                rows["numel"][i] = p.numel()
+                rows["bc1"][i] = 1.0 - b1 ** k
+                rows["bc2_sqrt"][i] = (1.0 - b2 ** k) ** 0.5
+            tab = _Table(rows, ps[0].device)
+            check(load().pmoe_mt_adam(*tab.args(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                      float(group["weight_decay"]), int(bool(group["amsgrad"])),
+                                      C.c_void_p(clip_state.data_ptr()) if clip_state is not None else None, stream_ptr()),
+                  "pmoe_mt_adam")
+            # the kernel wrote through raw pointers: tell autograd (and the engine's packed-weight cache, which keys
+            # on the version counters) that these tensors changed in place
+            torch.autograd.graph.increment_version(ps)
+        return loss
+
+
+class FusedAveragedModel(torch.optim.swa_utils.AveragedModel):
+    """``AveragedModel(model)`` (train_2.py:120,184) whose ``update_parameters`` is one multi-tensor launch."""
+
+    @torch.no_grad()
+    def update_parameters(self, model):
+        mine, theirs = list(self.module.parameters()), list(model.parameters())
+        if len(mine) != len(theirs):
+            raise ValueError("FusedAveragedModel: parameter lists differ")
+        rows = _rows(len(mine))
+        for i, (a, p) in enumerate(zip(mine, theirs)):
+            if a.shape != p.shape:
+                raise ValueError("FusedAveragedModel: parameter shapes differ")
+            rows["param"][i] = _f32_cuda(p.detach(), "parameter")
+            rows["swa"][i] = _f32_cuda(a.detach(), "averaged parameter")
+            rows["numel"][i] = p.numel()
+        tab = _Table(rows, mine[0].device)
+        n = int(self.n_averaged.item())
+        check(load().pmoe_mt_swa_update(*tab.args(), n, stream_ptr()), "pmoe_mt_swa_update")
+        torch.autograd.graph.increment_version(mine)
+        self.n_averaged += 1

@@ -50,6 +50,9 @@ def test_struct_layouts_match_c(lib):
     assert ctypes.sizeof(hip.ConvDesc) == 160 == lib.pmoe_abi_sizeof(0)
     assert ctypes.sizeof(hip.WgradDesc) == lib.pmoe_abi_sizeof(1)
     assert ctypes.sizeof(hip.WgradDesc) == 3 * 8 + 19 * 4 + 4  # padded to 8
+    from pmoe_amd import optim
+    assert ctypes.sizeof(optim.OptTensor) == 64 == lib.pmoe_abi_sizeof(2)
+    assert optim.CHUNK == 16384          # PMOE_OPT_CHUNK
 
 
 def test_no_cpu_fallback(lib):
