@@ -282,10 +282,12 @@ typedef struct pmoe_opt_tensor {
 int pmoe_mt_grad_norm(const pmoe_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index,
                       int32_t n_chunks, float max_norm, float* partial, float* norm, int32_t scale_grads, void* stream);
 /* Adam / AMSGrad update (torch/optim/adam.py single-tensor formulas); norm != NULL applies the clip coefficient
- * norm[1] to the gradient on the fly (clip + step fused: the gradients themselves stay unscaled). */
+ * norm[1] to the gradient on the fly (clip + step fused: the gradients themselves stay unscaled).
+ * bc1_all / bc2_sqrt_all > 0: bias corrections shared by all tensors (every tensor at the same step, the usual case;
+ * the cached table is then reused unchanged step after step); <= 0: the per-tensor bc1 / bc2_sqrt of the table. */
 int pmoe_mt_adam(const pmoe_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index, int32_t n_chunks,
-                 float lr, float beta1, float beta2, float eps, float weight_decay, int32_t amsgrad, const float* norm,
-                 void* stream);
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int32_t amsgrad, float bc1_all,
+                 float bc2_sqrt_all, const float* norm, void* stream);
 /* swa = param (n_averaged == 0) or swa + (param - swa) / (n_averaged + 1) */
 int pmoe_mt_swa_update(const pmoe_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index,
                        int32_t n_chunks, int64_t n_averaged, void* stream);

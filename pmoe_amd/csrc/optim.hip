@@ -88,13 +88,15 @@ __global__ void __launch_bounds__(256) mt_adam_kernel(const pmoe_opt_tensor* __r
                                                      const int32_t* __restrict__ chunk_tensor,
                                                      const int32_t* __restrict__ chunk_index, float lr, float beta1,
                                                      float beta2, float eps, float weight_decay, int amsgrad,
-                                                     const float* __restrict__ norm) {
+                                                     float bc1_all, float bc2s_all, const float* __restrict__ norm) {
     const pmoe_opt_tensor t = tab[chunk_tensor[blockIdx.x]];
     const long long base = (long long)chunk_index[blockIdx.x] * CHUNK;
     long long n = t.numel - base;
     if (n > CHUNK) n = CHUNK;
     const float clip = norm ? norm[1] : 1.f;
-    const float step_size = lr / t.bc1, inv_bc2s = 1.f / t.bc2_sqrt;
+    // bias corrections: one value for all tensors (kernel argument, > 0) or the per-tensor entries of the table
+    const float step_size = lr / (bc1_all > 0.f ? bc1_all : t.bc1);
+    const float inv_bc2s = 1.f / (bc2s_all > 0.f ? bc2s_all : t.bc2_sqrt);
     float* p = t.param + base;
     const float* g = t.grad + base;
     float* m = t.exp_avg + base;
@@ -175,11 +177,11 @@ int pmoe_mt_grad_norm(const pmoe_opt_tensor* table, const int32_t* chunk_tensor,
 }
 
 int pmoe_mt_adam(const pmoe_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index, int32_t n_chunks,
-                 float lr, float beta1, float beta2, float eps, float weight_decay, int32_t amsgrad, const float* norm,
-                 void* stream) {
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int32_t amsgrad, float bc1_all,
+                 float bc2_sqrt_all, const float* norm, void* stream) {
     if (n_chunks < 1 || !table) return PMOE_ERR_ARG;
     hipLaunchKernelGGL(mt_adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor, chunk_index,
-                       lr, beta1, beta2, eps, weight_decay, amsgrad, norm);
+                       lr, beta1, beta2, eps, weight_decay, amsgrad, bc1_all, bc2_sqrt_all, norm);
     return (int)hipGetLastError();
 }
 

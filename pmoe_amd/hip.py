@@ -99,7 +99,7 @@ SIGNATURES = {
     "pmoe_blend_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P],
     "pmoe_blend_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "pmoe_mt_grad_norm": [_P, _P, _P, _I, _F, _P, _P, _I, _P],
-    "pmoe_mt_adam": [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P, _P],
+    "pmoe_mt_adam": [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P],
     "pmoe_mt_swa_update": [_P, _P, _P, _I, _L, _P],
 }
 _RESTYPES = {"pmoe_error_string": C.c_char_p}

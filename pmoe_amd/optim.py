@@ -41,28 +41,35 @@ def _f32_cuda(t, what):
 
 
 class _Table:
-    """Device copy of a pmoe_opt_tensor array + its chunk lists (the chunk lists are cached per shape signature)."""
+    """Device copy of a pmoe_opt_tensor array + its chunk lists.  Tables are cached on the tuple of raw pointers they
+    hold (parameter / state storage is stable, and torch's caching allocator hands the gradient arena back at the same
+    address step after step), so the steady state uploads nothing; a new table goes up through pinned memory without
+    blocking the host."""
 
-    _chunk_cache = {}
+    _cache = {}
+
+    @classmethod
+    def get(cls, key, device, build_rows):
+        tab = cls._cache.get(key)
+        if tab is None:
+            if len(cls._cache) > 8:
+                cls._cache.clear()
+            tab = cls._cache[key] = cls(build_rows(), device)
+        return tab
 
     def __init__(self, rows, device):
         self.n = len(rows)
-        raw = torch.from_numpy(rows.view(np.uint8).reshape(-1))
-        self.table = raw.to(device, non_blocking=False)
-        key = (str(device), tuple(int(r) for r in rows["numel"]))
-        cached = _Table._chunk_cache.get(key)
-        if cached is None:
-            ct, ci = [], []
-            for t, n in enumerate(rows["numel"]):
-                k = (int(n) + CHUNK - 1) // CHUNK
-                ct.extend([t] * k)
-                ci.extend(range(k))
-            cached = (torch.tensor(ct, dtype=torch.int32, device=device), torch.tensor(ci, dtype=torch.int32, device=device))
-            if len(_Table._chunk_cache) > 16:
-                _Table._chunk_cache.clear()
-            _Table._chunk_cache[key] = cached
-        self.chunk_tensor, self.chunk_index = cached
-        self.n_chunks = int(self.chunk_tensor.numel())
+        self.host = torch.from_numpy(rows.view(np.uint8).reshape(-1).copy()).pin_memory()     # kept alive with the table
+        self.table = self.host.to(device, non_blocking=True)
+        ct, ci = [], []
+        for t, n in enumerate(rows["numel"]):
+            k = (int(n) + CHUNK - 1) // CHUNK
+            ct.extend([t] * k)
+            ci.extend(range(k))
+        self._chunks_host = torch.tensor([ct, ci], dtype=torch.int32).pin_memory()
+        chunks = self._chunks_host.to(device, non_blocking=True)
+        self.chunk_tensor, self.chunk_index = chunks[0], chunks[1]
+        self.n_chunks = len(ct)
 
     def args(self):
         return (C.c_void_p(self.table.data_ptr()), C.c_void_p(self.chunk_tensor.data_ptr()),
@@ -77,11 +84,14 @@ def _grad_table(params):
     ps = [p for p in params if p.grad is not None]
     if not ps:
         return None, ps
-    rows = _rows(len(ps))
-    for i, p in enumerate(ps):
-        rows["grad"][i] = _f32_cuda(p.grad, "gradient")
-        rows["numel"][i] = p.numel()
-    return _Table(rows, ps[0].device), ps
+    ptrs = tuple(_f32_cuda(p.grad, "gradient") for p in ps)
+
+    def build():
+        rows = _rows(len(ps))
+        rows["grad"] = ptrs
+        rows["numel"] = [p.numel() for p in ps]
+        return rows
+    return _Table.get(("g",) + ptrs, ps[0].device, build), ps
 
 
 def clip_grad_norm_(parameters, max_norm, norm_type=2.0, scale=True):
@@ -134,31 +144,41 @@ class FusedAdam(torch.optim.Optimizer):
             if not ps:
                 continue
             b1, b2 = group["betas"]
-            rows = _rows(len(ps))
-            for i, p in enumerate(ps):
+            ams = bool(group["amsgrad"])
+            keys = ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if ams else ())
+            steps = []
+            for p in ps:
                 if p.grad.is_sparse:
                     raise RuntimeError("FusedAdam does not support sparse gradients")
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.tensor(0.0, dtype=F32)      # torch keeps `step` as a CPU f32 scalar tensor
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    if group["amsgrad"]:
-                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    for k in keys:
+                        st[k] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                k = float(st["step"])
-                rows["param"][i] = _f32_cuda(p, "parameter")
-                rows["grad"][i] = _f32_cuda(p.grad, "gradient")
-                rows["exp_avg"][i] = _f32_cuda(st["exp_avg"], "exp_avg")
-                rows["exp_avg_sq"][i] = _f32_cuda(st["exp_avg_sq"], "exp_avg_sq")
-                if group["amsgrad"]:
-                    rows["max_exp_avg_sq"][i] = _f32_cuda(st["max_exp_avg_sq"], "max_exp_avg_sq")
-                rows["numel"][i] = p.numel()
-                rows["bc1"][i] = 1.0 - b1 ** k
-                rows["bc2_sqrt"][i] = (1.0 - b2 ** k) ** 0.5
-            tab = _Table(rows, ps[0].device)
+                steps.append(float(st["step"]))
+            cols = {"param": tuple(_f32_cuda(p, "parameter") for p in ps),
+                    "grad": tuple(_f32_cuda(p.grad, "gradient") for p in ps)}
+            for k in keys:
+                cols[k] = tuple(_f32_cuda(self.state[p][k], k) for p in ps)
+            uniform = min(steps) == max(steps)
+
+            def build():
+                rows = _rows(len(ps))
+                for k, v in cols.items():
+                    rows[k] = v
+                rows["numel"] = [p.numel() for p in ps]
+                rows["bc1"] = [1.0 - b1 ** k for k in steps]
+                rows["bc2_sqrt"] = [(1.0 - b2 ** k) ** 0.5 for k in steps]
+                return rows
+            key = ("a",) + tuple(v for c in cols.values() for v in c) + (() if uniform else tuple(steps))
+            tab = _Table.get(key, ps[0].device, build)
+            # all tensors at the same step (the normal case): bias corrections travel as kernel arguments and the cached
+            # table is reused; otherwise the per-tensor values of a freshly built table are used (argument < 0)
+            bc1 = 1.0 - b1 ** steps[0] if uniform else -1.0
+            bc2s = (1.0 - b2 ** steps[0]) ** 0.5 if uniform else -1.0
             check(load().pmoe_mt_adam(*tab.args(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                      float(group["weight_decay"]), int(bool(group["amsgrad"])),
+                                      float(group["weight_decay"]), int(ams), float(bc1), float(bc2s),
                                       C.c_void_p(clip_state.data_ptr()) if clip_state is not None else None, stream_ptr()),
                   "pmoe_mt_adam")
             # the kernel wrote through raw pointers: tell autograd (and the engine's packed-weight cache, which keys
@@ -175,14 +195,18 @@ class FusedAveragedModel(torch.optim.swa_utils.AveragedModel):
         mine, theirs = list(self.module.parameters()), list(model.parameters())
         if len(mine) != len(theirs):
             raise ValueError("FusedAveragedModel: parameter lists differ")
-        rows = _rows(len(mine))
-        for i, (a, p) in enumerate(zip(mine, theirs)):
+        for a, p in zip(mine, theirs):
             if a.shape != p.shape:
                 raise ValueError("FusedAveragedModel: parameter shapes differ")
-            rows["param"][i] = _f32_cuda(p.detach(), "parameter")
-            rows["swa"][i] = _f32_cuda(a.detach(), "averaged parameter")
-            rows["numel"][i] = p.numel()
-        tab = _Table(rows, mine[0].device)
+        pp = tuple(_f32_cuda(p.detach(), "parameter") for p in theirs)
+        aa = tuple(_f32_cuda(a.detach(), "averaged parameter") for a in mine)
+
+        def build():
+            rows = _rows(len(mine))
+            rows["param"], rows["swa"] = pp, aa
+            rows["numel"] = [p.numel() for p in theirs]
+            return rows
+        tab = _Table.get(("s",) + pp + aa, mine[0].device, build)
         n = int(self.n_averaged.item())
         check(load().pmoe_mt_swa_update(*tab.args(), n, stream_ptr()), "pmoe_mt_swa_update")
         torch.autograd.graph.increment_version(mine)
