@@ -191,13 +191,15 @@ def main():
             agg = {}
             for name, meta, ms_k in recs:
                 key = (name, meta.get("name", ""))
-                a = agg.setdefault(key, [0.0, 0, 0.0])
+                a = agg.setdefault(key, [0.0, 0, 0.0, 0.0])
                 a[0] += ms_k
                 a[1] += 1
                 a[2] += meta.get("flop", 0.0)
-            for (name, lname), (ms_k, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+                a[3] += meta.get("bytes", 0.0)
+            for (name, lname), (ms_k, n, fl, nb) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:120]:
                 tf = fl / (ms_k * 1e-3) / 1e12 if ms_k > 0 and fl else 0.0
-                print(f"  {name:18s} {lname:24s} n={n:3d} {ms_k:8.3f} ms  {tf:8.1f} TF/s", file=sys.stderr)
+                tb = f"{nb / (ms_k * 1e-3) / 1e12:6.2f} TB/s" if ms_k > 0 and nb else ""
+                print(f"  {name:18s} {lname:24s} n={n:3d} {ms_k:8.3f} ms  {tf:8.1f} TF/s {tb}", file=sys.stderr)
         by = {}
         for name, meta, ms_k in recs:
             k = by.setdefault(name, {"ms": 0.0, "n": 0, "flop": 0.0, "bytes": 0.0})

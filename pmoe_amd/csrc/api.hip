@@ -14,6 +14,8 @@ static ConvArgs to_args(const pmoe_conv_desc* d) {
     a.act = d->act; a.res_mode = d->res ? d->res_mode : PMOE_RES_NONE;
     a.drop_p = d->drop_p; a.seed = d->seed;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = 0;
+    a.kh = a.kw = d->ks; a.use_tapmap = 0; a.tapmap[0] = a.tapmap[1] = a.tapmap[2] = a.tapmap[3] = 0;
+    a.out_step = 1; a.out_offy = a.out_offx = 0; a.OH = d->ho; a.OW = d->wo;
     return a;
 }
 

@@ -57,9 +57,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     const int lTW = a.lTW, lTH = a.lTH;
     const int TW = 1 << lTW, TH = 1 << lTH;
     // a strided 1x1 conv stages only the pixels it uses: LDS pixel stride 1, source step = stride
-    const int KS = a.ks, TAPS = KS * KS;
+    const int KS = a.ks, TAPS = KS * KS;           // TAPS = tap stride of the packed weights
+    const int KH = a.kh, KW = a.kw, NTAP = KH * KW; // taps actually visited (a sub-window for the parity classes)
     const int S = KS == 1 ? 1 : a.stride, step = KS == 1 ? a.stride : 1;
-    const int PW = (TW - 1) * S + KS, PH = (TH - 1) * S + KS;
+    const int PW = (TW - 1) * S + KW, PH = (TH - 1) * S + KH;
     const int NPIX = a.TN * PH * PW;
     const int n0 = e * a.ipe + ng * a.TN, n_end = (e + 1) * a.ipe;
     const int oy0 = py * TH, ox0 = px * TW;
@@ -133,19 +134,20 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
 
     const int nchunks = a.Cin / CK;
     int cur = 0;
-    w_issue(0, 0);
+    auto wtap = [&](int i) { return a.use_tapmap ? a.tapmap[i] : i; };
+    w_issue(0, wtap(0));
     w_commit(0);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
         load_patch(c0);
         __syncthreads();
-        for (int r = 0; r < KS; ++r) {
-            for (int q = 0; q < KS; ++q) {
-                const int tap = r * KS + q;
-                const bool last = (ch == nchunks - 1) && (tap == TAPS - 1);
+        for (int r = 0; r < KH; ++r) {
+            for (int q = 0; q < KW; ++q) {
+                const int tap = r * KW + q;
+                const bool last = (ch == nchunks - 1) && (tap == NTAP - 1);
                 int ntap = tap + 1, nc0 = c0;
-                if (ntap == TAPS) { ntap = 0; nc0 += CK; }
-                if (!last) w_issue(nc0, ntap);
+                if (ntap == NTAP) { ntap = 0; nc0 += CK; }
+                if (!last) w_issue(nc0, wtap(ntap));
                 const char* wb = wbuf + cur * (BN * RB);
                 const int tapoff = r * PW + q;
                 int pp[2], fp[2];
@@ -223,7 +225,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
             for (int i = 0; i < 4; ++i) v[4 * k + i] = tt[i];
         }
         if (ok) {
-            const size_t opix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+            const size_t opix = ((size_t)n * a.OH + oy * a.out_step + a.out_offy) * a.OW + ox * a.out_step + a.out_offx;
 #pragma unroll
             for (int i = 0; i < VE; ++i) v[i] += bias[i];
             if (a.res_mode) {
@@ -332,7 +334,7 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         const int TN = BM >> (lTW + lTH);
         const int TW = 1 << lTW, TH = 1 << lTH;
         const int lstride = a.ks == 1 ? 1 : a.stride;
-        const int PW = (TW - 1) * lstride + a.ks, PH = (TH - 1) * lstride + a.ks;
+        const int PW = (TW - 1) * lstride + a.kw, PH = (TH - 1) * lstride + a.kh;
         size_t smem = (((size_t)TN * PH * PW * rb + 255) & ~(size_t)255) + 2 * (size_t)BN * rb;
         const size_t stg = (size_t)BM * BN * 4;
         if (smem < stg) smem = stg;
@@ -358,7 +360,34 @@ struct ResPlan {
 bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan);
 int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st);
 
+// stride-2 3x3 data gradient (forward pad 1) by output parity class instead of a zero-dilated source: dx[2a+py][2b+px]
+// only receives the taps ky = 1 (py = 0) or ky in {2, 0} at dy rows {a, a+1} (py = 1), same along x -> 1+2+2+4 = 9 tap
+// visits per 2x2 output pixels instead of 36.  Weight taps are those of the flipped dgrad packing (fy = 2 - ky).
+// (One launch with the class in the block index was measured slower: LDS sized for the widest class, uneven work.)
+static int launch_stride2_dgrad(const ConvArgs& a, int dtype, hipStream_t st) {
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            ConvArgs c = a;
+            c.dilate = 0; c.stride = 1; c.pad = 0;
+            c.kh = 1 + py; c.kw = 1 + px;
+            c.Ho = (a.Ho - py + 1) / 2; c.Wo = (a.Wo - px + 1) / 2;
+            if (c.Ho <= 0 || c.Wo <= 0) continue;
+            c.OH = a.Ho; c.OW = a.Wo; c.out_step = 2; c.out_offy = py; c.out_offx = px;
+            c.use_tapmap = 1;
+            for (int r = 0; r < c.kh; ++r)
+                for (int q = 0; q < c.kw; ++q) {
+                    const int fy = py ? (r == 0 ? 0 : 2) : 1, fx = px ? (q == 0 ? 0 : 2) : 1;
+                    c.tapmap[r * c.kw + q] = fy * 3 + fx;
+                }
+            const int rc = dtype == PMOE_DT_BF16 ? launch_dtype<bf16>(c, st, nullptr)
+                         : dtype == PMOE_DT_F32 ? launch_dtype<float>(c, st, nullptr) : PMOE_ERR_ARG;
+            if (rc) return rc;
+        }
+    return 0;
+}
+
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
+    if (a.dilate && a.ks == 3 && a.pad == 1 && a.kh == 3) return launch_stride2_dgrad(a, dtype, st);
     ResPlan plan;
     if (conv_res_plan(a, dtype, &plan)) return conv_res_launch(a, plan, st);
     if (dtype == PMOE_DT_BF16) return launch_dtype<bf16>(a, st, nullptr);

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     const long long nvec = rpe * CV;
     const size_t ebase = (size_t)e * rpe * C;
     const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int cv = (int)(i0 % CV);               // constant per thread (grid stride is a multiple of CV)
+    const int cv = (int)(threadIdx.x & (CV - 1)); // CV is a power of two <= 256: constant per thread over the grid stride
     // dx = scale*(g - c1 - xhat*c2) = g*A + (x - mean)*Bx + K   with per-channel A, Bx, K (centred x: stable)
     float A[VE], Bx[VE], K[VE], sc[VE], sh[VE], mu[VE];
 #pragma unroll
@@ -642,7 +642,11 @@ int pmoe_bn_bwd_apply(const void* dy, const void* y, const void* x, const float*
         constexpr int VE = 16 / (int)sizeof(T);
         if (C % VE || !pow2(C / VE) || C / VE > 256) return PMOE_ERR_ARG;   // kernels keep one channel vector per thread
         const long long nvec = rows_per_expert * (C / VE);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(nvec, 2048), E), dim3(256), 0, (hipStream_t)stream,
+        // every thread first loads 6 per-channel constant vectors: keep ~1024 workgroups in total (4 per CU) so that this
+        // prologue is amortised over many rows (8192 workgroups cost a flat 170 us on the small layer3/4 tensors)
+        int cap = 1024 / (E > 0 ? E : 1);
+        cap = cap < 64 ? 64 : cap;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(nvec, cap), E), dim3(256), 0, (hipStream_t)stream,
                            (const T*)dy, (const T*)y, (const T*)x, mean, invstd, scale, shift, c1, c2, (T*)dx, (T*)gmask_out,
                            (long long)rows_per_expert, C, relu);
         return (int)hipGetLastError();

@@ -22,6 +22,11 @@ struct ConvArgs {
     unsigned long long seed;
     // filled by the launcher
     int lTW, lTH, TN, n_groups, tiles_y, tiles_x;
+    // tap window + output lattice (defaults: kh = kw = ks, identity tap order, dense output).  A stride-2 data gradient
+    // is issued as 4 launches, one per output parity class (py,px): a kh x kw = (1+py) x (1+px) stride-1 correlation over
+    // dy whose taps are `tapmap` entries of the 3x3 filter, written to dx[2a+py][2b+px] (out_step 2).
+    int kh, kw, use_tapmap, tapmap[4];
+    int out_step, out_offy, out_offx, OH, OW;
 };
 
 struct WgradArgs {

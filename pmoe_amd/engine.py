@@ -461,6 +461,7 @@ class ExpertGroupEngine:
             raise RuntimeError("fused stats width mismatch")
         scale, shift, mean, invstd = self._bn_coeffs(layer, rpe, stats, stats.shape[0] // E if stats is not None else 0, z)
         y = Var(torch.empty_like(z.t))
+        ops.set_meta(name=layer.name, bytes=z.t.numel() * z.t.element_size() * (3 if res is not None else 2))
         ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, mean, rpe, E, C_, relu)
         y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
         if self.taping and y.needs_grad:
@@ -479,6 +480,8 @@ class ExpertGroupEngine:
         E, C_ = self.E, layer.C
         nparts = self._nparts(rpe)
         part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
+        nb = z.t.numel() * z.t.element_size()
+        ops.set_meta(name=layer.name, bytes=nb * (3 if ysrc is not None else 2))
         ops.bn_bwd_reduce(dy, ysrc, z.t, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts)
         part, nparts = self._fold_parts(part, nparts, 2 * C_)
         c1, c2 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(2))
@@ -494,6 +497,7 @@ class ExpertGroupEngine:
             return
         if dz is None:
             dz = torch.empty_like(z.t)
+        ops.set_meta(name=layer.name, bytes=nb * (2 + (ysrc is not None) + 1 + (gm is not None)))
         ops.bn_bwd_apply(dy, ysrc, z.t, mean, invstd, scale, shift, c1, c2, dz, gm, rpe, E, C_, relu)
         if self.debug_grads is not None:
             self.debug_grads[layer.name + ":dz"] = dz.detach().clone()

@@ -394,3 +394,8 @@ def blend_bwd(moe_act, pu_act, lat_w, long_w, out, dout, dlat_w, dlat_b, dlong_w
                                 ptr(dlat_w, "dlat_w", f32), ptr(dlat_b, "dlat_b", f32), ptr(dlong_w, "dlong_w", f32),
                                 ptr(dlong_b, "dlong_b", f32), ptr(dpu, "dpunet", f32) if dpu is not None else None, B,
                                 stream_ptr()), "pmoe_blend_bwd")
+
+
+for _n in ("maxpool2_fwd", "pixel_shuffle2", "copy_window", "action_head_fwd", "action_head_bwd", "action_loss",
+           "blend_fwd", "blend_bwd"):
+    globals()[_n] = _timed(globals()[_n])

@@ -76,6 +76,8 @@ CONV_CASES = [
     (2, 2, 64, 128, 32, 32, 1, 2),
     (1, 3, 128, 128, 16, 16, 3, 1),
     (2, 2, 128, 256, 14, 14, 3, 2),
+    (1, 2, 64, 64, 13, 9, 3, 2),          # odd sizes: the parity classes of the stride-2 data gradient differ in extent
+    (2, 1, 64, 128, 7, 10, 3, 2),
     (1, 5, 256, 256, 7, 7, 3, 1),
     (2, 3, 512, 512, 4, 4, 3, 1),
 ]
