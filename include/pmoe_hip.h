@@ -100,6 +100,13 @@ int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
 int pmoe_pack_conv_weights(const void* const* src_ptrs, void* fwd, void* dgrd, int32_t E, int32_t cout,
                            int32_t cin, int32_t ks, int32_t coutp, int32_t cinp, int32_t cinp2, int32_t coutp2,
                            int32_t dtype, void* stream);
+/* Per-IMAGE weight packs with the ECA gate folded in (basics.py:69-76 in front of basics.py:113):
+ * conv(x * g[n,c], W) == conv(x, W * g[n,c]); the convolution then runs with ipe = 1 (one "expert" per image) on
+ * fwd [N][coutp][ks*ks][cinp] / dgrd [N][cinp2][ks*ks][coutp2] and the gated activation is never written.
+ * gate [N][gate_ld] f32; src_ptrs: the E = N / ipe per-expert OIHW f32 parameters. */
+int pmoe_pack_conv_weights_gated(const void* const* src_ptrs, const float* gate, int32_t gate_ld, void* fwd, void* dgrd,
+                                 int32_t N, int32_t ipe, int32_t cout, int32_t cin, int32_t ks, int32_t coutp,
+                                 int32_t cinp, int32_t cinp2, int32_t coutp2, int32_t dtype, void* stream);
 /* dw_ws [E][ks*ks][coutp][cinp] f32 -> grads [E][cout][cin][ks][ks] f32 (contiguous arena slice) */
 int pmoe_unpack_conv_wgrad(const float* dw_ws, float* grads, int32_t E, int32_t cout, int32_t cin, int32_t ks,
                            int32_t coutp, int32_t cinp, void* stream);
@@ -184,11 +191,12 @@ int pmoe_eca_gate(const float* gap_part, int32_t nparts, int64_t HW, const void*
 /* y[n] = x[n or n%ipe] * gate[n]   (x_shared_ipe>0: x holds ipe images shared by all experts) */
 int pmoe_eca_scale(const void* x, const float* gate, void* y, int32_t N, int64_t HW, int32_t C, int32_t x_shared_ipe,
                    int32_t dtype, void* stream);
-/* from dgate-sums (sum_hw dy*x, partials) -> dpre, dgap [N][C] and dw [E][k] (written to the arena);
+/* from dgate-sums (sum_hw dy*x, partials) -> dpre, dgap [N][C] (times dgap_scale: 1, or 1/HW when the result is used
+ * directly as the per-image bias of the gate-folded data-gradient convolution) and dw [E][k] (written to the arena);
  * dw_scratch: [N][k] f32 caller-owned scratch (per-image partials, summed per expert in fixed order) */
 int pmoe_eca_bwd_small(const float* dot_part, int32_t nparts, const float* gate, const float* gapmean,
                        const void* const* w_ptrs, int32_t k, float* dgap, float* dw, float* dw_scratch, int32_t N,
-                       int32_t ipe, int32_t C, int32_t creal, void* stream);
+                       int32_t ipe, int32_t C, int32_t creal, float dgap_scale, void* stream);
 /* Stem input stage (conv1 reads frames * ECA gate): from per-image filter gradients G [N][ks*ks][coutp][cinp]
  * (pmoe_conv2d_wgrad with per_image=1 on the unscaled, shared frames) produce
  *   dw [E][cout][cin][ks][ks] = sum_n gate[n][c] * G[n]      and      ds [N][cinp] = sum_{k,t} W[e] * G[n],

@@ -305,10 +305,10 @@ def main():
         ("g5_moe_e3_b3_96", "moe", 3, 3, 96, True, 0),
     ]
     only = set(sys.argv[1:])          # optional: regenerate just the named cases
-    cases.append(("g6_moeshared_k4_b3_96", "moe_shared", 4, 3, 96, True, 3))
+    cases.append(("g6_moeshared_k4_b6_96", "moe_shared", 4, 6, 96, True, 3))
     cases.append(("g7_moeshared_k6_b1_224_eval", "moe_shared", 6, 1, 224, False, 0))
-    cases.append(("g8_moeshared_k3_b2_128", "moe_shared", 3, 2, 128, True, 0))
-    cases.append(("g9_moeshared_k5_b4_64", "moe_shared", 5, 4, 64, True, 0))
+    cases.append(("g8_moeshared_k3_b4_128", "moe_shared", 3, 4, 128, True, 0))
+    cases.append(("g9_moeshared_k5_b8_64", "moe_shared", 5, 8, 64, True, 0))
     for name, t, e, b, s, train, steps in cases:
         if only and name not in only:
             continue

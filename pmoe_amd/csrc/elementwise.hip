@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(256) eca_bwd_small_kernel(const float* __restr
                                                            const float* __restrict__ gate,
                                                            const float* __restrict__ gapmean, const float* const* w,
                                                            int k, float* __restrict__ dgap, float* __restrict__ dw_img,
-                                                           int ipe, int C, int creal) {
+                                                           int ipe, int C, int creal, float dgap_scale) {
     const int n = blockIdx.x, e = n / ipe;
     __shared__ float dpre[1024];
     __shared__ float wacc[256][9];
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(256) eca_bwd_small_kernel(const float* __restr
             const int cc = c - j + pad;
             if (cc >= 0 && cc < creal) d += we[j] * dpre[cc];
         }
-        if (dgap) dgap[(size_t)n * C + c] = c < creal ? d : 0.f;
+        if (dgap) dgap[(size_t)n * C + c] = c < creal ? d * dgap_scale : 0.f;
         if (c < creal)
             for (int j = 0; j < k; ++j) {
                 const int cc = c + j - pad;
@@ -731,10 +731,10 @@ int pmoe_eca_scale(const void* x, const float* gate, void* y, int32_t N, int64_t
 
 int pmoe_eca_bwd_small(const float* dot_part, int32_t nparts, const float* gate, const float* gapmean,
                        const void* const* w_ptrs, int32_t k, float* dgap, float* dw, float* dw_scratch, int32_t N,
-                       int32_t ipe, int32_t C, int32_t creal, void* stream) {
+                       int32_t ipe, int32_t C, int32_t creal, float dgap_scale, void* stream) {
     if (C > 1024 || k > 9 || k < 1 || N % ipe || !dw_scratch) return PMOE_ERR_ARG;
     hipLaunchKernelGGL(eca_bwd_small_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dot_part, nparts, gate,
-                       gapmean, (const float* const*)w_ptrs, k, dgap, dw_scratch, ipe, C, creal);
+                       gapmean, (const float* const*)w_ptrs, k, dgap, dw_scratch, ipe, C, creal, dgap_scale);
     hipLaunchKernelGGL(eca_bwd_dw_kernel, dim3(N / ipe), dim3(64), 0, (hipStream_t)stream, dw_scratch, dw, ipe, k);
     return (int)hipGetLastError();
 }

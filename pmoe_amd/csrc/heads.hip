@@ -33,6 +33,39 @@ __global__ void __launch_bounds__(256) pack_w_kernel(const float* const* __restr
     }
 }
 
+// Per-IMAGE weights with the ECA gate folded in (basics.py:69-76 feeding basics.py:113): conv(x * g[n,c], W) ==
+// conv(x, W * g[n,c]), so the gated activation is never materialised -- the conv runs with "one expert per image"
+// (ipe = 1) on these packs.  fwd[n][co][tap][ci] = W[e][co][ci][tap] * g[n][ci]; dgrd[n][ci][tap'][co] likewise (flipped).
+template <typename T>
+__global__ void __launch_bounds__(256) pack_w_gated_kernel(const float* const* __restrict__ src,
+                                                          const float* __restrict__ gate, int gate_ld, T* __restrict__ fwd,
+                                                          T* __restrict__ dgrd, int ipe, int cout, int cin, int taps,
+                                                          int coutp, int cinp, int cinp2, int coutp2) {
+    const int n = blockIdx.y;
+    const float* s = src[n / ipe];
+    const float* g = gate + (size_t)n * gate_ld;
+    const long long nf = fwd ? (long long)coutp * taps * cinp : 0;
+    const long long nd = dgrd ? (long long)cinp2 * taps * coutp2 : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nf + nd; i += (long long)gridDim.x * 256) {
+        if (i < nf) {
+            const int ci = (int)(i % cinp);
+            long long t = i / cinp;
+            const int tp = (int)(t % taps);
+            const int co = (int)(t / taps);
+            const float v = (co < cout && ci < cin) ? s[((size_t)co * cin + ci) * taps + tp] * g[ci] : 0.f;
+            fwd[(size_t)n * nf + i] = from_f32<T>(v);
+        } else {
+            const long long k = i - nf;
+            const int co = (int)(k % coutp2);
+            long long t = k / coutp2;
+            const int tp = (int)(t % taps);
+            const int ci = (int)(t / taps);
+            const float v = (co < cout && ci < cin) ? s[((size_t)co * cin + ci) * taps + (taps - 1 - tp)] * g[ci] : 0.f;
+            dgrd[(size_t)n * nd + k] = from_f32<T>(v);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ g, int cout,
                                                           int cin, int taps, int coutp, int cinp) {
     const int e = blockIdx.y;
@@ -304,6 +337,29 @@ int pmoe_pack_conv_weights(const void* const* src_ptrs, void* fwd, void* dgrd, i
         hipLaunchKernelGGL((pack_w_kernel<float>), dim3((int)g, E), dim3(256), 0, (hipStream_t)stream,
                            (const float* const*)src_ptrs, (float*)fwd, (float*)dgrd, cout, cin, taps, coutp, cinp, cinp2,
                            coutp2);
+    else
+        return PMOE_ERR_ARG;
+    return (int)hipGetLastError();
+}
+
+int pmoe_pack_conv_weights_gated(const void* const* src_ptrs, const float* gate, int32_t gate_ld, void* fwd, void* dgrd,
+                                 int32_t N, int32_t ipe, int32_t cout, int32_t cin, int32_t ks, int32_t coutp, int32_t cinp,
+                                 int32_t cinp2, int32_t coutp2, int32_t dtype, void* stream) {
+    if (N < 1 || ipe < 1 || N % ipe || coutp < cout || cinp < cin || gate_ld < cin || !gate ||
+        (dgrd && (cinp2 < cin || coutp2 < cout)))
+        return PMOE_ERR_ARG;
+    const int taps = ks * ks;
+    const long long n = (fwd ? (long long)coutp * taps * cinp : 0) + (dgrd ? (long long)cinp2 * taps * coutp2 : 0);
+    long long g = (n + 255) / 256;
+    if (g > 64) g = 64;
+    if (dtype == PMOE_DT_BF16)
+        hipLaunchKernelGGL((pack_w_gated_kernel<bf16>), dim3((int)g, N), dim3(256), 0, (hipStream_t)stream,
+                           (const float* const*)src_ptrs, gate, gate_ld, (bf16*)fwd, (bf16*)dgrd, ipe, cout, cin, taps, coutp,
+                           cinp, cinp2, coutp2);
+    else if (dtype == PMOE_DT_F32)
+        hipLaunchKernelGGL((pack_w_gated_kernel<float>), dim3((int)g, N), dim3(256), 0, (hipStream_t)stream,
+                           (const float* const*)src_ptrs, gate, gate_ld, (float*)fwd, (float*)dgrd, ipe, cout, cin, taps, coutp,
+                           cinp, cinp2, coutp2);
     else
         return PMOE_ERR_ARG;
     return (int)hipGetLastError();

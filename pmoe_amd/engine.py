@@ -132,6 +132,7 @@ class ExpertGroupEngine:
         self.fuse_conv_stats = True
         self.fuse_stem_tail = True
         self.fold_stem_input = True
+        self.fold_eca_gate = True     # ECA gate folded into per-image conv weights (no gated activation in memory)
         self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tools/probe_layers.py)
         self._collect()
 
@@ -614,6 +615,72 @@ class ExpertGroupEngine:
             self.tape.append(bwd)
         return y
 
+    def _eca_conv_folded(self, x, ecal, layer):
+        """conv(x * sigmoid(conv1d(GAP(x)))) with the gate folded into per-IMAGE weight packs (the conv runs with one
+        "expert" per image), so neither the gated activation nor its gradient is ever written:
+          forward : gap -> gate [N,C] -> pack W*g[n] -> conv(x, W_n)
+          backward: per-image filter gradients G[n] = dy (x) x  ->  dW = sum_n g[n] G[n],  ds = sum W G[n]  (eca_stem_fold)
+                    -> ECA weight gradient and dgap  ->  dx = conv^T(dy, W_n) + dgap/HW  (the per-image bias of that conv)"""
+        nx, h, w, c = x.t.shape
+        hw = h * w
+        N, B_, E = self.N, self.B, self.E
+        nparts = self._gap_parts(hw)
+        part = torch.empty(nx, nparts, c, dtype=F32, device=self.dev)
+        ops.gap_partial(x.t, None, part, nparts)
+        gate = torch.empty(N, c, dtype=F32, device=self.dev)
+        gapmean = torch.empty(N, c, dtype=F32, device=self.dev)
+        ops.eca_gate(part, nparts, hw, self._tab("eca", ecal), ecal.k, gate, gapmean, N, B_, 0, c, ecal.creal)
+        wf = torch.empty(N, layer.coutp, layer.taps, layer.cinp, dtype=self.dtype, device=self.dev)
+        wd = torch.empty(N, layer.dg_rows, layer.taps, layer.dg_red, dtype=self.dtype, device=self.dev) if x.needs_grad else None
+        ops.pack_conv_weights_gated(self._tab("w", layer), gate, wf, wd, N, B_, layer.cout, layer.cin, layer.ks, layer.coutp,
+                                    layer.cinp, layer.dg_rows, layer.dg_red, self.dtype)
+        Ho = ops.conv_out_size(h, layer.ks, layer.stride, layer.pad)
+        Wo = ops.conv_out_size(w, layer.ks, layer.stride, layer.pad)
+        o = Var(self._new(N, Ho, Wo, layer.cout_st), layer.cout_st, 0)
+        stats = None
+        if self.training and self.fuse_conv_stats and self.dtype == torch.bfloat16:
+            rows = ops.conv2d_stat_rows(N, h, w, Ho, Wo, layer.cinp, layer.cout_st, layer.coutp, 1, layer.ks, layer.stride,
+                                        layer.pad, self.dtype)
+            stats = torch.empty(rows, 2, layer.coutp, dtype=F32, device=self.dev)
+        flop = 2.0 * N * Ho * Wo * layer.cout * layer.cin * layer.taps
+        ops.set_meta(flop=flop, name=layer.name)
+        ops.conv2d(x.t, wf, o.t, cin=layer.cinp, cout=layer.cout_st, coutp=layer.coutp, ipe=1, ks=layer.ks,
+                   stride=layer.stride, pad=layer.pad, stats=stats)
+        o.needs_grad = x.needs_grad or layer.trainable or ecal.trainable
+        if self.taping and o.needs_grad:
+            def bwd():
+                dy = o.grad
+                if dy is None:
+                    return
+                ckw = 64 if self.dtype == torch.bfloat16 else 32
+                cpw = (layer.cinp + ckw - 1) // ckw * ckw
+                cow = (layer.cout_st + ckw - 1) // ckw * ckw
+                G = self._wgrad_ws(N * layer.taps * cow * cpw)
+                G.zero_()
+                ops.set_meta(flop=flop, name=layer.name)
+                ops.conv2d_wgrad(x.t, dy, G, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=B_, ks=layer.ks,
+                                 stride=layer.stride, pad=layer.pad, per_image=True)
+                ds = torch.empty(N, c, dtype=F32, device=self.dev)
+                dw = self._grad_slot("w", layer) if layer.trainable else torch.empty(
+                    E * layer.cout * layer.cin * layer.taps, dtype=F32, device=self.dev)
+                ops.eca_stem_fold(G, gate, self._tab("w", layer), dw, ds, N, B_, layer.cout, layer.cin, layer.ks, cow, cpw)
+                dgap = torch.empty(N, c, dtype=F32, device=self.dev) if x.needs_grad else None
+                if ecal.trainable or x.needs_grad:
+                    dwe = self._grad_slot("eca", ecal).view(E, ecal.k) if ecal.trainable else torch.empty(
+                        E, ecal.k, dtype=F32, device=self.dev)
+                    ops.eca_bwd_small(ds, 1, gate, gapmean, self._tab("eca", ecal), ecal.k, dgap, dwe, N, B_, c, ecal.creal,
+                                      dgap_scale=1.0 / hw)
+                if x.needs_grad:
+                    if x.grad is not None or x.act != hip.ACT_NONE:
+                        raise RuntimeError("gate-folded conv: its input must have this conv as the only consumer")
+                    g = torch.empty_like(x.t)
+                    ops.set_meta(flop=flop, name=layer.name + ":dgrad")
+                    ops.conv2d(dy, wd, g, cin=layer.dg_red, cout=layer.cinp, coutp=layer.dg_rows, ipe=1, ks=layer.ks,
+                               stride=1, pad=layer.ks - 1 - layer.pad, bias=dgap)
+                    x.set_grad(g)
+            self.tape.append(bwd)
+        return o, stats
+
     def _gap_to(self, x, feat, coff):
         n, h, w, c = x.t.shape
         hw = h * w
@@ -738,8 +805,11 @@ class ExpertGroupEngine:
             x0s = self._eca(x0, self.eca1, shared=True)
             z1, st = self._conv_stats(x0s, self.conv1)
         a1 = self._bn(z1, self.bn_c1, relu=True, stats=st)
-        a1s = self._eca(a1, self.eca2, shared=False)
-        z2, st = self._conv_stats(a1s, self.conv2)
+        if self.fold_eca_gate and hw_ok and self.conv2.cin % 64 == 0:
+            z2, st = self._eca_conv_folded(a1, self.eca2, self.conv2)
+        else:
+            a1s = self._eca(a1, self.eca2, shared=False)
+            z2, st = self._conv_stats(a1s, self.conv2)
         if self.fuse_stem_tail:
             o = self._stem_tail(z2, st)                        # BN+ReLU, bn1+ReLU, maxpool in one fused chain
         else:

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pmoe_conv2d_stat_rows": [C.POINTER(ConvDesc)],
     "pmoe_conv2d_wgrad": [C.POINTER(WgradDesc), _P],
     "pmoe_pack_conv_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_pack_conv_weights_gated": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_unpack_conv_wgrad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_bias": [_P, _P, _I, _I, _I, _P],
     "pmoe_colstats": [_P, _L, _I, _I, _I, _I, _P, _I, _P, _I, _P],
@@ -82,7 +83,7 @@ SIGNATURES = {
     "pmoe_gap_bwd": [_P, _P, _I, _L, _I, _I, _I, _I, _P],
     "pmoe_eca_gate": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "pmoe_eca_scale": [_P, _P, _P, _I, _L, _I, _I, _I, _P],
-    "pmoe_eca_bwd_small": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pmoe_eca_bwd_small": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "pmoe_eca_stem_fold": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_eca_bwd_apply": [_P, _P, _P, _P, _I, _L, _I, _I, _P],
     "pmoe_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -93,6 +93,12 @@ def pack_conv_weights(ptr_tab, fwd, dgrd, E, cout, cin, ks, coutp, cinp, cinp2, 
           "pmoe_pack_conv_weights")
 
 
+def pack_conv_weights_gated(ptr_tab, gate, fwd, dgrd, N, ipe, cout, cin, ks, coutp, cinp, cinp2, coutp2, dtype):
+    check(load().pmoe_pack_conv_weights_gated(ptr(ptr_tab, "ptr table", torch.int64), ptr(gate, "gate", torch.float32),
+                                              gate.shape[-1], ptr(fwd), ptr(dgrd), N, ipe, cout, cin, ks, coutp, cinp, cinp2,
+                                              coutp2, hip._TORCH_DT[dtype], stream_ptr()), "pmoe_pack_conv_weights_gated")
+
+
 def unpack_conv_wgrad(dw_ws, grads, E, cout, cin, ks, coutp, cinp):
     check(load().pmoe_unpack_conv_wgrad(ptr(dw_ws, "dw_ws", torch.float32), ptr(grads, "grads", torch.float32), E, cout,
                                         cin, ks, coutp, cinp, stream_ptr()), "pmoe_unpack_conv_wgrad")
@@ -214,10 +220,10 @@ def eca_scale(x, gate, y, x_shared_ipe=0):
                                 x_shared_ipe, dt(x), stream_ptr()), "pmoe_eca_scale")
 
 
-def eca_bwd_small(dot_part, nparts, gate, gapmean, w_tab, k, dgap, dw, n, ipe, c, creal):
+def eca_bwd_small(dot_part, nparts, gate, gapmean, w_tab, k, dgap, dw, n, ipe, c, creal, dgap_scale=1.0):
     scratch = torch.empty(n, k, dtype=torch.float32, device=gate.device)
     check(load().pmoe_eca_bwd_small(ptr(dot_part), nparts, ptr(gate), ptr(gapmean), ptr(w_tab), k, ptr(dgap), ptr(dw),
-                                    ptr(scratch), n, ipe, c, creal, stream_ptr()), "pmoe_eca_bwd_small")
+                                    ptr(scratch), n, ipe, c, creal, float(dgap_scale), stream_ptr()), "pmoe_eca_bwd_small")
 
 
 def eca_stem_fold(G, gate, w_tab, dw, ds, n, ipe, cout, cin, ks, coutp, cinp):
@@ -318,7 +324,7 @@ def _timed(fn):
     return wrapper
 
 
-for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "conv2d", "conv2d_wgrad", "pack_conv_weights", "unpack_conv_wgrad", "pack_bias", "colstats",
+for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "conv2d", "conv2d_wgrad", "pack_conv_weights", "pack_conv_weights_gated", "unpack_conv_wgrad", "pack_bias", "colstats",
            "reduce_partials", "bn_finalize", "bn_apply", "bn_bwd_reduce", "bn_bwd_finalize", "bn_bwd_apply",
            "maxpool_fwd", "maxpool_bwd", "gap_partial", "gap_finish", "gap_bwd", "eca_gate", "eca_scale",
            "eca_bwd_small", "eca_bwd_apply", "eca_stem_fold", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",

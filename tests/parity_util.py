@@ -172,7 +172,8 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
             if v.dtype == torch.long:
                 assert int(sd[k].item()) == int(v.item()), k
             else:
-                assert rel_err(sd[k], v) <= (1e-4 if dtype == torch.float32 else 1e-2), k
+                # bf16: same 3e-2 as the forward tolerance (the deepest running means average 32 bf16 activations here)
+                assert rel_err(sd[k], v) <= (1e-4 if dtype == torch.float32 else 3e-2), k
     if verbose:
         print(name, dtype, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in report.items()})
     return report

@@ -16,7 +16,7 @@ def _g(golden_dir, name):
 
 @pytest.mark.parametrize("name,typ,E", [("g1_moe_e4_b2_128", "moe", 4), ("g3_moe_e8_b2_128", "moe", 8),
                                         ("g4_moealt_e4_b2_64", "moe_alt", 4), ("g5_moe_e3_b3_96", "moe", 3),
-                                        ("g6_moeshared_k4_b3_96", "moe_shared", 4),
+                                        ("g6_moeshared_k4_b6_96", "moe_shared", 4),
                                         ("g7_moeshared_k6_b1_224_eval", "moe_shared", 6)])
 def test_state_dict_keys_match_reference(golden_dir, name, typ, E):
     g = _g(golden_dir, name)
