@@ -170,8 +170,11 @@ int pmoe_gap_bwd(const void* g, void* dx, int32_t N, int64_t HW, int32_t C, int3
  * All per-channel arrays are [E][C] f32.  part: [E][nparts][2][C] partial sums (finish with pmoe_bn_finalize /
  * pmoe_bn_bwd_finalize). */
 int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, const float* mu2, float* part,
-                         int32_t nparts, float* shiftc, int32_t E, int32_t ipe, int32_t H, int32_t W, int32_t C,
-                         int32_t dtype, void* stream);
+                         int32_t nparts, float* shiftc, float* part_x, int32_t E, int32_t ipe, int32_t H, int32_t W,
+                         int32_t C, int32_t dtype, void* stream);
+/* part_x (optional) [E][nparts][3][C]: channel moments sum m, sum m*u, sum a2*u (m = [a2 > 0], u = z2 - mu2) that the
+ * train-mode backward combines with the pooled pass below.  The argmax byte of pmoe_stem_tail_pool carries the winning
+ * tap in bits 0..3 and [winner's a2 > 0] in bit 7. */
 int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* sc2, const float* sh2, const float* sc1,
                         const float* sh1, const float* mu2, const float* mu1, int32_t N, int32_t ipe, int32_t H, int32_t W, int32_t C, int32_t dtype,
                         void* stream);
@@ -181,6 +184,18 @@ int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* s
 int pmoe_stem_tail_bwd(int32_t phase, const void* z2, const void* dpool, const uint8_t* argmax, void* dz2,
                        const float* const* consts, float* part, int32_t nparts, int32_t E, int32_t ipe, int32_t H,
                        int32_t W, int32_t C, int32_t dtype, void* stream);
+/* Train mode: phases 1 and 2 as ONE pass over the pooled tensors (y = pooled output, dpool, argmax; 1/4 of the
+ * elements) + a closed-form combine.  The pooled gradient only reaches the winning pixels, whose a3 is y itself, so
+ * xhat1 / xhat2 there are recovered from y; the BatchNorm-backward terms that touch every pixel reduce to the channel
+ * moments part_x of pmoe_stem_tail_stats.  part4 [E][nparts][4][C]; out1 / out2 [E][2][C] are the (sum g, sum g*xhat)
+ * rows of bn1 / of the conv2 BatchNorm for pmoe_bn_bwd_finalize; count = pixels per expert (B*H*W).
+ * (A channel whose BatchNorm scale is exactly 0 contributes xhat = 0: its value cannot be recovered from y.) */
+int pmoe_stem_tail_pooled(const void* y, const void* dpool, const uint8_t* argmax, const float* const* consts,
+                          float* part4, int32_t nparts, int32_t E, int64_t rows_per_expert, int32_t C, int32_t dtype,
+                          void* stream);
+int pmoe_stem_tail_combine(const float* part4, int32_t np4, const float* part_x, int32_t npx,
+                           const float* const* consts, int64_t count, float* out1, float* out2, int32_t E, int32_t C,
+                           void* stream);
 
 /* ---- ECA channel attention (EfficientBlock.forward, basics.py:69-76) -------------------------
  * gate[n][c] = sigmoid(sum_j w[e][j] * mean_hw(x)[n][c + j - k/2]) from GAP partials (creal = number

@@ -10,6 +10,11 @@
 //   backward: phase 1 (bn1:  sum g3, sum g3*xhat1)             1 read of z2 + pooled grad
 //             phase 2 (c2 :  sum g2, sum g2*xhat2)             1 read of z2 + pooled grad
 //             phase 3 (dz2 = BN backward)                      1 read of z2 + pooled grad, 1 write
+// Train mode replaces phases 1 and 2 by ONE pass over the POOLED tensors (1/4 of the elements) + closed forms:
+// the pooled gradient only reaches the winning pixels, whose a3 IS the stored pooled output y, so
+// (a2 - mu1) = (y - b1)/sc1 and (z - mu2) = (a2 - b2)/sc2 are recovered from y; the terms of the BatchNorm backward
+// that touch every pixel (xhat1*P + Q) only need channel moments of z2 (sum m, sum m*u, sum a2*u with m = [a2>0],
+// u = z - mu2), which the forward statistics pass accumulates alongside.  See stem_tail_combine_kernel.
 // Reductions: per-workgroup LDS, fixed-order partial rows (bit-reproducible).
 #include "common.h"
 
@@ -27,7 +32,8 @@ template <typename T, int MODE>
 __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2, const T* __restrict__ dpool,
                                                        const uint8_t* __restrict__ amax, T* __restrict__ dz2,
                                                        TailConsts k, float* __restrict__ part, int nparts, int ipe,
-                                                       int H, int W, int C, float* __restrict__ shiftc) {
+                                                       int H, int W, int C, float* __restrict__ shiftc,
+                                                       float* __restrict__ part_x) {
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE, RL = 256 / CV;
     const int tid = threadIdx.x, cv = tid % CV, rl = tid / CV;
@@ -61,9 +67,9 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
             S[i] = -sc2[i] * k.c12[c];
         }
     }
-    float s1[VE], s2[VE];
+    float s1[VE], s2[VE], x0[VE], x1[VE], x2[VE];       // x*: MODE 0 extra moments (sum m, sum m*u, sum a2*u)
 #pragma unroll
-    for (int i = 0; i < VE; ++i) s1[i] = s2[i] = 0.f;
+    for (int i = 0; i < VE; ++i) s1[i] = s2[i] = x0[i] = x1[i] = x2[i] = 0.f;
     // MODE 0: deviations from the channel's value at the expert's first pixel (see colstats_kernel)
     float c0v[VE];
 #pragma unroll
@@ -98,6 +104,15 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < VE; ++i) { const float d = a2[i] - c0v[i]; s1[i] += d; s2[i] += d * d; }
+            if (part_x) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    const float u = zv[i] - mu2[i];
+                    x0[i] += a2[i] > 0.f ? 1.f : 0.f;
+                    x1[i] += a2[i] > 0.f ? u : 0.f;
+                    x2[i] += a2[i] * u;
+                }
+            }
             continue;
         }
         // gradient arriving at a3 through the max-pool: gather from the <= 4 windows that contain (yy,xx)
@@ -114,7 +129,7 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
             else amw = *reinterpret_cast<const unsigned*>(amax + po);
 #pragma unroll
             for (int i = 0; i < VE; ++i)
-                if (((unsigned)(amw >> (8 * i)) & 0xffu) == (unsigned)tap) g3[i] += d[i];
+                if (((unsigned)(amw >> (8 * i)) & 0x7fu) == (unsigned)tap) g3[i] += d[i];   // bit 7 = winner's a2 > 0
         };
         const int tqA = xx - (2 * oxA - 1), tqB = xx - (2 * oxB - 1);
         const bool twoCols = oxB != oxA && oxB < Wo;
@@ -162,6 +177,111 @@ __global__ void __launch_bounds__(256) stem_tail_kernel(const T* __restrict__ z2
         for (int q = 0; q < RL; ++q) s += red[which][q * C + cc];
         part[(((size_t)e * nparts + pi) * 2 + which) * C + cc] = s;
     }
+    if (MODE == 0 && part_x) {
+        for (int w = 0; w < 3; ++w) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < VE; ++i) red[0][rl * C + cv * VE + i] = w == 0 ? x0[i] : (w == 1 ? x1[i] : x2[i]);
+            __syncthreads();
+            for (int c = tid; c < C; c += 256) {
+                float s = 0.f;
+                for (int q = 0; q < RL; ++q) s += red[0][q * C + c];
+                part_x[(((size_t)e * nparts + pi) * 3 + w) * C + c] = s;
+            }
+        }
+    }
+}
+
+// Train-mode backward, pooled pass: over the POOLED tensors only.  g = dpool * [y > 0]; recovered (a2 - mu1) = (y - b1)/sc1,
+// xhat1 = that * is1, m = bit 7 of the argmax byte, xhat2 = ((a2 - b2)/sc2) * is2.
+// part4 [E][nparts][4][C] = (sum g, sum g*xhat1, sum g*m, sum g*m*xhat2).
+template <typename T>
+__global__ void __launch_bounds__(256) stem_tail_pooled_kernel(const T* __restrict__ y, const T* __restrict__ dpool,
+                                                              const uint8_t* __restrict__ amax, TailConsts k,
+                                                              float* __restrict__ part4, int nparts, long long rpe, int C) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int CV = C / VE, RL = 256 / CV;
+    const int tid = threadIdx.x, cv = tid % CV, rl = tid / CV;
+    const int e = blockIdx.y, pi = blockIdx.x;
+    const long long rpp = (rpe + nparts - 1) / nparts;
+    long long r0 = (long long)pi * rpp, r1 = r0 + rpp;
+    if (r1 > rpe) r1 = rpe;
+    float sh1[VE], mu1[VE], is1[VE], isc1[VE], sh2[VE], isc2[VE], is2[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+        const int c = e * C + cv * VE + i;
+        const float a = k.sc1[c], b = k.sc2[c];
+        sh1[i] = k.sh1[c]; mu1[i] = k.mu1[c]; is1[i] = k.is1[c]; sh2[i] = k.sh2[c]; is2[i] = k.is2[c];
+        isc1[i] = a != 0.f ? 1.f / a : 0.f;          // gamma == 0: the channel's xhat cannot be recovered (contributes 0)
+        isc2[i] = b != 0.f ? 1.f / b : 0.f;
+    }
+    float s[4][VE];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int i = 0; i < VE; ++i) s[w][i] = 0.f;
+    for (long long r = r0 + rl; r < r1; r += RL) {
+        const size_t off = ((size_t)e * rpe + r) * C + cv * VE;
+        float yv[VE], dv[VE];
+        unpack16<T>(ldg16(y + off), yv);
+        unpack16<T>(ldg16(dpool + off), dv);
+        unsigned long long amw;
+        if (VE == 8) amw = *reinterpret_cast<const unsigned long long*>(amax + off);
+        else amw = *reinterpret_cast<const unsigned*>(amax + off);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            const float g = yv[i] > 0.f ? dv[i] : 0.f;
+            const float da = (yv[i] - sh1[i]) * isc1[i];                 // a2 - mu1 at the winning pixel
+            const float gm = ((unsigned)(amw >> (8 * i)) & 0x80u) ? g : 0.f;
+            const float u = (da + mu1[i] - sh2[i]) * isc2[i];            // z - mu2 there (only used where a2 > 0)
+            s[0][i] += g;
+            s[1][i] += g * (da * is1[i]);
+            s[2][i] += gm;
+            s[3][i] += gm * (u * is2[i]);
+        }
+    }
+    __shared__ float red[256 * 8];
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VE; ++i) red[rl * C + cv * VE + i] = s[w][i];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float t = 0.f;
+            for (int q = 0; q < RL; ++q) t += red[q * C + c];
+            part4[(((size_t)e * nparts + pi) * 4 + w) * C + c] = t;
+        }
+    }
+}
+
+// grid (E), threads over channels: pooled sums + forward moments -> the two (sum g, sum g*xhat) rows that
+// bn_bwd_finalize expects for bn1 (out1) and for the conv2 BatchNorm (out2).  count = pixels per expert (B*H*W).
+__global__ void __launch_bounds__(256) stem_tail_combine_kernel(const float* __restrict__ part4, int np4,
+                                                               const float* __restrict__ part_x, int npx, TailConsts k,
+                                                               float count, float* __restrict__ out1,
+                                                               float* __restrict__ out2, int C) {
+    const int e = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float p[4] = {0, 0, 0, 0}, x[3] = {0, 0, 0};
+        for (int i = 0; i < np4; ++i)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) p[w] += part4[(((size_t)e * np4 + i) * 4 + w) * C + c];
+        for (int i = 0; i < npx; ++i)
+#pragma unroll
+            for (int w = 0; w < 3; ++w) x[w] += part_x[(((size_t)e * npx + i) * 3 + w) * C + c];
+        const int ec = e * C + c;
+        const float sc1 = k.sc1[ec], mu1 = k.mu1[ec], is1 = k.is1[ec], is2 = k.is2[ec];
+        const float c11 = p[0] / count, c21 = p[1] / count;              // bn1 backward means
+        const float P = -sc1 * c21, Q = -sc1 * c11;
+        const float M0 = x[0], Mu = x[1], Au = x[2];
+        const float Mx1 = is1 * mu1 * (count - M0);                      // sum m*xhat1 = is1*(sum a2 - mu1*sum m), sum a2 = count*mu1
+        const float Mx2 = is2 * Mu;                                      // sum m*xhat2
+        const float Mx12 = is1 * is2 * (Au - mu1 * Mu);                  // sum m*xhat1*xhat2
+        out1[(e * 2 + 0) * C + c] = p[0];
+        out1[(e * 2 + 1) * C + c] = p[1];
+        out2[(e * 2 + 0) * C + c] = sc1 * p[2] + P * Mx1 + Q * M0;
+        out2[(e * 2 + 1) * C + c] = sc1 * p[3] + P * Mx12 + Q * Mx2;
+    }
 }
 
 // forward pool pass: a3 = relu(bn1(relu(bn_c2(z2)))) -> max over the 3x3/s2 window (first max wins), tap kept
@@ -189,7 +309,7 @@ __global__ void __launch_bounds__(256) stem_tail_pool_kernel(const T* __restrict
             sc2[q] = sc2a[c]; sh2[q] = sh2a[c]; sc1[q] = sc1a[c]; sh1[q] = sh1a[c]; mu2[q] = mu2a[c]; mu1[q] = mu1a[c];
         }
         float best[VE];
-        int bi[VE];
+        int bi[VE];                      // winning tap (0..8) | 0x80 if the winner's a2 > 0 (used by the pooled backward pass)
 #pragma unroll
         for (int q = 0; q < VE; ++q) { best[q] = -INFINITY; bi[q] = 0; }
         bool first = true;
@@ -206,7 +326,7 @@ __global__ void __launch_bounds__(256) stem_tail_pool_kernel(const T* __restrict
                         const float a2 = fmaxf((v[q] - mu2[q]) * sc2[q] + sh2[q], 0.f);
                         // round like the unfused path stores a3 (T precision) so ties resolve identically
                         const float a3 = to_f32(from_f32<T>(fmaxf((a2 - mu1[q]) * sc1[q] + sh1[q], 0.f)));
-                        if (first || a3 > best[q]) { best[q] = a3; bi[q] = r * 3 + q3; }
+                        if (first || a3 > best[q]) { best[q] = a3; bi[q] = (r * 3 + q3) | (a2 > 0.f ? 0x80 : 0); }
                     }
                     first = false;
                 }
@@ -223,18 +343,18 @@ static inline bool pow2i(int v) { return v > 0 && !(v & (v - 1)); }
 extern "C" {
 
 int pmoe_stem_tail_stats(const void* z2, const float* sc2, const float* sh2, const float* mu2, float* part,
-                         int32_t nparts, float* shiftc, int32_t E, int32_t ipe, int32_t H, int32_t W, int32_t C,
-                         int32_t dtype, void* stream) {
+                         int32_t nparts, float* shiftc, float* part_x, int32_t E, int32_t ipe, int32_t H, int32_t W,
+                         int32_t C, int32_t dtype, void* stream) {
     TailConsts k{};
     k.sc2 = sc2; k.sh2 = sh2; k.mu2 = mu2;
     const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
     if (C % ve || !pow2i(C / ve) || C / ve > 256 || nparts < 1) return PMOE_ERR_ARG;
     if (dtype == PMOE_DT_BF16)
         hipLaunchKernelGGL((stem_tail_kernel<bf16, 0>), dim3(nparts, E), dim3(256), 0, (hipStream_t)stream, (const bf16*)z2,
-                           nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C, shiftc);
+                           nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C, shiftc, part_x);
     else if (dtype == PMOE_DT_F32)
         hipLaunchKernelGGL((stem_tail_kernel<float, 0>), dim3(nparts, E), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)z2, nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C, shiftc);
+                           (const float*)z2, nullptr, nullptr, nullptr, k, part, nparts, ipe, H, W, C, shiftc, part_x);
     else
         return PMOE_ERR_ARG;
     return (int)hipGetLastError();
@@ -272,7 +392,7 @@ int pmoe_stem_tail_bwd(int32_t phase, const void* z2, const void* dpool, const u
     hipStream_t st = (hipStream_t)stream;
 #define TAIL_LAUNCH(TT, M)                                                                                           \
     hipLaunchKernelGGL((stem_tail_kernel<TT, M>), grid, block, 0, st, (const TT*)z2, (const TT*)dpool, argmax, (TT*)dz2, k, \
-                       part, nparts, ipe, H, W, C, nullptr)
+                       part, nparts, ipe, H, W, C, nullptr, nullptr)
     if (dtype == PMOE_DT_BF16) {
         if (phase == 1) TAIL_LAUNCH(bf16, 1); else if (phase == 2) TAIL_LAUNCH(bf16, 2); else TAIL_LAUNCH(bf16, 3);
     } else if (dtype == PMOE_DT_F32) {
@@ -281,6 +401,36 @@ int pmoe_stem_tail_bwd(int32_t phase, const void* z2, const void* dpool, const u
         return PMOE_ERR_ARG;
     }
 #undef TAIL_LAUNCH
+    return (int)hipGetLastError();
+}
+
+/* train-mode replacement of phases 1 and 2: pooled pass (part4 [E][nparts][4][C]) and the closed-form combine
+ * (out1 / out2 [E][2][C] = the (sum g, sum g*xhat) rows of bn1 / of the conv2 BatchNorm, for pmoe_bn_bwd_finalize).
+ * consts as in pmoe_stem_tail_bwd (entries 0..7 used); part_x [E][npx][3][C] from pmoe_stem_tail_stats. */
+int pmoe_stem_tail_pooled(const void* y, const void* dpool, const uint8_t* argmax, const float* const* consts, float* part4,
+                          int32_t nparts, int32_t E, int64_t rows_per_expert, int32_t C, int32_t dtype, void* stream) {
+    TailConsts k{consts[0], consts[1], consts[2], consts[3], consts[4], consts[5],
+                 consts[6], consts[7], consts[8], consts[9], consts[10], consts[11]};
+    const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
+    if (C % ve || !pow2i(C / ve) || C / ve > 256 || nparts < 1 || rows_per_expert < 1) return PMOE_ERR_ARG;
+    if (dtype == PMOE_DT_BF16)
+        hipLaunchKernelGGL((stem_tail_pooled_kernel<bf16>), dim3(nparts, E), dim3(256), 0, (hipStream_t)stream, (const bf16*)y,
+                           (const bf16*)dpool, argmax, k, part4, nparts, (long long)rows_per_expert, C);
+    else if (dtype == PMOE_DT_F32)
+        hipLaunchKernelGGL((stem_tail_pooled_kernel<float>), dim3(nparts, E), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)y, (const float*)dpool, argmax, k, part4, nparts, (long long)rows_per_expert, C);
+    else
+        return PMOE_ERR_ARG;
+    return (int)hipGetLastError();
+}
+
+int pmoe_stem_tail_combine(const float* part4, int32_t np4, const float* part_x, int32_t npx, const float* const* consts,
+                           int64_t count, float* out1, float* out2, int32_t E, int32_t C, void* stream) {
+    TailConsts k{consts[0], consts[1], consts[2], consts[3], consts[4], consts[5],
+                 consts[6], consts[7], consts[8], consts[9], consts[10], consts[11]};
+    if (np4 < 1 || npx < 1 || count < 1) return PMOE_ERR_ARG;
+    hipLaunchKernelGGL(stem_tail_combine_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, part4, np4, part_x, npx, k,
+                       (float)count, out1, out2, C);
     return (int)hipGetLastError();
 }
 

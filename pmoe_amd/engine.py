@@ -132,6 +132,7 @@ class ExpertGroupEngine:
         self.fuse_conv_stats = True
         self.fuse_stem_tail = True
         self.fold_stem_input = True
+        self.pooled_stem_bwd = True   # stem-tail BatchNorm reductions from the pooled tensors (train mode)
         self.fold_eca_gate = True     # ECA gate folded into per-image conv weights (no gated activation in memory)
         self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tools/probe_layers.py)
         self._collect()
@@ -520,11 +521,15 @@ class ExpertGroupEngine:
         rpe = self.B * h * w
         sc2, sh2, mu2, is2 = self._bn_coeffs(self.bn_c2, rpe, stats, stats.shape[0] // E if stats is not None else 0, z2)
         nparts = self._nparts(rpe)
-        part = None
+        part = part_x = None
         if self.training:
             part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
             shc = torch.empty(E, C_, dtype=F32, device=self.dev)
-            ops.stem_tail_stats(z2.t, sc2, sh2, mu2, part, nparts, E, self.B, shiftc=shc)
+            if self.taping:      # channel moments of z2 for the pooled-pass backward (stem_tail.hip)
+                part_x = torch.empty(E, nparts, 3, C_, dtype=F32, device=self.dev)
+            ops.stem_tail_stats(z2.t, sc2, sh2, mu2, part, nparts, E, self.B, shiftc=shc, part_x=part_x)
+            if part_x is not None:
+                part_x, npx = self._fold_parts(part_x, nparts, 3 * C_)
         sc1, sh1, mu1, is1 = self._bn_coeffs(self.bn1, rpe, part, nparts, shiftc=shc if self.training else None)
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         y = Var(self._new(n, ho, wo, C_))
@@ -541,20 +546,33 @@ class ExpertGroupEngine:
                 c11, c21, c12, c22 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(4))
                 consts = [sc2, sh2, sc1, sh1, mu1, is1, mu2, is2, c11, c21, c12, c22]
                 p1 = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
-                ops.stem_tail_bwd(1, z2.t, dp, am, None, consts, p1, nparts, E, self.B)
-                pf, nf = self._fold_parts(p1, nparts, 2 * C_)
-                ops.bn_bwd_finalize(pf, nf, rpe, self._grad_slot("gamma", self.bn1).view(E, C_),
-                                    self._grad_slot("beta", self.bn1).view(E, C_), c11, c21, E, C_)
-                if not train:
-                    c11.zero_()
-                    c21.zero_()
-                ops.stem_tail_bwd(2, z2.t, dp, am, None, consts, p1, nparts, E, self.B)
-                pf, nf = self._fold_parts(p1, nparts, 2 * C_)
-                ops.bn_bwd_finalize(pf, nf, rpe, self._grad_slot("gamma", self.bn_c2).view(E, C_),
-                                    self._grad_slot("beta", self.bn_c2).view(E, C_), c12, c22, E, C_)
-                if not train:
-                    c12.zero_()
-                    c22.zero_()
+                if train and part_x is not None and self.pooled_stem_bwd:
+                    # both reductions from ONE pass over the pooled tensors + the forward moments of z2
+                    np4 = self._nparts(self.B * ho * wo)
+                    p4 = torch.empty(E, np4, 4, C_, dtype=F32, device=self.dev)
+                    ops.stem_tail_pooled(y.t, dp, am, consts, p4, np4, E)
+                    p4, np4 = self._fold_parts(p4, np4, 4 * C_)
+                    o1, o2 = (torch.empty(E, 1, 2, C_, dtype=F32, device=self.dev) for _ in range(2))
+                    ops.stem_tail_combine(p4, np4, part_x, npx, consts, rpe, o1, o2, E, C_)
+                    ops.bn_bwd_finalize(o1, 1, rpe, self._grad_slot("gamma", self.bn1).view(E, C_),
+                                        self._grad_slot("beta", self.bn1).view(E, C_), c11, c21, E, C_)
+                    ops.bn_bwd_finalize(o2, 1, rpe, self._grad_slot("gamma", self.bn_c2).view(E, C_),
+                                        self._grad_slot("beta", self.bn_c2).view(E, C_), c12, c22, E, C_)
+                else:
+                    ops.stem_tail_bwd(1, z2.t, dp, am, None, consts, p1, nparts, E, self.B)
+                    pf, nf = self._fold_parts(p1, nparts, 2 * C_)
+                    ops.bn_bwd_finalize(pf, nf, rpe, self._grad_slot("gamma", self.bn1).view(E, C_),
+                                        self._grad_slot("beta", self.bn1).view(E, C_), c11, c21, E, C_)
+                    if not train:
+                        c11.zero_()
+                        c21.zero_()
+                    ops.stem_tail_bwd(2, z2.t, dp, am, None, consts, p1, nparts, E, self.B)
+                    pf, nf = self._fold_parts(p1, nparts, 2 * C_)
+                    ops.bn_bwd_finalize(pf, nf, rpe, self._grad_slot("gamma", self.bn_c2).view(E, C_),
+                                        self._grad_slot("beta", self.bn_c2).view(E, C_), c12, c22, E, C_)
+                    if not train:
+                        c12.zero_()
+                        c22.zero_()
                 if z2.needs_grad:
                     dz = torch.empty_like(z2.t)
                     ops.stem_tail_bwd(3, z2.t, dp, am, dz, consts, p1, nparts, E, self.B)

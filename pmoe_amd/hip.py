@@ -73,7 +73,9 @@ SIGNATURES = {
     "pmoe_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _I, _P],
     "pmoe_bn_bwd_finalize": [_P, _I, _L, _P, _P, _P, _P, _I, _I, _P],
     "pmoe_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
-    "pmoe_stem_tail_stats": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_stem_tail_stats": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_stem_tail_pooled": [_P, _P, _P, C.POINTER(C.c_void_p), _P, _I, _I, _L, _I, _I, _P],
+    "pmoe_stem_tail_combine": [_P, _I, _P, _I, C.POINTER(C.c_void_p), _L, _P, _P, _I, _I, _P],
     "pmoe_stem_tail_pool": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_stem_tail_bwd": [_I, _P, _P, _P, _P, C.POINTER(C.c_void_p), _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_maxpool3s2_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

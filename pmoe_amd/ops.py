@@ -155,11 +155,30 @@ def bn_bwd_apply(dy, y, x, mean, invstd, scale, shift, c1, c2, dx, gmask, rpe, E
                                    rpe, E, C_, int(relu), dt(dy), stream_ptr()), "pmoe_bn_bwd_apply")
 
 
-def stem_tail_stats(z2, sc2, sh2, mu2, part, nparts, E, ipe, shiftc=None):
+def stem_tail_stats(z2, sc2, sh2, mu2, part, nparts, E, ipe, shiftc=None, part_x=None):
     n, h, w_, c = _nhwc(z2, "z2")
     check(load().pmoe_stem_tail_stats(ptr(z2, "z2"), ptr(sc2), ptr(sh2), ptr(mu2), ptr(part, "part", torch.float32), nparts,
-                                      ptr(shiftc, "shiftc", torch.float32), E, ipe,
+                                      ptr(shiftc, "shiftc", torch.float32), ptr(part_x, "part_x", torch.float32), E, ipe,
                                       h, w_, c, dt(z2), stream_ptr()), "pmoe_stem_tail_stats")
+
+
+def _consts12(consts):
+    return (C.c_void_p * 12)(*[t.data_ptr() if t is not None else None for t in consts])
+
+
+def stem_tail_pooled(y, dpool, argmax, consts, part4, nparts, E):
+    """train-mode backward over the pooled tensors: part4 [E,nparts,4,C] = sums of g, g*xhat1, g*m, g*m*xhat2."""
+    n, ho, wo, c = _nhwc(y, "y")
+    check(load().pmoe_stem_tail_pooled(ptr(y, "y"), ptr(dpool, "dpool", y.dtype), ptr(argmax, "argmax", torch.uint8),
+                                       _consts12(consts), ptr(part4, "part4", torch.float32), nparts, E,
+                                       (n // E) * ho * wo, c, dt(y), stream_ptr()), "pmoe_stem_tail_pooled")
+
+
+def stem_tail_combine(part4, np4, part_x, npx, consts, count, out1, out2, E, c):
+    f32 = torch.float32
+    check(load().pmoe_stem_tail_combine(ptr(part4, "part4", f32), np4, ptr(part_x, "part_x", f32), npx, _consts12(consts),
+                                        count, ptr(out1, "out1", f32), ptr(out2, "out2", f32), E, c, stream_ptr()),
+          "pmoe_stem_tail_combine")
 
 
 def stem_tail_pool(z2, y, argmax, sc2, sh2, sc1, sh1, mu2, mu1, ipe):
@@ -324,7 +343,7 @@ def _timed(fn):
     return wrapper
 
 
-for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "conv2d", "conv2d_wgrad", "pack_conv_weights", "pack_conv_weights_gated", "unpack_conv_wgrad", "pack_bias", "colstats",
+for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "stem_tail_pooled", "stem_tail_combine", "conv2d", "conv2d_wgrad", "pack_conv_weights", "pack_conv_weights_gated", "unpack_conv_wgrad", "pack_bias", "colstats",
            "reduce_partials", "bn_finalize", "bn_apply", "bn_bwd_reduce", "bn_bwd_finalize", "bn_bwd_apply",
            "maxpool_fwd", "maxpool_bwd", "gap_partial", "gap_finish", "gap_bwd", "eca_gate", "eca_scale",
            "eca_bwd_small", "eca_bwd_apply", "eca_stem_fold", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",

@@ -183,3 +183,27 @@ def test_eca_gate_fold_matches_explicit_path(dtype):
             assert e <= 2e-2, (k, e)           # two f32 summation orders upstream of a chaotic network (see parity_util)
         errs = sorted(((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-20)).item() for k in ga if gb[k].norm() > 1e-8)
         assert errs[len(errs) // 2] <= 1e-3, errs[len(errs) // 2]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pooled_stem_tail_backward_matches_three_phase_path(dtype):
+    """Train-mode stem-tail BatchNorm reductions from ONE pass over the pooled tensors + forward channel moments
+    (stem_tail_pooled / stem_tail_combine) against the three full sweeps over z2."""
+    from pmoe_amd.loss import moe_loss
+    g = torch.load(GOLDEN / "g5_moe_e3_b3_96.pt", weights_only=False)
+    res = []
+    for pooled in (True, False):
+        _, _, model, inp = build_pair(g, dtype)
+        model._engine().pooled_stem_bwd = pooled
+        dev = {k: v.cuda() for k, v in inp.items()}
+        dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+        moe_loss(dist, speeds, dev["control"], dev["target_speed"], [0.7, 0.3]).backward()
+        res.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    ga, gb = res
+    errs = sorted((((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-20)).item(), k) for k in ga
+                  if "backbone.conv1." in k or "backbone.bn1." in k)
+    assert len(errs) == 3 * 10
+    if dtype == torch.float32:
+        assert errs[-1][0] <= 2e-4, errs[-1]
+    else:       # bf16: xhat is recovered from the bf16-ROUNDED pooled output; the 3-element ECA filters cancel heavily
+        assert errs[len(errs) // 2][0] <= 2e-2 and errs[-1][0] <= 0.15, (errs[len(errs) // 2], errs[-1])
