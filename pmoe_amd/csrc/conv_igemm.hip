@@ -15,6 +15,7 @@
 // by 2, i.e. a transposed conv), and the expert MLP heads (1x1 conv on 1x1 images = grouped GEMM
 // over experts with TN samples per tile).
 #include "conv_common.h"
+#include <stdlib.h>
 #include "kernels.h"
 
 template <int LOG_RB> __device__ __forceinline__ int swz(int x) { return swz_chunk<LOG_RB, 0>(x); }
@@ -322,7 +323,12 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
     if (a.N % a.ipe) return PMOE_ERR_ARG;
     const int E = a.N / a.ipe;
     const bool wide = (a.CoutP % 128 == 0);
-    const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+    // bf16, >= 128 output channels: 8 waves on a 256-pixel x 128-channel tile (each weight tile and each barrier serves
+    // twice the pixels of the 4-wave 128 x 128 tile: +5-8 % on the 3x3 layers, +30 % on the stride-2 forward convs)
+    static int cfg42 = -1;      // PMOE_CONV_CFG42=0 switches back to the 4-wave tile (A/B measurements)
+    if (cfg42 < 0) { const char* ev = getenv("PMOE_CONV_CFG42"); cfg42 = ev ? atoi(ev) : 1; }
+    const bool big = wide && cfg42 && sizeof(T) == 2 && (long long)a.ipe * a.Ho * a.Wo >= 4096;   // not the MLP GEMMs
+    const int BM = wide ? (big ? 256 : 128) : 256, BN = wide ? 128 : 64;
     auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     // candidate chunk widths (bytes per pixel row in LDS), widest first
     for (int log_rb = 7; log_rb >= 5; --log_rb) {
@@ -345,6 +351,9 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         a.tiles_x = (a.Wo + TW - 1) / TW;
         const int mblocks = E * a.n_groups * a.tiles_y * a.tiles_x;
         if (out_mblocks) { *out_mblocks = mblocks; return 0; }
+        if (log_rb == 7 && big) return launch_cfg<T, 7, 4, 2>(a, mblocks, smem, st);
+        if (log_rb == 6 && big) return launch_cfg<T, 6, 4, 2>(a, mblocks, smem, st);
+        if (log_rb == 5 && big) return launch_cfg<T, 5, 4, 2>(a, mblocks, smem, st);
         if (log_rb == 7) return wide ? launch_cfg<T, 7, 2, 2>(a, mblocks, smem, st) : launch_cfg<T, 7, 4, 1>(a, mblocks, smem, st);
         if (log_rb == 6) return wide ? launch_cfg<T, 6, 2, 2>(a, mblocks, smem, st) : launch_cfg<T, 6, 4, 1>(a, mblocks, smem, st);
         return wide ? launch_cfg<T, 5, 2, 2>(a, mblocks, smem, st) : launch_cfg<T, 5, 4, 1>(a, mblocks, smem, st);
