@@ -102,10 +102,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # rehearsal of the N-rank control flow on a ONE-GPU box: PMOE_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # uses gloo (RCCL refuses two ranks on one device); the real multi-GPU run is one rank per GPU over RCCL
+    share = os.environ.get("PMOE_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from pmoe_amd import hip, ops
     from pmoe_amd.loss import moe_loss
@@ -182,10 +190,13 @@ def main():
 
     # ---- per-kernel timing with HIP events on the launch stream (one instrumented step, untimed region)
     log(f"timed: {ms:.2f} ms/step")
-    if rank == 0 and not args.no_kernel_profile:
-        ops.profile_begin()
+    if not args.no_kernel_profile:
+        # every rank runs this step (its backward holds collectives); only rank 0 records the per-launch events
+        if rank == 0:
+            ops.profile_begin()
         step()
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_kernel_profile:
         recs = ops.profile_end()
         if args.detail:
             agg = {}
