@@ -207,3 +207,28 @@ def test_pooled_stem_tail_backward_matches_three_phase_path(dtype):
         assert errs[-1][0] <= 2e-4, errs[-1]
     else:       # bf16: xhat is recovered from the bf16-ROUNDED pooled output; the 3-element ECA filters cancel heavily
         assert errs[len(errs) // 2][0] <= 2e-2 and errs[-1][0] <= 0.15, (errs[len(errs) // 2], errs[-1])
+
+
+def test_graph_captured_inference_matches_eager():
+    """pmoe_amd.infer.GraphedMixture: the eval-mode B=1 chain captured into a HIP graph replays
+    bit-identically, follows new inputs, and must be refreshed after a weight change."""
+    from pmoe_amd.infer import GraphedMixture
+    g = torch.load(GOLDEN / "g2_moe_e4_b1_224_eval.pt", weights_only=False)
+    _, _, model, inp = build_pair(g, torch.bfloat16)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    with torch.no_grad():
+        ref = [t.clone() for t in model.mixture_params(dev["images"], dev["speed"], dev["command"])]
+    gm = GraphedMixture(model, dev["images"], dev["speed"], dev["command"])
+    for a, b in zip(ref, gm(dev["images"], dev["speed"], dev["command"])):
+        assert torch.equal(a, b)
+    img2 = dev["images"].flip(-1).contiguous()
+    with torch.no_grad():
+        ref2 = [t.clone() for t in model.mixture_params(img2, dev["speed"], dev["command"])]
+    for a, b in zip(ref2, gm(img2, dev["speed"], dev["command"])):
+        assert torch.equal(a, b)
+    assert gm.sample(img2, dev["speed"], dev["command"]).shape == (1, 2)
+    with pytest.raises(ValueError, match="captured for input shape"):
+        gm(dev["images"][:, :, :, :64], dev["speed"], dev["command"])
+    model.train()
+    with pytest.raises(RuntimeError, match="eval"):
+        GraphedMixture(model, dev["images"], dev["speed"], dev["command"])
