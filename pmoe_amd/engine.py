@@ -14,6 +14,7 @@ into one flat f32 arena in backward order, which is also the data-parallel all-r
 (bucketed RCCL all-reduce launched while earlier layers are still in backward).
 """
 import itertools
+import os
 
 import torch
 import torch.distributed as dist
@@ -132,6 +133,8 @@ class ExpertGroupEngine:
         self.fuse_conv_stats = True
         self.fuse_stem_tail = True
         self.fold_stem_input = True
+        # weight gradients on a side stream, overlapped with the BatchNorm backward passes (PMOE_OVERLAP_WGRAD=0: off)
+        self.overlap_wgrad = os.environ.get("PMOE_OVERLAP_WGRAD", "1") != "0"
         self.pooled_stem_bwd = True   # stem-tail BatchNorm reductions from the pooled tensors (train mode)
         self.fold_eca_gate = True     # ECA gate folded into per-image conv weights (no gated activation in memory)
         self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tools/probe_layers.py)
@@ -372,7 +375,28 @@ class ExpertGroupEngine:
         if dy is None:
             return
         E = self.E
-        if layer.trainable:
+        if layer.trainable and self.overlap_wgrad:
+            # weight / bias gradients on a second HIP stream: they depend on nothing downstream, so the MFMA-bound
+            # wgrad kernel overlaps the HBM-bound BatchNorm-backward passes and the next data gradient of the main stream
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._wgrad_block(x, layer, o, dy, in_shared, flop)
+            x.t.record_stream(side)
+            dy.record_stream(side)
+        elif layer.trainable:
+            self._wgrad_block(x, layer, o, dy, in_shared, flop)
+        self._dgrad_block(x, layer, o, dy, flop)
+
+    def _side_stream(self):
+        st = self.__dict__.get("_side")
+        if st is None or st.device != self.dev:
+            st = self.__dict__["_side"] = torch.cuda.Stream(device=self.dev)
+        return st
+
+    def _wgrad_block(self, x, layer, o, dy, in_shared, flop):
+        E = self.E
+        if True:
             ckw = 64 if self.dtype == torch.bfloat16 else 32
             cpw = (layer.cinp + ckw - 1) // ckw * ckw
             cow = (layer.cout_st + ckw - 1) // ckw * ckw
@@ -402,6 +426,8 @@ class ExpertGroupEngine:
                     ra = parts[0][2]
                     self._grad_slot("b_part", (layer, "action_pred")).view(E, ra).copy_(sums[:, 0:ra])
                     self._grad_slot("b_part", (layer, "alpha")).view(E, layer.cout - ra).copy_(sums[:, ra:])
+
+    def _dgrad_block(self, x, layer, o, dy, flop):
         if x.needs_grad:
             prev = x.grad
             res, res_mode = None, hip.RES_NONE
@@ -673,7 +699,7 @@ class ExpertGroupEngine:
                 ckw = 64 if self.dtype == torch.bfloat16 else 32
                 cpw = (layer.cinp + ckw - 1) // ckw * ckw
                 cow = (layer.cout_st + ckw - 1) // ckw * ckw
-                G = self._wgrad_ws(N * layer.taps * cow * cpw)
+                G = self._wgrad_ws(N * layer.taps * cow * cpw, main=True)
                 G.zero_()
                 ops.set_meta(flop=flop, name=layer.name)
                 ops.conv2d_wgrad(x.t, dy, G, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=B_, ks=layer.ks,
@@ -731,10 +757,16 @@ class ExpertGroupEngine:
         return v
 
     # ------------------------------------------------------------------ gradient arena
-    def _wgrad_ws(self, numel):
-        if self._ws is None or self._ws.numel() < numel:
-            self._ws = torch.empty(numel, dtype=F32, device=self.dev)
-        return self._ws[:numel]
+    def _wgrad_ws(self, numel, main=False):
+        """f32 scratch of the weight-gradient kernels.  Two buffers: the per-layer wgrads may run on the side stream
+        (overlap_wgrad) while the per-image filter-gradient folds of the stem stay on the main stream."""
+        key = "_ws_main" if main else "_ws"
+        buf = self.__dict__.get(key)
+        if buf is None or buf.numel() < numel or buf.device != self.dev:
+            with torch.cuda.stream(torch.cuda.default_stream(self.dev)):      # owned by no transient stream's pool
+                buf = torch.empty(numel, dtype=F32, device=self.dev)
+            self.__dict__[key] = buf
+        return buf[:numel]
 
     @staticmethod
     def _key(kind, layer):
@@ -788,9 +820,6 @@ class ExpertGroupEngine:
         self._pack_all()
         self.tape, self._bn_touched = [], []
         self._seed_counter = itertools.count(1)       # dropout masks are a function of (base_seed, layer order)
-        self._ws = getattr(self, "_ws", None)
-        if self._ws is not None and self._ws.device != self.dev:
-            self._ws = None
 
         return Bsz
 
@@ -915,7 +944,7 @@ class ExpertGroupEngine:
         ckw = 64 if self.dtype == torch.bfloat16 else 32
         cpw = (layer.cinp + ckw - 1) // ckw * ckw
         cow = (layer.cout_st + ckw - 1) // ckw * ckw
-        G = self._wgrad_ws(self.N * layer.taps * cow * cpw)
+        G = self._wgrad_ws(self.N * layer.taps * cow * cpw, main=True)
         G.zero_()
         ops.set_meta(flop=2.0 * self.N * dy.shape[1] * dy.shape[2] * layer.cout * layer.cin * layer.taps, name=layer.name)
         ops.conv2d_wgrad(x0.t, dy, G, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B, ks=layer.ks,
@@ -975,13 +1004,29 @@ class ExpertGroupEngine:
             reducer = BucketedAllReduce(self.dp_group, self.dp_buckets)
             reducer.begin(self._arena)
         self._tail_bwd(tape_state["tail"], *douts)
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_wgrad else None
         for fn in reversed(tape):
             fn()
             if reducer is not None:
-                # every launch of the finished closures is enqueued: buckets below the prefix can fly
-                reducer.ready(self._final_prefix())
+                # every launch of the finished closures is enqueued (weight gradients possibly on the side stream):
+                # buckets below the prefix can fly once BOTH streams have reached this point
+                if side is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        reducer.ready(self._final_prefix())
+                else:
+                    reducer.ready(self._final_prefix())
         if reducer is not None:
-            reducer.finish()
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    reducer.finish()
+            else:
+                reducer.finish()
+        if side is not None:
+            main.wait_stream(side)
+            self._arena.record_stream(side)
         grads = {}
         for key, (off, n, plist) in self._slots.items():
             o = off
