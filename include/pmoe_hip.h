@@ -73,6 +73,12 @@ int pmoe_conv2d_igemm(const pmoe_conv_desc* d, void* stream);
 /* number of [2][coutp] partial-sum rows the launch writes to d->stats (rows of expert e are
  * contiguous: [e*rows/E, (e+1)*rows/E) ); <0 = error */
 int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
+/* which kernel instantiation pmoe_conv2d_igemm would run for this descriptor (nothing is launched; used by bench.py
+ * to attribute measured launch times to kernel symbols that a rocprofv3 kernel trace shows):
+ *   1000 + LOG_RB            conv3x3_res_kernel<LOG_RB>            (resident-filter kernel, conv_res.hip)
+ *   LOG_RB*100 + WM*10 + WN  conv_igemm_kernel<T, LOG_RB, WM, WN>  (halo-patch implicit GEMM, conv_igemm.hip)
+ *   4000 + the latter        the four parity-class launches of a stride-2 3x3 data gradient */
+int pmoe_conv2d_plan(const pmoe_conv_desc* d);
 
 /* Weight gradient of the same layers (autograd of nn.Conv2d / nn.Linear at the call sites above).
  * Accumulates into dw_ws [E][ks*ks][coutp][cinp] f32 with atomics: zero it first. */

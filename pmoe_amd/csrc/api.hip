@@ -63,6 +63,11 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d) {
     return conv_igemm_mblocks(to_args(d), d->dtype);
 }
 
+int pmoe_conv2d_plan(const pmoe_conv_desc* d) {
+    if (!d || d->ipe <= 0) return PMOE_ERR_ARG;
+    return conv_igemm_plan(to_args(d), d->dtype);
+}
+
 int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream) {
     if (!d || !d->x || !d->dy || !d->dw_ws || d->ipe <= 0) return PMOE_ERR_ARG;
     const int ve = d->dtype == PMOE_DT_BF16 ? 8 : 4;

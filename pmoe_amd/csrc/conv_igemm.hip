@@ -316,7 +316,7 @@ static int launch_cfg(const ConvArgs& a, int mblocks, size_t smem, hipStream_t s
     return (int)hipGetLastError();
 }
 
-template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* out_mblocks) {
+template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* out_mblocks, int* out_cfg = nullptr) {
     const int esz = (int)sizeof(T);
     if (a.Cin <= 0 || a.CoutP % 64 || a.Cout % (16 / esz) || a.Cin % (32 / esz)) return PMOE_ERR_ARG;
     if ((a.ks != 1 && a.ks != 3) || (a.stride != 1 && a.stride != 2) || (a.dilate && a.stride != 1)) return PMOE_ERR_ARG;
@@ -350,6 +350,7 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         a.tiles_y = (a.Ho + TH - 1) / TH;
         a.tiles_x = (a.Wo + TW - 1) / TW;
         const int mblocks = E * a.n_groups * a.tiles_y * a.tiles_x;
+        if (out_cfg) *out_cfg = log_rb * 100 + (wide ? (big ? 42 : 22) : 41);      // <T, LOG_RB, WM, WN> of the launch
         if (out_mblocks) { *out_mblocks = mblocks; return 0; }
         if (log_rb == 7 && big) return launch_cfg<T, 7, 4, 2>(a, mblocks, smem, st);
         if (log_rb == 6 && big) return launch_cfg<T, 6, 4, 2>(a, mblocks, smem, st);
@@ -402,6 +403,26 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
     if (dtype == PMOE_DT_BF16) return launch_dtype<bf16>(a, st, nullptr);
     if (dtype == PMOE_DT_F32) return launch_dtype<float>(a, st, nullptr);
     return PMOE_ERR_ARG;
+}
+
+// which kernel a descriptor runs on (no launch): 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; LOG_RB*100 + WM*10 + WN =
+// conv_igemm_kernel<T, LOG_RB, WM, WN>; + 4000 = the four parity-class launches of a stride-2 data gradient
+int conv_igemm_plan(const ConvArgs& a, int dtype) {
+    ConvArgs c = a;
+    int extra = 0;
+    if (a.dilate && a.ks == 3 && a.pad == 1 && a.kh == 3) {
+        c.dilate = 0; c.stride = 1; c.pad = 0; c.kh = c.kw = 2;
+        c.Ho = a.Ho / 2; c.Wo = a.Wo / 2; c.OH = a.Ho; c.OW = a.Wo; c.out_step = 2;
+        if (c.Ho <= 0 || c.Wo <= 0) return PMOE_ERR_ARG;
+        extra = 4000;
+    } else {
+        ResPlan plan;
+        if (conv_res_plan(a, dtype, &plan)) return 1000 + plan.log_rb;
+    }
+    int mb = 0, cfg = 0;
+    const int rc = dtype == PMOE_DT_BF16 ? launch_dtype<bf16>(c, nullptr, &mb, &cfg)
+                 : dtype == PMOE_DT_F32 ? launch_dtype<float>(c, nullptr, &mb, &cfg) : PMOE_ERR_ARG;
+    return rc ? rc : cfg + extra;
 }
 
 int conv_igemm_mblocks(const ConvArgs& a, int dtype) {

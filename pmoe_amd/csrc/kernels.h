@@ -45,4 +45,5 @@ struct WgradArgs {
 struct ResPlan;
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st);
 int conv_igemm_mblocks(const ConvArgs& a, int dtype);
+int conv_igemm_plan(const ConvArgs& a, int dtype);
 int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);

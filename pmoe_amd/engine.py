@@ -133,8 +133,10 @@ class ExpertGroupEngine:
         self.fuse_conv_stats = True
         self.fuse_stem_tail = True
         self.fold_stem_input = True
-        # weight gradients on a side stream, overlapped with the BatchNorm backward passes (PMOE_OVERLAP_WGRAD=0: off)
-        self.overlap_wgrad = os.environ.get("PMOE_OVERLAP_WGRAD", "1") != "0"
+        # weight gradients on a side HIP stream, overlapped with the BatchNorm backward passes and the next data gradient
+        # (+2 % step throughput at the headline shape).  Off by default: co-running kernels stretch each other, which
+        # makes per-kernel durations (bench.py roofline, rocprofv3 traces) meaningless; PMOE_OVERLAP_WGRAD=1 turns it on
+        self.overlap_wgrad = os.environ.get("PMOE_OVERLAP_WGRAD", "0") == "1"
         self.pooled_stem_bwd = True   # stem-tail BatchNorm reductions from the pooled tensors (train mode)
         self.fold_eca_gate = True     # ECA gate folded into per-image conv weights (no gated activation in memory)
         self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tools/probe_layers.py)

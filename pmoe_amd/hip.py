@@ -61,6 +61,7 @@ SIGNATURES = {
     "pmoe_abi_sizeof": [C.c_int],
     "pmoe_conv2d_igemm": [C.POINTER(ConvDesc), _P],
     "pmoe_conv2d_stat_rows": [C.POINTER(ConvDesc)],
+    "pmoe_conv2d_plan": [C.POINTER(ConvDesc)],
     "pmoe_conv2d_wgrad": [C.POINTER(WgradDesc), _P],
     "pmoe_pack_conv_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights_gated": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

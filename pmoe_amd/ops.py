@@ -55,6 +55,8 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
         raise ValueError("conv2d: input/output image counts differ")
     if w_packed.numel() < (n // ipe) * coutp * ks * ks * cin:
         raise ValueError("conv2d: packed weight tensor too small")
+    if _prof is not None:            # profiling: remember which kernel instantiation serves this launch
+        _launch_info["kernel"] = load().pmoe_conv2d_plan(C.byref(d))
     check(load().pmoe_conv2d_igemm(C.byref(d), stream_ptr()), "pmoe_conv2d_igemm")
     return out
 
@@ -305,6 +307,7 @@ import functools as _functools
 
 _prof = None
 _next_meta = {}
+_launch_info = {}        # filled by a wrapper during its launch (e.g. which conv kernel instantiation ran)
 
 
 def set_meta(**kw):
@@ -338,6 +341,9 @@ def _timed(fn):
         e0.record()
         r = fn(*a, **k)
         e1.record()
+        if _launch_info:
+            meta.update(_launch_info)
+            _launch_info.clear()
         _prof.append((fn.__name__, meta, e0, e1))
         return r
     return wrapper
