@@ -21,7 +21,9 @@ struct ResPlan {
     size_t smem;
 };
 
-template <int LOG_RB>
+// BIAS: per-expert (= per-image for the gate-folded layers) channel bias in the store path.  A separate instantiation,
+// so the register allocation of the common (bias-free) kernel is untouched.
+template <int LOG_RB, bool BIAS = false>
 __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, const int tiles_per_expert,
                                                          const int wgs_per_expert, const int region_bytes) {
     constexpr int RB = 1 << LOG_RB, CPR = RB / 16, LOG_CPR = LOG_RB - 4;
@@ -46,6 +48,9 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
     char* Wl = smem;                                     // [9][64][RB]
     char* region = smem + 9 * 64 * RB + grp * region_bytes;   // this half's patch / staging area
 
+    // per-expert channel bias: 64 floats in LDS behind the two regions (read in the store path; no registers held)
+    float* lbias = reinterpret_cast<float*>(smem + 9 * 64 * RB + 2 * region_bytes);
+    if (BIAS && tid < 64) lbias[tid] = a.bias[(size_t)e * a.CoutP + tid];
     // ---- resident filter bank of expert e
     {
         const bf16* wsrc = (const bf16*)a.w + (size_t)e * a.CoutP * 9 * a.Cin;
@@ -151,12 +156,27 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
             // ================= MFMA role: tile h =================
             const bool live = h < n;
             if (live) {
+                if (BIAS) {
+                    // accumulators start from the channel bias (acc[nt][*][4g+i] is cout (nt*4+g)*8 + hh*4 + i):
+                    // the store path stays that of the bias-free kernel
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + (i * 4 + g) * 8 + hh * 4);
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+                            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) acc[i][j][4 * g + k] = b[k];
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+                }
                 taps(0);
             }
             __syncthreads();
@@ -266,7 +286,8 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
 bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan) {
     if (dtype != PMOE_DT_BF16 || a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dilate) return false;
     if (a.CoutP != 64 || a.Cout % 8 || (a.Cin != 64 && a.Cin != 16)) return false;
-    if (a.act != PMOE_ACT_NONE || a.drop_p > 0.f || a.bias) return false;
+    if (a.act != PMOE_ACT_NONE || a.drop_p > 0.f) return false;
+    if (a.bias && (a.res_mode != PMOE_RES_NONE || a.Cin != 64)) return false;
     if (a.res_mode != PMOE_RES_NONE && a.res_mode != PMOE_RES_ADD) return false;
     if (a.N % a.ipe || a.Ho != a.H || a.Wo != a.W) return false;
     auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
@@ -282,7 +303,7 @@ bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan) {
     if (region < 256 * 128) region = 256 * 128;
     region = (region + 255) & ~(size_t)255;
     const size_t smem = (size_t)9 * 64 * rb + 2 * region;
-    if (smem > 163840) return false;
+    if (smem + (a.bias ? 256 : 0) > 163840) return false;
     const int E = a.N / a.ipe;
     plan->lTW = lTW; plan->lTH = lTH; plan->TN = TN;
     plan->n_groups = (a.ipe + TN - 1) / TN;
@@ -302,8 +323,16 @@ int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
     const int E = a.N / a.ipe;
     const int region = (int)((p.smem - (size_t)9 * 64 * (1 << p.log_rb)) / 2);
     dim3 grid(p.wgs_per_expert, E), block(512);
-    static bool attr7 = false, attr5 = false;
-    if (p.log_rb == 7) {
+    static bool attr7 = false, attr5 = false, attr7b = false;
+    if (p.log_rb == 7 && a.bias) {
+        if (!attr7b) {
+            HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_res_kernel<7, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+            attr7b = true;
+        }
+        hipLaunchKernelGGL((conv3x3_res_kernel<7, true>), grid, block, p.smem + 256, st, a, p.tiles_per_expert,
+                           p.wgs_per_expert, region);
+    } else if (p.log_rb == 7) {
         if (!attr7) {
             HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_res_kernel<7>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
