@@ -68,8 +68,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     const int Y0 = oy0 * a.stride - a.pad, X0 = ox0 * a.stride - a.pad;
     const int cout0 = blockIdx.y * BN;
 
-    char* patch = smem;
-    char* wbuf = smem + ((NPIX * RB + 255) & ~255);
+    // one halo-patch buffer, or two when the launcher asked for chunk prefetch (a.prefetch)
+    const int PB = (NPIX * RB + 255) & ~255;
+    char* patch0 = smem;
+    char* wbuf = smem + PB * (a.prefetch ? 2 : 1);
 
     int ppb[2];
 #pragma unroll
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     const T* in = (const T*)a.in;
     const bool one_batch = NPIX * CPR <= 12 * NTHR;     // every load of the patch in flight at once
     const bool big_batch = NPIX * CPR <= 20 * NTHR;     // stride-2 halos (17x33 pixels): one workgroup per CU anyway
-    auto load_patch = [&](int c0) {
+    auto load_patch = [&](char* patch, int c0) {
         if (one_batch) {
             PatchStage<T, LOG_RB, NTHR, 12> ps;
             ps.issue(in, geo, c0, tid);
@@ -138,10 +140,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     auto wtap = [&](int i) { return a.use_tapmap ? a.tapmap[i] : i; };
     w_issue(0, wtap(0));
     w_commit(0);
+    PatchStage<T, LOG_RB, NTHR, 6> nxt;             // prefetch registers (live across the tap loop only when a.prefetch)
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
-        load_patch(c0);
-        __syncthreads();
+        char* patch = a.prefetch ? patch0 + (ch & 1) * PB : patch0;
+        if (!a.prefetch || ch == 0) {
+            load_patch(patch, c0);
+            __syncthreads();
+        }
+        const bool more = a.prefetch && ch + 1 < nchunks;
+        if (more) nxt.issue(in, geo, c0 + CK, tid);      // in flight under this chunk's taps of MFMAs
         for (int r = 0; r < KH; ++r) {
             for (int q = 0; q < KW; ++q) {
                 const int tap = r * KW + q;
@@ -174,6 +182,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
                         for (int mt = 0; mt < 2; ++mt) Mma<T>::run(af[nt], bfr[mt], acc[nt][mt]);
                 }
                 if (!last) w_commit(cur ^ 1);
+                if (more && tap == NTAP - 1) nxt.template commit<0>(patch0 + ((ch + 1) & 1) * PB, NPIX, tid);
                 __syncthreads();
                 cur ^= 1;
             }
@@ -341,7 +350,14 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         const int TW = 1 << lTW, TH = 1 << lTH;
         const int lstride = a.ks == 1 ? 1 : a.stride;
         const int PW = (TW - 1) * lstride + a.kw, PH = (TH - 1) * lstride + a.kh;
-        size_t smem = (((size_t)TN * PH * PW * rb + 255) & ~(size_t)255) + 2 * (size_t)BN * rb;
+        const size_t pbytes = ((size_t)TN * PH * PW * rb + 255) & ~(size_t)255;
+        // chunk prefetch: 8-wave tile, >= 2 channel chunks, the whole patch in <= 6 vectors per thread (24 VGPRs)
+        const int nthr = big ? 512 : 256;
+        static int pf_on = -1;      // PMOE_CONV_PREFETCH=0: A/B switch
+        if (pf_on < 0) { const char* ev = getenv("PMOE_CONV_PREFETCH"); pf_on = ev ? atoi(ev) : 1; }
+        a.prefetch = pf_on && big && a.Cin / ck >= 2 && (size_t)TN * PH * PW * (rb / 16) <= (size_t)6 * nthr &&
+                     2 * pbytes + 2 * (size_t)BN * rb <= 150 * 1024;
+        size_t smem = pbytes * (a.prefetch ? 2 : 1) + 2 * (size_t)BN * rb;
         const size_t stg = (size_t)BM * BN * 4;
         if (smem < stg) smem = stg;
         if (smem > 150 * 1024) continue;
