@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.3, help="stage_2*.yaml value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--measure-overlap", action="store_true",
+                    help="also time the step with weight gradients on a side stream (co-running kernels: keep it out of "
+                         "runs that are profiled per kernel)")
     ap.add_argument("--detail", action="store_true", help="per-layer launch table on stderr")
     return ap.parse_args()
 
@@ -310,7 +313,7 @@ def main():
         del opt
 
     # ---- optional mode: weight gradients on a side stream (engine.overlap_wgrad), reported beside the standard path
-    if world == 1:
+    if world == 1 and args.measure_overlap:
         eng = model._engine()
         eng.overlap_wgrad = True
         step()

@@ -355,7 +355,8 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         const int nthr = big ? 512 : 256;
         static int pf_on = -1;      // PMOE_CONV_PREFETCH=0: A/B switch
         if (pf_on < 0) { const char* ev = getenv("PMOE_CONV_PREFETCH"); pf_on = ev ? atoi(ev) : 1; }
-        a.prefetch = pf_on && big && a.Cin / ck >= 2 && (size_t)TN * PH * PW * (rb / 16) <= (size_t)6 * nthr &&
+        // (also the expert MLP GEMMs: 1x1 "images", K = 512..1536 in 64-channel chunks -- a latency chain of 8..24 chunks)
+        a.prefetch = pf_on && (big || (a.H == 1 && a.W == 1 && a.ks == 1)) && a.Cin / ck >= 2 && (size_t)TN * PH * PW * (rb / 16) <= (size_t)6 * nthr &&
                      2 * pbytes + 2 * (size_t)BN * rb <= 150 * 1024;
         size_t smem = pbytes * (a.prefetch ? 2 : 1) + 2 * (size_t)BN * rb;
         const size_t stg = (size_t)BM * BN * 4;
