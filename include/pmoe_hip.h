@@ -137,9 +137,11 @@ int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const voi
                      const void* const* beta_ptrs, void* const* rmean_ptrs, void* const* rvar_ptrs, float momentum,
                      float eps, int32_t training, float* scale, float* shift, float* mean, float* invstd, int32_t E,
                      int32_t C, const float* shiftc, void* stream);
-/* y = [relu]( (x - mean)*scale + shift [+ res] ) */
+/* y = [relu]( (x - mean)*scale + shift [+ res] ); y is dense (y_ld = 0 or C) or the channel window
+ * [y_coff, y_coff + C) of rows y_ld wide -- the skip half of a U-Net concatenation buffer (unet.py:72) */
 int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, const float* mean,
-                  int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream);
+                  int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t y_ld, int32_t y_coff,
+                  int32_t dtype, void* stream);
 /* backward reduce: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat -> part [E][nparts][2][C].
  * y may be NULL when relu is set and the forward had no residual: the mask is then recomputed as
  * x*scale+shift > 0 and the saved output is not read at all (one tensor pass less). */

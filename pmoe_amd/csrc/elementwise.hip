@@ -197,7 +197,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                       T* __restrict__ y, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const float* __restrict__ mean,
-                                                      long long rpe, int C, int relu) {
+                                                      long long rpe, int C, int relu, int y_ld, int y_coff, int log_cv) {
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE;                       // power of two <= 256*gridDim.x: a thread keeps ONE channel vector
     const int e = blockIdx.y;
@@ -226,7 +226,9 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int k = 0; k < VE; ++k) xv[k] = fmaxf(xv[k], 0.f);
         }
-        stg16(y + off, pack16<T>(xv));
+        // dense output, or a channel window [y_coff, y_coff + C) of rows y_ld wide (skip-concatenation buffers)
+        const size_t yoff = y_ld == C ? off : ((size_t)e * rpe + (size_t)(i >> log_cv)) * y_ld + y_coff + (size_t)cv * VE;
+        stg16(y + yoff, pack16<T>(xv));
     }
 }
 
@@ -624,13 +626,19 @@ int pmoe_bn_bwd_finalize(const float* part, int32_t nparts, int64_t count, float
 }
 
 int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, const float* mean,
-                  int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream) {
+                  int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t y_ld, int32_t y_coff, int32_t dtype,
+                  void* stream) {
     DISPATCH_DT(dtype, {
         constexpr int VE = 16 / (int)sizeof(T);
         if (C % VE || !pow2(C / VE) || C / VE > 256) return PMOE_ERR_ARG;   // kernels keep one channel vector per thread
+        if (y_ld <= 0) { y_ld = C; y_coff = 0; }
+        if (y_ld % VE || y_coff % VE || y_coff + C > y_ld) return PMOE_ERR_ARG;
+        int log_cv = 0;
+        while ((1 << log_cv) < C / VE) ++log_cv;
         const long long nvec = rows_per_expert * (C / VE);
         hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(nvec, 2048), E), dim3(256), 0, (hipStream_t)stream,
-                           (const T*)x, (const T*)res, (T*)y, scale, shift, mean, (long long)rows_per_expert, C, relu);
+                           (const T*)x, (const T*)res, (T*)y, scale, shift, mean, (long long)rows_per_expert, C, relu,
+                           y_ld, y_coff, log_cv);
         return (int)hipGetLastError();
     });
 }

@@ -482,7 +482,7 @@ class ExpertGroupEngine:
                             self._tab("rv", layer), layer.momentum, layer.eps, False, scale, shift, mean, invstd, E, C_)
         return scale, shift, mean, invstd
 
-    def _bn(self, z, layer, relu, res=None, stats=None):
+    def _bn(self, z, layer, relu, res=None, stats=None, out=None, out_coff=0):
         """y = [relu](bn(z) [+ res]); train mode: batch statistics (fused conv partials or a colstats pass)."""
         E, C_ = self.E, layer.C
         n, h, w, _ = z.t.shape
@@ -490,9 +490,12 @@ class ExpertGroupEngine:
         if stats is not None and stats.shape[2] != C_:
             raise RuntimeError("fused stats width mismatch")
         scale, shift, mean, invstd = self._bn_coeffs(layer, rpe, stats, stats.shape[0] // E if stats is not None else 0, z)
-        y = Var(torch.empty_like(z.t))
+        # out: write into the channel window [out_coff, out_coff + C) of a wider buffer (U-Net skip concatenation)
+        y = Var(torch.empty_like(z.t)) if out is None else out.window(out_coff, C_)
+        if out is not None and self.taping:
+            raise RuntimeError("BatchNorm into a channel window is forward-only (frozen U-Nets)")
         ops.set_meta(name=layer.name, bytes=z.t.numel() * z.t.element_size() * (3 if res is not None else 2))
-        ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, mean, rpe, E, C_, relu)
+        ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, mean, rpe, E, C_, relu, y_coff=y.coff)
         y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
         if self.taping and y.needs_grad:
             train = self.training

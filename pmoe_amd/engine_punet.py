@@ -162,16 +162,16 @@ class PUNetEngine(ExpertGroupEngine):
                 m.running_var.copy_(l.shadow["rv"][:c])
 
     # ------------------------------------------------------------------ PU-Net forward
-    def _conv3(self, x, blk):
+    def _conv3(self, x, blk, out=None):
         z, st = self._conv_stats(x, blk["c1"])
         a = self._bn(z, blk["bn1"], relu=True, stats=st)
         z, st = self._conv_stats(a, blk["c2"])
-        return self._bn(z, blk["bn2"], relu=True, stats=st)
+        return self._bn(z, blk["bn2"], relu=True, stats=st, out=out)
 
     def _maxpool2(self, x):
-        n, h, w, c = x.t.shape
-        y = Var(self._new(n, h // 2, w // 2, c))
-        ops.maxpool2_fwd(x.t, y.t)
+        n, h, w, _ = x.t.shape
+        y = Var(self._new(n, h // 2, w // 2, x.c))
+        ops.maxpool2_fwd(x.t, y.t, c=x.c, x_coff=x.coff)      # x may be the skip window of a concatenation buffer
         return y
 
     def _unet_fwd(self, U, x):
@@ -182,13 +182,14 @@ class PUNetEngine(ExpertGroupEngine):
             raise NotImplementedError("UNet on the HIP path needs H and W divisible by 16 (no output_padding rows in "
                                       "the transposed convolutions); the reference configs use 224/256")
         cats, h = [], x
+        hh, ww = H, W
         for i in range(4):
-            a = self._conv3(h, U["dwn"][i])
-            c = a.t.shape[-1]
-            cat = Var(self._new(n, a.t.shape[1], a.t.shape[2], 2 * c))      # torch.cat([x_k, up], 1) buffer (unet.py:72)
-            ops.copy_window(a.t, 0, cat.t, 0, c)
+            c = U["dwn"][i]["c2"].cout
+            cat = Var(self._new(n, hh, ww, 2 * c))          # torch.cat([x_k, up], 1) buffer (unet.py:72)
+            a = self._conv3(h, U["dwn"][i], out=cat)       # the block's last BatchNorm writes the skip half directly
             cats.append(cat)
             h = self._maxpool2(a)
+            hh, ww = hh // 2, ww // 2
         x5 = h = self._conv3(h, U["dwn"][4])
         for j in range(4):
             cat, up = cats[3 - j], U["up"][j]

@@ -132,11 +132,11 @@ def bn_finalize(part, nparts, count, gamma_tab, beta_tab, rmean_tab, rvar_tab, m
                                   ptr(shiftc, "shiftc", f32), stream_ptr()), "pmoe_bn_finalize")
 
 
-def bn_apply(x, res, y, scale, shift, mean, rpe, E, C_, relu):
-    """y = [relu]((x - mean)*scale + shift [+ res]); shift is the BN beta (bn_finalize's output)."""
+def bn_apply(x, res, y, scale, shift, mean, rpe, E, C_, relu, y_coff=0):
+    """y[..., y_coff:y_coff+C] = [relu]((x - mean)*scale + shift [+ res]); shift is the BN beta (bn_finalize's output)."""
     check(load().pmoe_bn_apply(ptr(x, "x"), ptr(res, "res", x.dtype), ptr(y, "y", x.dtype), ptr(scale), ptr(shift),
                                ptr(mean, "mean", torch.float32), rpe,
-                               E, C_, int(relu), dt(x), stream_ptr()), "pmoe_bn_apply")
+                               E, C_, int(relu), y.shape[-1], y_coff, dt(x), stream_ptr()), "pmoe_bn_apply")
 
 
 def bn_bwd_reduce(dy, y, x, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts):
