@@ -307,6 +307,7 @@ def main():
     only = set(sys.argv[1:])          # optional: regenerate just the named cases
     cases.append(("g6_moeshared_k4_b6_96", "moe_shared", 4, 6, 96, True, 3))
     cases.append(("g7_moeshared_k6_b1_224_eval", "moe_shared", 6, 1, 224, False, 0))
+    cases.append(("g10_moe_e4_b32_64", "moe", 4, 32, 64, True, 0))      # realistic batch statistics (bf16 tolerance case)
     cases.append(("g8_moeshared_k3_b4_128", "moe_shared", 3, 4, 128, True, 0))
     cases.append(("g9_moeshared_k5_b8_64", "moe_shared", 5, 8, 64, True, 0))
     for name, t, e, b, s, train, steps in cases:

@@ -22,7 +22,7 @@ def _run(g):
     return cfg, model, inp
 
 
-CASES = ["g1_moe_e4_b2_128", "g3_moe_e8_b2_128", "g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g6_moeshared_k4_b6_96",
+CASES = ["g1_moe_e4_b2_128", "g3_moe_e8_b2_128", "g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g10_moe_e4_b32_64", "g6_moeshared_k4_b6_96",
          "g8_moeshared_k3_b4_128", "g9_moeshared_k5_b8_64"]
 
 
