@@ -61,3 +61,24 @@ def test_no_cpu_fallback(lib):
     x = torch.zeros(1, 4, 4, 16)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.maxpool_fwd(x, torch.zeros(1, 2, 2, 16), torch.zeros(1, 2, 2, 16, dtype=torch.uint8))
+
+
+def test_conv_plan_reports_the_kernel_instantiation():
+    """pmoe_conv2d_plan (bench.py uses it to attribute launch times to rocprof kernel symbols)."""
+    import ctypes as C
+    from pmoe_amd.hip import ConvDesc, load
+
+    def plan(cin, cout, H, ks, stride, dtype, B=64, E=4, dilate=False, Hout=None):
+        d = ConvDesc()
+        pad = ks // 2
+        Ho = Hout or (H + 2 * pad - ks) // stride + 1
+        d.n, d.h, d.w_, d.cin, d.ho, d.wo, d.cout, d.coutp = E * B, H, H, cin, Ho, Ho, cout, (cout + 63) // 64 * 64
+        d.in_ld, d.out_ld, d.ipe, d.ks, d.stride, d.pad, d.dilate = cin, cout, B, ks, stride, pad, int(dilate)
+        d.dtype = 0 if dtype == torch.bfloat16 else 1
+        return load().pmoe_conv2d_plan(C.byref(d))
+    assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1007                 # conv3x3_res_kernel<7>
+    assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1005                 # 12(16)-channel stem on the resident kernel
+    assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 742                 # conv_igemm_kernel<bf16,7,4,2>
+    assert plan(256, 256, 32, 3, 1, torch.float32) == 722                  # f32: 4-wave 128x128 tile, 32-channel chunks
+    assert plan(1536, 512, 1, 1, 1, torch.bfloat16) == 722                 # expert MLP GEMM: 4-wave tile
+    assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 4741   # stride-2 dgrad: 4 class launches <7,4,1>
