@@ -5,6 +5,7 @@ import re
 from pathlib import Path
 
 import pytest
+import torch
 
 from pmoe_amd import hip
 
