@@ -398,36 +398,35 @@ class ExpertGroupEngine:
 
     def _wgrad_block(self, x, layer, o, dy, in_shared, flop):
         E = self.E
-        if True:
-            ckw = 64 if self.dtype == torch.bfloat16 else 32
-            cpw = (layer.cinp + ckw - 1) // ckw * ckw
-            cow = (layer.cout_st + ckw - 1) // ckw * ckw
-            ws = self._wgrad_ws(E * layer.taps * cow * cpw)
-            ws.zero_()
-            ops.set_meta(flop=flop, name=layer.name)
-            ops.conv2d_wgrad(x.t, dy, ws, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B,
-                             ks=layer.ks, stride=layer.stride, pad=layer.pad, x_shared=in_shared, x_coff=x.coff,
-                             dy_coff=o.coff)
-            parts = getattr(layer, "parts", None)
+        ckw = 64 if self.dtype == torch.bfloat16 else 32
+        cpw = (layer.cinp + ckw - 1) // ckw * ckw
+        cow = (layer.cout_st + ckw - 1) // ckw * ckw
+        ws = self._wgrad_ws(E * layer.taps * cow * cpw)
+        ws.zero_()
+        ops.set_meta(flop=flop, name=layer.name)
+        ops.conv2d_wgrad(x.t, dy, ws, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B,
+                         ks=layer.ks, stride=layer.stride, pad=layer.pad, x_shared=in_shared, x_coff=x.coff,
+                         dy_coff=o.coff)
+        parts = getattr(layer, "parts", None)
+        if parts is None:
+            ops.unpack_conv_wgrad(ws, self._grad_slot("w", layer), E, layer.cout, layer.cin, layer.ks, cow, cpw)
+        else:
+            full = torch.empty(E, layer.cout, layer.cin, dtype=F32, device=self.dev)
+            ops.unpack_conv_wgrad(ws, full, E, layer.cout, layer.cin, 1, cow, cpw)
+            ra = parts[0][2]
+            self._grad_slot("w_part", (layer, "action_pred")).view(E, ra, layer.cin).copy_(full[:, 0:ra])
+            self._grad_slot("w_part", (layer, "alpha")).view(E, layer.cout - ra, layer.cin).copy_(full[:, ra:])
+        if layer.biases is not None:
+            rpe = self.B * dy.shape[1] * dy.shape[2]
+            part = torch.empty(E, 1, 2, layer.cout_st, dtype=F32, device=self.dev)
+            ops.colstats(rpe, dy, E, layer.cout_st, part, 1, ld=dy.shape[-1], coff=o.coff)
+            sums = part[:, 0, 0, :layer.cout]
             if parts is None:
-                ops.unpack_conv_wgrad(ws, self._grad_slot("w", layer), E, layer.cout, layer.cin, layer.ks, cow, cpw)
+                self._grad_slot("b", layer).view(E, layer.cout).copy_(sums)
             else:
-                full = torch.empty(E, layer.cout, layer.cin, dtype=F32, device=self.dev)
-                ops.unpack_conv_wgrad(ws, full, E, layer.cout, layer.cin, 1, cow, cpw)
                 ra = parts[0][2]
-                self._grad_slot("w_part", (layer, "action_pred")).view(E, ra, layer.cin).copy_(full[:, 0:ra])
-                self._grad_slot("w_part", (layer, "alpha")).view(E, layer.cout - ra, layer.cin).copy_(full[:, ra:])
-            if layer.biases is not None:
-                rpe = self.B * dy.shape[1] * dy.shape[2]
-                part = torch.empty(E, 1, 2, layer.cout_st, dtype=F32, device=self.dev)
-                ops.colstats(rpe, dy, E, layer.cout_st, part, 1, ld=dy.shape[-1], coff=o.coff)
-                sums = part[:, 0, 0, :layer.cout]
-                if parts is None:
-                    self._grad_slot("b", layer).view(E, layer.cout).copy_(sums)
-                else:
-                    ra = parts[0][2]
-                    self._grad_slot("b_part", (layer, "action_pred")).view(E, ra).copy_(sums[:, 0:ra])
-                    self._grad_slot("b_part", (layer, "alpha")).view(E, layer.cout - ra).copy_(sums[:, ra:])
+                self._grad_slot("b_part", (layer, "action_pred")).view(E, ra).copy_(sums[:, 0:ra])
+                self._grad_slot("b_part", (layer, "alpha")).view(E, layer.cout - ra).copy_(sums[:, ra:])
 
     def _dgrad_block(self, x, layer, o, dy, flop):
         if x.needs_grad:
