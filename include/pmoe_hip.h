@@ -106,6 +106,13 @@ int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
 int pmoe_pack_conv_weights(const void* const* src_ptrs, void* fwd, void* dgrd, int32_t E, int32_t cout,
                            int32_t cin, int32_t ks, int32_t coutp, int32_t cinp, int32_t cinp2, int32_t coutp2,
                            int32_t dtype, void* stream);
+/* Inference (callers autoagents/image_agent.py:127-177, the validation loop train_2.py:245-275):
+ * eval-mode BatchNorm folded into the preceding convolution, bn(conv(x, W)) = conv(x, W * s) + (beta - mean * s) with
+ * s = gamma / sqrt(running_var + eps).  scale / shift / mean: [E][cout] f32 as produced by pmoe_bn_finalize(training=0);
+ * fwd [E][coutp][ks*ks][cinp], bias [E][coutp] f32 (the conv then runs with bias + ReLU / residual in its epilogue). */
+int pmoe_pack_conv_weights_scaled(const void* const* src_ptrs, const float* scale, const float* shift, const float* mean,
+                                  void* fwd, float* bias, int32_t E, int32_t cout, int32_t cin, int32_t ks, int32_t coutp,
+                                  int32_t cinp, int32_t dtype, void* stream);
 /* Per-IMAGE weight packs with the ECA gate folded in (basics.py:69-76 in front of basics.py:113):
  * conv(x * g[n,c], W) == conv(x, W * g[n,c]); the convolution then runs with ipe = 1 (one "expert" per image) on
  * fwd [N][coutp][ks*ks][cinp] / dgrd [N][cinp2][ks*ks][coutp2] and the gated activation is never written.

@@ -66,6 +66,30 @@ __global__ void __launch_bounds__(256) pack_w_gated_kernel(const float* const* _
     }
 }
 
+// Inference: eval-mode BatchNorm folded into the preceding conv:
+//   bn(conv(x, W)) = conv(x, W * s[co]) + (beta - mean * s),   s = gamma / sqrt(running_var + eps)
+// fwd[e][co][tap][ci] = W[e][co][ci][tap] * scale[e][co];  bias[e][co] = shift[e][co] - mean[e][co] * scale[e][co]
+template <typename T>
+__global__ void __launch_bounds__(256) pack_w_scaled_kernel(const float* const* __restrict__ src,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, T* __restrict__ fwd,
+                                                           float* __restrict__ bias, int cout, int cin, int taps, int coutp,
+                                                           int cinp) {
+    const int e = blockIdx.y;
+    const float* s = src[e];
+    const long long nf = (long long)coutp * taps * cinp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nf; i += (long long)gridDim.x * 256) {
+        const int ci = (int)(i % cinp);
+        long long t = i / cinp;
+        const int tp = (int)(t % taps);
+        const int co = (int)(t / taps);
+        const float v = (co < cout && ci < cin) ? s[((size_t)co * cin + ci) * taps + tp] * scale[e * cout + co] : 0.f;
+        fwd[(size_t)e * nf + i] = from_f32<T>(v);
+    }
+    for (int co = blockIdx.x * 256 + threadIdx.x; co < coutp; co += gridDim.x * 256)
+        bias[e * coutp + co] = co < cout ? shift[e * cout + co] - mean[e * cout + co] * scale[e * cout + co] : 0.f;
+}
+
 __global__ void __launch_bounds__(256) unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ g, int cout,
                                                           int cin, int taps, int coutp, int cinp) {
     const int e = blockIdx.y;
@@ -360,6 +384,24 @@ int pmoe_pack_conv_weights_gated(const void* const* src_ptrs, const float* gate,
         hipLaunchKernelGGL((pack_w_gated_kernel<float>), dim3((int)g, N), dim3(256), 0, (hipStream_t)stream,
                            (const float* const*)src_ptrs, gate, gate_ld, (float*)fwd, (float*)dgrd, ipe, cout, cin, taps, coutp,
                            cinp, cinp2, coutp2);
+    else
+        return PMOE_ERR_ARG;
+    return (int)hipGetLastError();
+}
+
+int pmoe_pack_conv_weights_scaled(const void* const* src_ptrs, const float* scale, const float* shift, const float* mean,
+                                  void* fwd, float* bias, int32_t E, int32_t cout, int32_t cin, int32_t ks, int32_t coutp,
+                                  int32_t cinp, int32_t dtype, void* stream) {
+    if (E < 1 || coutp < cout || cinp < cin || !scale || !shift || !mean || !fwd || !bias) return PMOE_ERR_ARG;
+    const int taps = ks * ks;
+    long long g = ((long long)coutp * taps * cinp + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (dtype == PMOE_DT_BF16)
+        hipLaunchKernelGGL((pack_w_scaled_kernel<bf16>), dim3((int)g, E), dim3(256), 0, (hipStream_t)stream,
+                           (const float* const*)src_ptrs, scale, shift, mean, (bf16*)fwd, bias, cout, cin, taps, coutp, cinp);
+    else if (dtype == PMOE_DT_F32)
+        hipLaunchKernelGGL((pack_w_scaled_kernel<float>), dim3((int)g, E), dim3(256), 0, (hipStream_t)stream,
+                           (const float* const*)src_ptrs, scale, shift, mean, (float*)fwd, bias, cout, cin, taps, coutp, cinp);
     else
         return PMOE_ERR_ARG;
     return (int)hipGetLastError();

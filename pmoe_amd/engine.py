@@ -137,6 +137,7 @@ class ExpertGroupEngine:
         # (+2 % step throughput at the headline shape).  Off by default: co-running kernels stretch each other, which
         # makes per-kernel durations (bench.py roofline, rocprofv3 traces) meaningless; PMOE_OVERLAP_WGRAD=1 turns it on
         self.overlap_wgrad = os.environ.get("PMOE_OVERLAP_WGRAD", "0") == "1"
+        self.fold_bn_eval = True      # inference: eval-mode BatchNorm folded into the conv weights / epilogue
         self.pooled_stem_bwd = True   # stem-tail BatchNorm reductions from the pooled tensors (train mode)
         self.fold_eca_gate = True     # ECA gate folded into per-image conv weights (no gated activation in memory)
         self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tools/probe_layers.py)
@@ -852,10 +853,10 @@ class ExpertGroupEngine:
             z1, st = self._conv_stats(x0s, self.conv1, tape=False)
             z1.needs_grad = True
             self.tape.append(lambda: self._stem_in_bwd(x0, z1, gate, gapmean))
+            a1 = self._bn(z1, self.bn_c1, relu=True, stats=st)
         else:
             x0s = self._eca(x0, self.eca1, shared=True)
-            z1, st = self._conv_stats(x0s, self.conv1)
-        a1 = self._bn(z1, self.bn_c1, relu=True, stats=st)
+            a1 = self._conv_bn(x0s, self.conv1, self.bn_c1, relu=True)
         if self.fold_eca_gate and hw_ok and self.conv2.cin % 64 == 0:
             z2, st = self._eca_conv_folded(a1, self.eca2, self.conv2)
         else:
@@ -868,15 +869,43 @@ class ExpertGroupEngine:
             a3 = self._bn(a2, self.bn1, relu=True)             # torchvision bn1 + relu stay after the stem
             o = self._maxpool(a3)
         for blk in self.blocks:
-            zA, st = self._conv_stats(o, blk["conv1"])
-            aA = self._bn(zA, blk["bn1"], relu=True, stats=st)
-            zB, st = self._conv_stats(aA, blk["conv2"])
+            aA = self._conv_bn(o, blk["conv1"], blk["bn1"], relu=True)
             idn = o
             if blk["down"] is not None:
-                zD, std_ = self._conv_stats(o, blk["down"][0])
-                idn = self._bn(zD, blk["down"][1], relu=False, stats=std_)
-            o = self._bn(zB, blk["bn2"], relu=True, res=idn, stats=st)
+                idn = self._conv_bn(o, blk["down"][0], blk["down"][1], relu=False)
+            o = self._conv_bn(aA, blk["conv2"], blk["bn2"], relu=True, res=idn)
         self._gap_to(o, feat, 0)
+
+    def _conv_bn(self, x, conv, bn, relu, res=None, out=None):
+        """[relu](bn(conv(x)) [+ res]).  Training / taped: conv (+ fused statistics) then the BatchNorm passes.
+        Inference (eval mode, nothing taped): the BatchNorm is FOLDED into the conv -- weights scaled per output channel,
+        beta - mean*scale as the bias, residual add and ReLU in the conv epilogue: no pass over the activation at all."""
+        if self.training or self.taping or not self.fold_bn_eval:
+            z, st = self._conv_stats(x, conv)
+            return self._bn(z, bn, relu=relu, res=res, stats=st, out=out)
+        E = self.E
+        key = (self.dtype, str(self.dev)) + tuple(p._version for p in conv.weights) + tuple(
+            v for m in bn.mods for v in (m.weight._version, m.bias._version, m.running_mean._version, m.running_var._version))
+        cache = conv.__dict__.get("_bn_fold")
+        if cache is None or cache[0] != key:
+            scale, shift, mean, _ = self._bn_coeffs(bn, 1)
+            wf = torch.empty(E, conv.coutp, conv.taps, conv.cinp, dtype=self.dtype, device=self.dev)
+            bf = torch.empty(E, conv.coutp, dtype=F32, device=self.dev)
+            ops.pack_conv_weights_scaled(self._tab("w", conv), scale, shift, mean, wf, bf, E, conv.cout, conv.cin, conv.ks,
+                                         conv.coutp, conv.cinp, self.dtype)
+            cache = conv.__dict__["_bn_fold"] = (key, wf, bf)
+        _, wf, bf = cache
+        H, W = x.t.shape[1], x.t.shape[2]
+        Ho = ops.conv_out_size(H, conv.ks, conv.stride, conv.pad)
+        Wo = ops.conv_out_size(W, conv.ks, conv.stride, conv.pad)
+        o = Var(self._new(self.N, Ho, Wo, conv.cout_st), conv.cout_st, 0) if out is None else out.window(0, conv.cout_st)
+        ops.set_meta(flop=2.0 * self.N * Ho * Wo * conv.cout * conv.cin * conv.taps, name=conv.name + "+bn")
+        ops.conv2d(x.t, wf, o.t, cin=conv.cinp, cout=conv.cout_st, coutp=conv.coutp, ipe=self.B, ks=conv.ks,
+                   stride=conv.stride, pad=conv.pad, in_shared=(x.t.shape[0] != self.N), in_coff=x.coff, out_coff=o.coff,
+                   bias=bf,
+                   act=hip.ACT_RELU if relu else hip.ACT_NONE, res=res.t if res is not None else None,
+                   res_coff=res.coff if res is not None else 0, res_mode=hip.RES_ADD)
+        return o
 
     def _heads_fwd(self, feat, Bsz, training):
         E = self.E

@@ -163,10 +163,8 @@ class PUNetEngine(ExpertGroupEngine):
 
     # ------------------------------------------------------------------ PU-Net forward
     def _conv3(self, x, blk, out=None):
-        z, st = self._conv_stats(x, blk["c1"])
-        a = self._bn(z, blk["bn1"], relu=True, stats=st)
-        z, st = self._conv_stats(a, blk["c2"])
-        return self._bn(z, blk["bn2"], relu=True, stats=st, out=out)
+        a = self._conv_bn(x, blk["c1"], blk["bn1"], relu=True)
+        return self._conv_bn(a, blk["c2"], blk["bn2"], relu=True, out=out)
 
     def _maxpool2(self, x):
         n, h, w, _ = x.t.shape
@@ -202,8 +200,7 @@ class PUNetEngine(ExpertGroupEngine):
         eb = self.entry
         self.training = self.pu.entry_block.training
         a = self._eca(masks, eb["eca1"], shared=False)
-        z, st = self._conv_stats(a, eb["conv1"])
-        a = self._bn(z, eb["bn1"], relu=True, stats=st)
+        a = self._conv_bn(a, eb["conv1"], eb["bn1"], relu=True)
         a = self._eca(a, eb["eca2"], shared=False)
         z = self._conv(a, eb["conv2"], bias=False)       # 3 real channels: centred colstats pass (no fused epilogue stats)
         return self._bn(z, eb["bn2"], relu=True)

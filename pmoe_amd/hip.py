@@ -64,6 +64,7 @@ SIGNATURES = {
     "pmoe_conv2d_plan": [C.POINTER(ConvDesc)],
     "pmoe_conv2d_wgrad": [C.POINTER(WgradDesc), _P],
     "pmoe_pack_conv_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_pack_conv_weights_scaled": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights_gated": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_unpack_conv_wgrad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_bias": [_P, _P, _I, _I, _I, _P],

@@ -95,6 +95,14 @@ def pack_conv_weights(ptr_tab, fwd, dgrd, E, cout, cin, ks, coutp, cinp, cinp2, 
           "pmoe_pack_conv_weights")
 
 
+def pack_conv_weights_scaled(ptr_tab, scale, shift, mean, fwd, bias, E, cout, cin, ks, coutp, cinp, dtype):
+    f32 = torch.float32
+    check(load().pmoe_pack_conv_weights_scaled(ptr(ptr_tab, "ptr table", torch.int64), ptr(scale, "scale", f32),
+                                               ptr(shift, "shift", f32), ptr(mean, "mean", f32), ptr(fwd),
+                                               ptr(bias, "bias", f32), E, cout, cin, ks, coutp, cinp, hip._TORCH_DT[dtype],
+                                               stream_ptr()), "pmoe_pack_conv_weights_scaled")
+
+
 def pack_conv_weights_gated(ptr_tab, gate, fwd, dgrd, N, ipe, cout, cin, ks, coutp, cinp, cinp2, coutp2, dtype):
     check(load().pmoe_pack_conv_weights_gated(ptr(ptr_tab, "ptr table", torch.int64), ptr(gate, "gate", torch.float32),
                                               gate.shape[-1], ptr(fwd), ptr(dgrd), N, ipe, cout, cin, ks, coutp, cinp, cinp2,
@@ -349,7 +357,7 @@ def _timed(fn):
     return wrapper
 
 
-for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "stem_tail_pooled", "stem_tail_combine", "conv2d", "conv2d_wgrad", "pack_conv_weights", "pack_conv_weights_gated", "unpack_conv_wgrad", "pack_bias", "colstats",
+for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "stem_tail_pooled", "stem_tail_combine", "conv2d", "conv2d_wgrad", "pack_conv_weights", "pack_conv_weights_scaled", "pack_conv_weights_gated", "unpack_conv_wgrad", "pack_bias", "colstats",
            "reduce_partials", "bn_finalize", "bn_apply", "bn_bwd_reduce", "bn_bwd_finalize", "bn_bwd_apply",
            "maxpool_fwd", "maxpool_bwd", "gap_partial", "gap_finish", "gap_bwd", "eca_gate", "eca_scale",
            "eca_bwd_small", "eca_bwd_apply", "eca_stem_fold", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",
