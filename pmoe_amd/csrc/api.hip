@@ -15,7 +15,7 @@ static ConvArgs to_args(const pmoe_conv_desc* d) {
     a.drop_p = d->drop_p; a.seed = d->seed;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = 0;
     a.kh = a.kw = d->ks; a.use_tapmap = 0; a.tapmap[0] = a.tapmap[1] = a.tapmap[2] = a.tapmap[3] = 0;
-    a.out_step = 1; a.out_offy = a.out_offx = 0; a.OH = d->ho; a.OW = d->wo; a.prefetch = 0;
+    a.out_step = 1; a.out_offy = a.out_offx = 0; a.OH = d->ho; a.OW = d->wo; a.prefetch = 0; a.stagger = 0;
     return a;
 }
 

@@ -119,15 +119,17 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     geo.H = a.H; geo.W = a.W; geo.ld = a.in_ld; geo.coff = a.in_coff; geo.cmax = a.Cin;
     geo.dilate = a.dilate; geo.shared = a.in_shared; geo.step = step;
     const T* in = (const T*)a.in;
-    const bool one_batch = NPIX * CPR <= 12 * NTHR;     // every load of the patch in flight at once
-    const bool big_batch = NPIX * CPR <= 20 * NTHR;     // stride-2 halos (17x33 pixels): one workgroup per CU anyway
+    // vectors per thread held in registers while a patch is in flight: the 8-wave tile needs half as many per thread
+    constexpr int MV1 = NTHR == 512 ? 6 : 12, MV2 = NTHR == 512 ? 10 : 20;
+    const bool one_batch = NPIX * CPR <= MV1 * NTHR;    // every load of the patch in flight at once
+    const bool big_batch = NPIX * CPR <= MV2 * NTHR;    // stride-2 halos (17x33 / 33x33 pixels)
     auto load_patch = [&](char* patch, int c0) {
         if (one_batch) {
-            PatchStage<T, LOG_RB, NTHR, 12> ps;
+            PatchStage<T, LOG_RB, NTHR, MV1> ps;
             ps.issue(in, geo, c0, tid);
             ps.template commit<0>(patch, NPIX, tid);
         } else if (big_batch) {
-            PatchStage<T, LOG_RB, NTHR, 20> ps;
+            PatchStage<T, LOG_RB, NTHR, MV2> ps;
             ps.issue(in, geo, c0, tid);
             ps.template commit<0>(patch, NPIX, tid);
         } else {
@@ -141,6 +143,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     w_issue(0, wtap(0));
     w_commit(0);
     PatchStage<T, LOG_RB, NTHR, 6> nxt;             // prefetch registers (live across the tap loop only when a.prefetch)
+    // Stagger (MI355X_MICROARCH.md "two waves that run the same program"): waves 4-7 -- the SIMD partners of waves 0-3 in the
+    // 8-wave tile -- hold back the MFMAs of each tap's LAST k-substep and issue them after the barrier, i.e. under the
+    // partners' first LDS reads of the next tap, so the two waves of a SIMD stop reaching MFMA bursts, LDS bursts and
+    // barriers in lockstep.  Fragments wait in registers; results are bit-identical (same MFMAs, same order per accumulator).
+    const bool stag = (WM * WN == 8) && wave >= 4 && a.stagger;
+    constexpr int NDEF = KSUB >= 2 ? KSUB / 2 : 1;      // k-substeps held back: half a tap
+    v4i paf[NDEF][2], pbf[NDEF][2];
+    bool pend = false;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
         char* patch = a.prefetch ? patch0 + (ch & 1) * PB : patch0;
@@ -165,6 +175,15 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
                     pp[mt] = ppb[mt] + tapoff;
                     fp[mt] = swz<LOG_RB>(pp[mt]);
                 }
+                if (pend) {
+#pragma unroll
+                    for (int d = 0; d < NDEF; ++d)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt) Mma<T>::run(paf[d][nt], pbf[d][mt], acc[nt][mt]);
+                    pend = false;
+                }
 #pragma unroll
                 for (int ks = 0; ks < KSUB; ++ks) {
                     v4i af[2], bfr[2];
@@ -176,10 +195,16 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
                         bfr[mt] = *reinterpret_cast<const v4i*>(patch + pp[mt] * RB + (((ks * 2 + h) ^ fp[mt]) << 4));
+                    if (stag && ks >= KSUB - NDEF) {
+                        const int d = ks - (KSUB - NDEF);
+                        paf[d][0] = af[0]; paf[d][1] = af[1]; pbf[d][0] = bfr[0]; pbf[d][1] = bfr[1];
+                        pend = true;
+                    } else {
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) Mma<T>::run(af[nt], bfr[mt], acc[nt][mt]);
+                            for (int mt = 0; mt < 2; ++mt) Mma<T>::run(af[nt], bfr[mt], acc[nt][mt]);
+                    }
                 }
                 if (!last) w_commit(cur ^ 1);
                 if (more && tap == NTAP - 1) nxt.template commit<0>(patch0 + ((ch + 1) & 1) * PB, NPIX, tid);
@@ -189,6 +214,14 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
         }
     }
 
+    if (pend) {
+#pragma unroll
+        for (int d = 0; d < NDEF; ++d)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) Mma<T>::run(paf[d][nt], pbf[d][mt], acc[nt][mt]);
+    }
     // ---- epilogue: D[cout][pixel] -> LDS f32 [BM][BN] (16B units XOR-swizzled by pixel) ----
     constexpr int UPR = BN / 4;
     float* stg = reinterpret_cast<float*>(smem);
@@ -353,6 +386,9 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         const size_t pbytes = ((size_t)TN * PH * PW * rb + 255) & ~(size_t)255;
         // chunk prefetch: 8-wave tile, >= 2 channel chunks, the whole patch in <= 6 vectors per thread (24 VGPRs)
         const int nthr = big ? 512 : 256;
+        static int stg_on = -1;     // PMOE_CONV_STAGGER=0: A/B switch
+        if (stg_on < 0) { const char* ev = getenv("PMOE_CONV_STAGGER"); stg_on = ev ? atoi(ev) : 1; }
+        a.stagger = stg_on && big;
         static int pf_on = -1;      // PMOE_CONV_PREFETCH=0: A/B switch
         if (pf_on < 0) { const char* ev = getenv("PMOE_CONV_PREFETCH"); pf_on = ev ? atoi(ev) : 1; }
         // (also the expert MLP GEMMs: 1x1 "images", K = 512..1536 in 64-channel chunks -- a latency chain of 8..24 chunks)
