@@ -449,8 +449,23 @@ static int launch_stride2_dgrad(const ConvArgs& a, int dtype, hipStream_t st) {
     return 0;
 }
 
+// stride-2 1x1 data gradient (the ResNet downsample conv) ACCUMULATED IN PLACE into an existing gradient: only the
+// even-even pixels receive anything, so one class-(0,0) launch adds there and the other 3/4 of the tensor is not touched
+// (the zero-dilated form reads and rewrites all of it).
+static int launch_stride2_1x1_inplace(const ConvArgs& a, int dtype, hipStream_t st) {
+    ConvArgs c = a;
+    c.dilate = 0; c.stride = 1; c.pad = 0; c.kh = c.kw = 1;
+    c.Ho = (a.Ho + 1) / 2; c.Wo = (a.Wo + 1) / 2;
+    c.OH = a.Ho; c.OW = a.Wo; c.out_step = 2; c.out_offy = c.out_offx = 0;
+    return dtype == PMOE_DT_BF16 ? launch_dtype<bf16>(c, st, nullptr)
+         : dtype == PMOE_DT_F32 ? launch_dtype<float>(c, st, nullptr) : PMOE_ERR_ARG;
+}
+
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
     if (a.dilate && a.ks == 3 && a.pad == 1 && a.kh == 3) return launch_stride2_dgrad(a, dtype, st);
+    if (a.dilate && a.ks == 1 && a.pad == 0 && a.res_mode == PMOE_RES_ADD && a.res == a.out && a.res_ld == a.out_ld &&
+        a.res_coff == a.out_coff && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f)
+        return launch_stride2_1x1_inplace(a, dtype, st);
     ResPlan plan;
     if (conv_res_plan(a, dtype, &plan)) return conv_res_launch(a, plan, st);
     if (dtype == PMOE_DT_BF16) return launch_dtype<bf16>(a, st, nullptr);

@@ -869,10 +869,12 @@ class ExpertGroupEngine:
             a3 = self._bn(a2, self.bn1, relu=True)             # torchvision bn1 + relu stay after the stem
             o = self._maxpool(a3)
         for blk in self.blocks:
-            aA = self._conv_bn(o, blk["conv1"], blk["bn1"], relu=True)
             idn = o
             if blk["down"] is not None:
+                # before conv1 on the tape, so that in backward the 1x1 stride-2 data gradient runs LAST and is added in
+                # place at the even pixels of conv1's (dense) data gradient instead of writing a mostly-zero tensor first
                 idn = self._conv_bn(o, blk["down"][0], blk["down"][1], relu=False)
+            aA = self._conv_bn(o, blk["conv1"], blk["bn1"], relu=True)
             o = self._conv_bn(aA, blk["conv2"], blk["bn2"], relu=True, res=idn)
         self._gap_to(o, feat, 0)
 

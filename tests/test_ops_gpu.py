@@ -122,6 +122,13 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     ops.conv2d(dyd, wd, dx, cin=r16(cout), cout=cinp, coutp=r64(cin), ipe=ipe, ks=ks, stride=1,
                pad=ks - 1 - pad, dilate=(stride == 2))
     close(from_nhwc(dx, cin), xr.grad, dtype, "conv dgrad")
+    if stride == 2:
+        # second consumer: accumulated IN PLACE into an existing gradient (for the 1x1 case only the even pixels are touched)
+        prev = rnd((N, cin, H, W), torch.Generator().manual_seed(9), dtype)
+        acc = nhwc(prev, cinp, dtype)
+        ops.conv2d(dyd, wd, acc, cin=r16(cout), cout=cinp, coutp=r64(cin), ipe=ipe, ks=ks, stride=1, pad=ks - 1 - pad,
+                   dilate=True, res=acc, res_mode=hip.RES_ADD)
+        close(from_nhwc(acc, cin), xr.grad + prev, dtype, "conv dgrad accumulated in place")
 
     # weight gradient
     ckw = 64 if dtype == torch.bfloat16 else 32
