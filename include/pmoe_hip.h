@@ -330,6 +330,19 @@ int pmoe_mt_adam(const pmoe_opt_tensor* table, const int32_t* chunk_tensor, cons
 int pmoe_mt_swa_update(const pmoe_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index,
                        int32_t n_chunks, int64_t n_averaged, void* stream);
 
+/* ---- input pipeline (callers: model/data_loader.py:255-275, autoagents/image_agent.py:71-78,132-136):
+ * Crop([top, bottom]) -> torchvision Resize((h, w)) on a PIL image (= Pillow ImagingResample, BILINEAR with the support
+ * stretched by the down-scaling factor) -> ToTensor (uint8 HWC -> f32 CHW / 255), bit-exact.  Two passes like Pillow:
+ * horizontal over the cropped rows into an 8-bit intermediate, then vertical.  bounds [out][2] = (first tap, tap count),
+ * coeffs [out][ksize] = 22-bit fixed-point weights, both from Resample.c:precompute_coeffs / normalize_coeffs_8bpc
+ * (pmoe_amd/preprocess.py computes them in double precision). */
+int pmoe_resample_u8_horizontal(const uint8_t* src, uint8_t* dst, int32_t n_img, int32_t H0, int32_t W0, int32_t row0,
+                                int32_t rows, int32_t C, int32_t Wout, const int32_t* bounds, const int32_t* coeffs,
+                                int32_t ksize, void* stream);
+int pmoe_resample_u8_vertical_to_f32(const uint8_t* src, float* dst_nchw, int32_t n_img, int32_t Hin, int32_t W,
+                                     int32_t C, int32_t Hout, const int32_t* bounds, const int32_t* coeffs,
+                                     int32_t ksize, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
