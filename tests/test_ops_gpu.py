@@ -577,6 +577,51 @@ def test_action_head_loss_and_blend_kernels():
         close(got.grad, ref.grad, torch.float32, nm)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_folded_weight_packs(dtype):
+    """pmoe_pack_conv_weights_scaled (eval-mode BatchNorm folded into the conv, with residual add + ReLU in the epilogue)
+    and pmoe_pack_conv_weights_gated (ECA gate folded into per-image weights) against the unfused torch chains."""
+    g = torch.Generator().manual_seed(21)
+    E, ipe, cin, cout, H, W = 2, 3, 64, 64, 10, 12
+    N = E * ipe
+    x = rnd((N, cin, H, W), g, dtype)
+    res = rnd((N, cout, H, W), g, dtype)
+    ws = [rnd((cout, cin, 3, 3), g, dtype, (2.0 / (cin * 9)) ** 0.5) for _ in range(E)]
+    gamma, beta = torch.rand(E, cout, generator=g) + 0.5, torch.randn(E, cout, generator=g) * 0.3
+    rm, rv = torch.randn(E, cout, generator=g) * 0.2, torch.rand(E, cout, generator=g) + 0.5
+    eps = 1e-5
+    ref = torch.cat([torch.relu(F.batch_norm(F.conv2d(x[e * ipe:(e + 1) * ipe], ws[e], padding=1), rm[e].clone(), rv[e].clone(),
+                                             gamma[e], beta[e], False, 0.1, eps) + res[e * ipe:(e + 1) * ipe])
+                     for e in range(E)])
+    dev_ws = [w.to(DEV).contiguous() for w in ws]
+    tab = hip.ptr_table(dev_ws, DEV)
+    scale = (gamma / torch.sqrt(rv + eps)).to(DEV).contiguous()
+    wf = torch.empty(E, 64, 9, cin, dtype=dtype, device=DEV)
+    bf = torch.empty(E, 64, device=DEV)
+    ops.pack_conv_weights_scaled(tab, scale, beta.to(DEV).contiguous(), rm.to(DEV).contiguous(), wf, bf, E, cout, cin, 3, 64, cin, dtype)
+    xd, rd = nhwc(x, cin, dtype), nhwc(res, cout, dtype)
+    y = torch.empty(N, H, W, cout, dtype=dtype, device=DEV)
+    ops.conv2d(xd, wf, y, cin=cin, cout=cout, coutp=64, ipe=ipe, ks=3, stride=1, pad=1, bias=bf, act=hip.ACT_RELU,
+               res=rd, res_mode=hip.RES_ADD)
+    close(from_nhwc(y, cout), ref, dtype, "conv with folded BatchNorm + residual + ReLU")
+    # gate fold: conv(x * g[n, c], W[e]) == conv(x, W[e] * g[n, c]) with one weight pack per image
+    gate = torch.rand(N, cin, generator=g)
+    ref2 = torch.cat([F.conv2d(x[n:n + 1] * gate[n].view(1, -1, 1, 1), ws[n // ipe], padding=1) for n in range(N)])
+    wg = torch.empty(N, 64, 9, cin, dtype=dtype, device=DEV)
+    wd = torch.empty(N, 64, 9, cout, dtype=dtype, device=DEV)
+    ops.pack_conv_weights_gated(tab, gate.to(DEV).contiguous(), wg, wd, N, ipe, cout, cin, 3, 64, cin, 64, cout, dtype)
+    y2 = torch.empty(N, H, W, cout, dtype=dtype, device=DEV)
+    ops.conv2d(xd, wg, y2, cin=cin, cout=cout, coutp=64, ipe=1, ks=3, stride=1, pad=1)
+    close(from_nhwc(y2, cout), ref2, dtype, "conv with per-image gate-folded weights")
+    # and its data gradient (flipped pack) against autograd through the gated input
+    xr = x.clone().requires_grad_(True)
+    dy = rnd((N, cout, H, W), g, dtype)
+    torch.cat([F.conv2d(xr[n:n + 1] * gate[n].view(1, -1, 1, 1), ws[n // ipe], padding=1) for n in range(N)]).backward(dy)
+    dx = torch.empty(N, H, W, cin, dtype=dtype, device=DEV)
+    ops.conv2d(nhwc(dy, cout, dtype), wd, dx, cin=cout, cout=cin, coutp=64, ipe=1, ks=3, stride=1, pad=1)
+    close(from_nhwc(dx, cin), xr.grad, dtype, "gate-folded data gradient")
+
+
 def test_batchnorm_statistics_are_centred():
     """|mean| >> std (a near-constant channel): one-pass E[x^2]-mean^2 in f32 loses the variance; the centred sums
     (deviations from a sample of the channel) must reproduce the float64 statistics."""
