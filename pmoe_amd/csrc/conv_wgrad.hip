@@ -17,6 +17,7 @@
 // right after the barrier that publishes m-block i and land under its ~4600 cycles of MFMA; they
 // are written to LDS after the next barrier (issue early / write late).
 #include "conv_common.h"
+#include <stdlib.h>
 #include "kernels.h"
 
 template <typename T> struct WgradCfg;
@@ -236,9 +237,13 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st) {
         a.tiles_y = (a.Ho + TH - 1) / TH;
         a.tiles_x = (a.Wo + TW - 1) / TW;
         const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
-        // K-split: one workgroup per CU is resident; aim for ~2 rounds of 256 workgroups
+        // K-split: one workgroup per CU is resident; ONE round of 256 workgroups measured best (each walks more m-blocks,
+        // flushes its 9 x 64 x 64 accumulators once, no second-round tail): 2 rounds -10 %, 1.25-1.5 rounds -25..30 %.
+        // PMOE_WGRAD_WGS overrides the target for A/B runs.
         const int pairs = ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW) * E;
-        int want = (512 + pairs - 1) / pairs;
+        static int target = 0;
+        if (!target) { const char* ev = getenv("PMOE_WGRAD_WGS"); target = ev ? atoi(ev) : 256; }
+        int want = (target + pairs - 1) / pairs;
         if (want < 1) want = 1;
         if (want > mbpe) want = mbpe;
         a.mb_per_wg = (mbpe + want - 1) / want;
