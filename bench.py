@@ -232,8 +232,11 @@ def main():
         def symbol(code):
             four = code >= 4000
             code %= 4000
+            if code >= 2000:
+                return (f"conv_igemm_lite_kernel<{args.dtype},{code - 2000}>" + (" (4 parity-class launches per stride-2 dgrad)" if four else ""),
+                        f"_Z22conv_igemm_lite_kernelI{tname}Li{code - 2000}EEv8ConvArgs", 4 if four else 1)
             if code >= 1000:
-                return f"conv3x3_res_kernel<{code - 1000}>", f"void conv3x3_res_kernel<{code - 1000}>", 1
+                return f"conv3x3_res_kernel<{code - 1000}>", f"void conv3x3_res_kernel<{code - 1000}", 1
             rb, wm, wn = code // 100, code // 10 % 10, code % 10
             return (f"conv_igemm_kernel<{args.dtype},{rb},{wm},{wn}>" + (" (4 parity-class launches per stride-2 dgrad)" if four else ""),
                     f"_Z17conv_igemm_kernelI{tname}Li{rb}ELi{wm}ELi{wn}EEv8ConvArgs", 4 if four else 1)

@@ -76,6 +76,7 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
 /* which kernel instantiation pmoe_conv2d_igemm would run for this descriptor (nothing is launched; used by bench.py
  * to attribute measured launch times to kernel symbols that a rocprofv3 kernel trace shows):
  *   1000 + LOG_RB            conv3x3_res_kernel<LOG_RB>            (resident-filter kernel, conv_res.hip)
+ *   2000 + LOG_RB            conv_igemm_lite_kernel<T, LOG_RB>     (8-wave 256 x 128 tile, two workgroups per CU)
  *   LOG_RB*100 + WM*10 + WN  conv_igemm_kernel<T, LOG_RB, WM, WN>  (halo-patch implicit GEMM, conv_igemm.hip)
  *   4000 + the latter        the four parity-class launches of a stride-2 3x3 data gradient */
 int pmoe_conv2d_plan(const pmoe_conv_desc* d);

@@ -35,8 +35,11 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int LOG_RB, int WM, int WN>
-__global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs a) {
+// LITE: the 8-wave tile without chunk prefetch and stagger and with the epilogue staged in two halves -- few enough
+// registers (launch bound: 2 workgroups per CU) and LDS for TWO resident workgroups, whose prologues / epilogues / barriers
+// then overlap each other's MFMAs.
+template <typename T, int LOG_RB, int WM, int WN, bool LITE>
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     constexpr int RB = 1 << LOG_RB, CPR = RB / 16, LOG_CPR = LOG_RB - 4;
     constexpr int NTHR = WM * WN * 64;
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -71,7 +74,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     // one halo-patch buffer, or two when the launcher asked for chunk prefetch (a.prefetch)
     const int PB = (NPIX * RB + 255) & ~255;
     char* patch0 = smem;
-    char* wbuf = smem + PB * (a.prefetch ? 2 : 1);
+    char* wbuf = smem + PB * ((!LITE && a.prefetch) ? 2 : 1);
 
     int ppb[2];
 #pragma unroll
@@ -124,7 +127,9 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     const bool one_batch = NPIX * CPR <= MV1 * NTHR;    // every load of the patch in flight at once
     const bool big_batch = NPIX * CPR <= MV2 * NTHR;    // stride-2 halos (17x33 / 33x33 pixels)
     auto load_patch = [&](char* patch, int c0) {
-        if (one_batch) {
+        if (LITE) {                                  // batches of 4 vectors: few registers, the other resident workgroup hides it
+            load_halo_patch<T, LOG_RB, NTHR, 0>(patch, in, geo, c0, tid);
+        } else if (one_batch) {
             PatchStage<T, LOG_RB, NTHR, MV1> ps;
             ps.issue(in, geo, c0, tid);
             ps.template commit<0>(patch, NPIX, tid);
@@ -147,18 +152,18 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     // 8-wave tile -- hold back the MFMAs of each tap's LAST k-substep and issue them after the barrier, i.e. under the
     // partners' first LDS reads of the next tap, so the two waves of a SIMD stop reaching MFMA bursts, LDS bursts and
     // barriers in lockstep.  Fragments wait in registers; results are bit-identical (same MFMAs, same order per accumulator).
-    const bool stag = (WM * WN == 8) && wave >= 4 && a.stagger;
+    const bool stag = !LITE && (WM * WN == 8) && wave >= 4 && a.stagger;
     constexpr int NDEF = KSUB >= 2 ? KSUB / 2 : 1;      // k-substeps held back: half a tap
     v4i paf[NDEF][2], pbf[NDEF][2];
     bool pend = false;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
-        char* patch = a.prefetch ? patch0 + (ch & 1) * PB : patch0;
-        if (!a.prefetch || ch == 0) {
+        char* patch = (!LITE && a.prefetch) ? patch0 + (ch & 1) * PB : patch0;
+        if (LITE || !a.prefetch || ch == 0) {
             load_patch(patch, c0);
             __syncthreads();
         }
-        const bool more = a.prefetch && ch + 1 < nchunks;
+        const bool more = !LITE && a.prefetch && ch + 1 < nchunks;
         if (more) nxt.issue(in, geo, c0 + CK, tid);      // in flight under this chunk's taps of MFMAs
         for (int r = 0; r < KH; ++r) {
             for (int q = 0; q < KW; ++q) {
@@ -222,24 +227,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) Mma<T>::run(paf[d][nt], pbf[d][mt], acc[nt][mt]);
     }
-    // ---- epilogue: D[cout][pixel] -> LDS f32 [BM][BN] (16B units XOR-swizzled by pixel) ----
+    // ---- epilogue: D[cout][pixel] -> LDS f32 [BM / EP][BN] (16B units XOR-swizzled by pixel) ----
     constexpr int UPR = BN / 4;
+    constexpr int EP = LITE ? 2 : 1, BMH = BM / EP;      // LITE: two halves of 128 pixel rows through a 64 KiB staging area
     float* stg = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int p = wm * 64 + mt * 32 + l31;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int u = wn * 16 + nt * 8 + 2 * g + h;
-                f32x4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[nt][mt][4 * g + i];
-                *reinterpret_cast<f32x4*>(stg + p * BN + ((u ^ (p & (UPR - 1))) << 2)) = v;
-            }
-        }
-    __syncthreads();
 
     constexpr int CPO = BN / VE;
     constexpr int PROWS = NTHR / CPO;
@@ -255,7 +246,27 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
     const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     T* out = (T*)a.out;
     const T* res = (const T*)a.res;
-    for (int p = pr; p < BM; p += PROWS) {
+  for (int half = 0; half < EP; ++half) {
+    if (half) __syncthreads();                      // the previous half has been read out
+    if (EP == 1 || wm / (WM / EP) == half) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int p = wm * 64 + mt * 32 + l31 - half * BMH;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int u = wn * 16 + nt * 8 + 2 * g + h;
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[nt][mt][4 * g + i];
+                    *reinterpret_cast<f32x4*>(stg + p * BN + ((u ^ (p & (UPR - 1))) << 2)) = v;
+                }
+            }
+    }
+    __syncthreads();
+    for (int ph = pr; ph < BMH; ph += PROWS) {
+        const int p = ph + half * BMH;
         const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
         const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
         const bool ok = cvalid && n < n_end && oy < a.Ho && ox < a.Wo;
@@ -263,7 +274,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
 #pragma unroll
         for (int k = 0; k < VE / 4; ++k) {
             const int u = cc * (VE / 4) + k;
-            const f32x4 tt = *reinterpret_cast<const f32x4*>(stg + p * BN + ((u ^ (p & (UPR - 1))) << 2));
+            const f32x4 tt = *reinterpret_cast<const f32x4*>(stg + ph * BN + ((u ^ (ph & (UPR - 1))) << 2));
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[4 * k + i] = tt[i];
         }
@@ -312,6 +323,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
             stg16(out + opix * a.out_ld + a.out_coff + cout, pk);
         }
     }
+  }
     if (a.stats) {
         // BatchNorm partial sums of this tile: lanes sharing a channel vector combine by xor-shuffle,
         // waves through LDS; one [2][CoutP] row per m-block, reduced later in fixed order.
@@ -342,6 +354,29 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs
             if (cout0 + c < a.CoutP) a.stats[((size_t)mb * 2 + which) * a.CoutP + cout0 + c] = s;
         }
     }
+}
+
+template <typename T, int LOG_RB, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs a) {
+    conv_igemm_body<T, LOG_RB, WM, WN, false>(a);
+}
+
+template <typename T, int LOG_RB>
+__global__ void __launch_bounds__(512, 4) conv_igemm_lite_kernel(const ConvArgs a) {
+    conv_igemm_body<T, LOG_RB, 4, 2, true>(a);
+}
+
+template <typename T, int LOG_RB>
+static int launch_lite(const ConvArgs& a, int mblocks, size_t smem, hipStream_t st) {
+    auto k = conv_igemm_lite_kernel<T, LOG_RB>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    dim3 grid(mblocks, a.CoutP / 128, 1), block(512, 1, 1);
+    hipLaunchKernelGGL(k, grid, block, smem, st, a);
+    return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,16 +421,22 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         const size_t pbytes = ((size_t)TN * PH * PW * rb + 255) & ~(size_t)255;
         // chunk prefetch: 8-wave tile, >= 2 channel chunks, the whole patch in <= 6 vectors per thread (24 VGPRs)
         const int nthr = big ? 512 : 256;
+        // 64-channel chunks: the LITE instantiation (<= 128 VGPRs, 73 KiB LDS) puts TWO 8-wave workgroups on a CU, which
+        // beats one workgroup with chunk prefetch + stagger by 12-30 % (l2 +12 %, l3 +30 %, l4 +25 %: 980-1000 TFLOP/s).
+        // PMOE_CONV_LITE=0 switches back for A/B runs.
+        static int lite_on = -1;
+        if (lite_on < 0) { const char* ev = getenv("PMOE_CONV_LITE"); lite_on = ev ? atoi(ev) : 1; }
+        const bool lite = lite_on && big && log_rb == 7 && pbytes + 2 * (size_t)BN * rb <= 80 * 1024;   // two must fit a CU
         static int stg_on = -1;     // PMOE_CONV_STAGGER=0: A/B switch
         if (stg_on < 0) { const char* ev = getenv("PMOE_CONV_STAGGER"); stg_on = ev ? atoi(ev) : 1; }
-        a.stagger = stg_on && big;
+        a.stagger = stg_on && big && !lite;
         static int pf_on = -1;      // PMOE_CONV_PREFETCH=0: A/B switch
         if (pf_on < 0) { const char* ev = getenv("PMOE_CONV_PREFETCH"); pf_on = ev ? atoi(ev) : 1; }
         // (also the expert MLP GEMMs: 1x1 "images", K = 512..1536 in 64-channel chunks -- a latency chain of 8..24 chunks)
-        a.prefetch = pf_on && (big || (a.H == 1 && a.W == 1 && a.ks == 1)) && a.Cin / ck >= 2 && (size_t)TN * PH * PW * (rb / 16) <= (size_t)6 * nthr &&
+        a.prefetch = !lite && pf_on && (big || (a.H == 1 && a.W == 1 && a.ks == 1)) && a.Cin / ck >= 2 && (size_t)TN * PH * PW * (rb / 16) <= (size_t)6 * nthr &&
                      2 * pbytes + 2 * (size_t)BN * rb <= 150 * 1024;
         size_t smem = pbytes * (a.prefetch ? 2 : 1) + 2 * (size_t)BN * rb;
-        const size_t stg = (size_t)BM * BN * 4;
+        const size_t stg = (size_t)BM * BN * 4 / (lite ? 2 : 1);
         if (smem < stg) smem = stg;
         if (smem > 150 * 1024) continue;
         a.lTW = lTW; a.lTH = lTH; a.TN = TN;
@@ -403,8 +444,9 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         a.tiles_y = (a.Ho + TH - 1) / TH;
         a.tiles_x = (a.Wo + TW - 1) / TW;
         const int mblocks = E * a.n_groups * a.tiles_y * a.tiles_x;
-        if (out_cfg) *out_cfg = log_rb * 100 + (wide ? (big ? 42 : 22) : 41);      // <T, LOG_RB, WM, WN> of the launch
+        if (out_cfg) *out_cfg = lite ? 2000 + log_rb : log_rb * 100 + (wide ? (big ? 42 : 22) : 41);   // see conv_igemm_plan
         if (out_mblocks) { *out_mblocks = mblocks; return 0; }
+        if (lite) return launch_lite<T, 7>(a, mblocks, smem, st);
         if (log_rb == 7 && big) return launch_cfg<T, 7, 4, 2>(a, mblocks, smem, st);
         if (log_rb == 6 && big) return launch_cfg<T, 6, 4, 2>(a, mblocks, smem, st);
         if (log_rb == 5 && big) return launch_cfg<T, 5, 4, 2>(a, mblocks, smem, st);
@@ -473,8 +515,9 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
     return PMOE_ERR_ARG;
 }
 
-// which kernel a descriptor runs on (no launch): 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; LOG_RB*100 + WM*10 + WN =
-// conv_igemm_kernel<T, LOG_RB, WM, WN>; + 4000 = the four parity-class launches of a stride-2 data gradient
+// which kernel a descriptor runs on (no launch): 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; 2000 + LOG_RB =
+// conv_igemm_lite_kernel<T, LOG_RB>; LOG_RB*100 + WM*10 + WN = conv_igemm_kernel<T, LOG_RB, WM, WN>; + 4000 = the four
+// parity-class launches of a stride-2 data gradient
 int conv_igemm_plan(const ConvArgs& a, int dtype) {
     ConvArgs c = a;
     int extra = 0;

@@ -79,7 +79,7 @@ def test_conv_plan_reports_the_kernel_instantiation():
         return load().pmoe_conv2d_plan(C.byref(d))
     assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1007                 # conv3x3_res_kernel<7>
     assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1005                 # 12(16)-channel stem on the resident kernel
-    assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 742                 # conv_igemm_kernel<bf16,7,4,2>
+    assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 2007                # conv_igemm_lite_kernel<bf16,7>: 2 workgroups / CU
     assert plan(256, 256, 32, 3, 1, torch.float32) == 722                  # f32: 4-wave 128x128 tile, 32-channel chunks
     assert plan(1536, 512, 1, 1, 1, torch.bfloat16) == 722                 # expert MLP GEMM: 4-wave tile
     assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 4741   # stride-2 dgrad: 4 class launches <7,4,1>
