@@ -12,6 +12,7 @@
 // (issue early / write late).  Then the roles swap.  Three workgroup barriers per tile, no weight
 // traffic, no prologue / epilogue bubble: the MFMA pipe of each SIMD always has one wave feeding it.
 #include "conv_common.h"
+#include <stdlib.h>
 #include "kernels.h"
 
 template <int LOG_RB> __device__ __forceinline__ int rswz(int x) { return swz_chunk<LOG_RB, 0>(x); }
@@ -284,6 +285,9 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
 
 // ------------------------------------------------------------------------------------------------
 bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan) {
+    static int res_on = -1;       // PMOE_CONV_RES=0: route the <=64-channel layers to the generic kernel (A/B runs)
+    if (res_on < 0) { const char* ev = getenv("PMOE_CONV_RES"); res_on = ev ? atoi(ev) : 1; }
+    if (!res_on) return false;
     if (dtype != PMOE_DT_BF16 || a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dilate) return false;
     if (a.CoutP != 64 || a.Cout % 8 || (a.Cin != 64 && a.Cin != 16)) return false;
     if (a.act != PMOE_ACT_NONE || a.drop_p > 0.f) return false;
