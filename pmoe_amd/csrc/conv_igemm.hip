@@ -52,7 +52,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    const unsigned mb = xcd_remap(blockIdx.x, gridDim.x);
+    // LITE launches a flat grid: output-channel block fastest, so that the workgroups that read the SAME input patch (one per
+    // cout block) are neighbours in dispatch order and -- through the XCD remap -- on the same XCD's L2
+    const int nblk = LITE ? a.CoutP / BN : 1;
+    const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned mb = LITE ? flat / nblk : flat;
+    const int nb = LITE ? (int)(flat % nblk) : (int)blockIdx.y;
     int t = (int)mb;
     const int px = t % a.tiles_x; t /= a.tiles_x;
     const int py = t % a.tiles_y; t /= a.tiles_y;
@@ -69,7 +74,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     const int n0 = e * a.ipe + ng * a.TN, n_end = (e + 1) * a.ipe;
     const int oy0 = py * TH, ox0 = px * TW;
     const int Y0 = oy0 * a.stride - a.pad, X0 = ox0 * a.stride - a.pad;
-    const int cout0 = blockIdx.y * BN;
+    const int cout0 = nb * BN;
 
     // one halo-patch buffer, or two when the launcher asked for chunk prefetch (a.prefetch)
     const int PB = (NPIX * RB + 255) & ~255;
@@ -374,7 +379,7 @@ static int launch_lite(const ConvArgs& a, int mblocks, size_t smem, hipStream_t 
         HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    dim3 grid(mblocks, a.CoutP / 128, 1), block(512, 1, 1);
+    dim3 grid(mblocks * (a.CoutP / 128), 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL(k, grid, block, smem, st, a);
     return (int)hipGetLastError();
 }
