@@ -295,18 +295,24 @@ __global__ void __launch_bounds__(256) stem_tail_pool_kernel(const T* __restrict
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE;
     const long long total = (long long)N * Ho * Wo * CV;
+    // the grid stride is a multiple of CV (a power of two <= 256), so a thread keeps ONE channel vector; its 6 constant
+    // vectors are reloaded only when the sweep crosses into the next expert
+    const int cv = (int)(threadIdx.x & (CV - 1));
+    int e_cur = -1;
+    float sc2[VE], sh2[VE], sc1[VE], sh1[VE], mu2[VE], mu1[VE];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % CV);
         long long t = i / CV;
         const int ox = (int)(t % Wo); t /= Wo;
         const int oy = (int)(t % Ho);
         const int n = (int)(t / Ho);
         const int e = n / ipe;
-        float sc2[VE], sh2[VE], sc1[VE], sh1[VE], mu2[VE], mu1[VE];
+        if (e != e_cur) {
+            e_cur = e;
 #pragma unroll
-        for (int q = 0; q < VE; ++q) {
-            const int c = e * C + cv * VE + q;
-            sc2[q] = sc2a[c]; sh2[q] = sh2a[c]; sc1[q] = sc1a[c]; sh1[q] = sh1a[c]; mu2[q] = mu2a[c]; mu1[q] = mu1a[c];
+            for (int q = 0; q < VE; ++q) {
+                const int c = e * C + cv * VE + q;
+                sc2[q] = sc2a[c]; sh2[q] = sh2a[c]; sc1[q] = sc1a[c]; sh1[q] = sh1a[c]; mu2[q] = mu2a[c]; mu1[q] = mu1a[c];
+            }
         }
         float best[VE];
         int bi[VE];                      // winning tap (0..8) | 0x80 if the winner's a2 > 0 (used by the pooled backward pass)
@@ -365,7 +371,7 @@ int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* s
                         void* stream) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
-    if (C % ve || N % ipe) return PMOE_ERR_ARG;
+    if (C % ve || N % ipe || !pow2i(C / ve) || C / ve > 256) return PMOE_ERR_ARG;   // one channel vector per thread
     long long g = ((long long)N * Ho * Wo * (C / ve) + 255) / 256;
     if (g > 16384) g = 16384;
     if (dtype == PMOE_DT_BF16)
