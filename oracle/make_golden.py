@@ -208,6 +208,71 @@ def run_punet_case(ref_moe, ref_loss, name, model_type, batch, size, future_fram
     return out
 
 
+STAGE1_SLICES = [
+    "entry_block.layer1.eca1.conv.weight", "entry_block.layer1.conv1.0.weight", "entry_block.layer1.conv1.1.weight",
+    "entry_block.layer2.eca2.conv.weight", "entry_block.layer2.conv2.0.weight", "entry_block.layer2.conv2.1.weight",
+    "entry_block.layer2.conv2.1.bias", "pred_unet.dwn_1.0.weight", "pred_unet.dwn_1.1.weight", "pred_unet.dwn_3.3.weight",
+    "pred_unet.dwn_5.0.weight", "pred_unet.dwn_5.4.bias", "pred_unet.up_1.weight", "pred_unet.up_1.bias",
+    "pred_unet.up_forw_1.0.weight", "pred_unet.up_3.weight", "pred_unet.up_4.bias", "pred_unet.up_forw_4.3.weight",
+    "pred_unet.up_forw_4.4.weight", "pred_unet.out.weight", "pred_unet.out.bias",
+]
+STAGE1_BN = ["unet.dwn_1.1", "unet.up_forw_4.4", "entry_block.layer1.conv1.1", "entry_block.layer2.conv2.1",
+             "pred_unet.dwn_1.1", "pred_unet.dwn_5.4", "pred_unet.up_forw_4.4"]
+
+
+def run_stage1_case(ref_loss, name, batch, size, future_frames, loss_type="tversky"):
+    """Stage-1 PU-Net training step (train_1.py:129-141): PredictiveUnet in train mode, AutoregressiveCriterion, backward
+    through the autoregressive chain.  ``unet`` is frozen (punet.py:46-48) but follows ``model.train()``."""
+    from model.blocks.unet import UNet as RefUNet
+    from model.punet import PredictiveUnet as RefPU
+    tmp = REPO / "build" / "golden_tmp"
+    tmp.mkdir(parents=True, exist_ok=True)
+    torch.save({"unet": RefUNet().state_dict()}, tmp / "unet.pth")
+    torch.manual_seed(0)
+    model = RefPU(past_frames=4, future_frames=future_frames, in_features=3, num_classes=23, gamma=2, b=1,
+                  model_name="unet", model_path=str(tmp / "unet.pth"))
+    weights.fill_state_dict(model, seed=0)
+    model.train()
+    inp = weights.make_inputs(batch, size, size, seed=1234)
+    target = weights.make_seg_targets(batch, future_frames, size, size, 23, seed=4321)
+    crit = ref_loss.AutoregressiveCriterion(future_frames, loss_type)
+    out = model(inp["images"])
+    out.retain_grad()
+    loss = crit(out, target)
+    loss.backward()
+    named = dict(model.named_parameters())
+    sd = model.state_dict()
+    res = {"meta": dict(name=name, batch=batch, size=size, future_frames=future_frames, loss_type=loss_type, weight_seed=0,
+                        input_seed=1234, target_seed=4321),
+           "state_dict_keys": list(sd.keys()),
+           "requires_grad": {k: p.requires_grad for k, p in named.items()},
+           "out_sub": out.detach()[..., ::4, ::4].clone(), "out_norm": out.detach().norm().item(),
+           "loss": loss.detach().clone(),
+           "dout_sub": out.grad[..., ::4, ::4].clone(), "dout_norm": out.grad.norm().item(),
+           "grad_norms": {k: p.grad.norm().item() for k, p in named.items() if p.grad is not None},
+           "grad_slices": {k: named[k].grad.flatten()[:64].clone() for k in STAGE1_SLICES},
+           "bn_after_1": {f"{b}.{leaf}": sd[f"{b}.{leaf}"].clone() for b in STAGE1_BN
+                          for leaf in ("running_mean", "running_var", "num_batches_tracked")}}
+    return res
+
+
+def segloss_cases(ref_loss):
+    """AutoregressiveCriterion (loss.py:86-118) on random logits: loss and d loss / d logits for the three loss types."""
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    for nm, (b, f, h, w, scale) in {"a": (2, 2, 16, 16, 2.0), "b": (3, 1, 8, 24, 0.5)}.items():
+        x = (torch.randn(b, f, 23, h, w, generator=g) * scale)
+        t = weights.make_seg_targets(b, f, h, w, 23, seed=7 + b, block=2)
+        case = {"logits": x.clone(), "target": t}
+        for lt in ("tversky", "l1", "l2"):
+            xi = x.clone().requires_grad_(True)
+            l = ref_loss.AutoregressiveCriterion(f, lt)(xi, t)
+            l.backward()
+            case[lt] = dict(loss=l.detach().clone(), dlogits=xi.grad.clone())
+        out[nm] = case
+    return out
+
+
 def run_pmoe_case(ref_moe, ref_loss, name, batch, size, future_frames, n_experts):
     """type 'pmoe' (moe.py:326-363) with exclude_freeze = [lat_weights, long_weights] (stage_2_pmoe.yaml:81) and no
     pretrained PU-Net action model: the blend weights and the PU-Net expert's heads / backbone train."""
@@ -328,6 +393,14 @@ def main():
         res = run_pmoe_case(ref_moe, ref_loss, "p5_pmoe_e2_b2_64_f2", 2, 64, 2, 2)
         torch.save(res, gold / "p5_pmoe_e2_b2_64_f2.pt")
         print("p5_pmoe_e2_b2_64_f2", float(res["loss"]), res["actions"].tolist())
+    for name, b, sz, f in [("s1_stage1_b3_32_f3", 3, 32, 3), ("s2_stage1_b2_64_f6", 2, 64, 6)]:
+        if only and name not in only:
+            continue
+        res = run_stage1_case(ref_loss, name, b, sz, f)
+        torch.save(res, gold / f"{name}.pt")
+        print(name, float(res["loss"]), res["out_norm"], res["dout_norm"])
+    if not only or "s0_segloss" in only:
+        torch.save(segloss_cases(ref_loss), gold / "s0_segloss.pt")
     if not only or "micro" in only:
         torch.save(micro_cases(ref_basics, ref_loss), gold / "micro.pt")
     import shutil

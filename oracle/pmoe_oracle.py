@@ -397,6 +397,61 @@ def pmoe_loss(actions, speed_pred, actions_gt, speed_gt, loss_coefs):
     return F.l1_loss(actions, actions_gt)
 
 
+def class_dice_weights(pred, target, eps=1e-6):
+    """``trainer/loss.py:6-17``: per-class ``1 - dice`` of the arg-max prediction over the WHOLE batch (no gradient)."""
+    hard = pred.argmax(dim=1)
+    w = torch.ones(pred.size(1), dtype=torch.float, device=pred.device)
+    for c in range(pred.size(1)):
+        p, t = hard == c, target == c
+        w[c] = 1 - 2 * ((p & t).sum().float() + eps) / (p.sum() + t.sum() + eps)
+    return w
+
+
+def tversky_loss(pred, target, alpha=0.5, beta=0.5):
+    """``trainer/loss.py:34-45``: 1 - mean TP / (TP + alpha FP + beta FN) on soft-max probabilities.  The reference
+    derives the reduced axes from the TARGET's rank (loss.py:40: ``range(2, target.ndimension())`` with target
+    [B,H,W]), i.e. it sums over batch and image ROWS only: the ratio is formed per (class, image column) and the mean
+    runs over both -- restated as is."""
+    onehot = F.one_hot(target, pred.size(1)).movedim(-1, 1).to(pred.dtype)
+    probs = torch.softmax(pred, dim=1)
+    dims = (0,) + tuple(range(2, target.dim()))
+    tp = (probs * onehot).sum(dims)
+    fp = (probs * (1 - onehot)).sum(dims)
+    fn = ((1 - probs) * onehot).sum(dims)
+    return 1 - (tp / (tp + alpha * fp + beta * fn)).mean()
+
+
+def cross_entropy_tversky_weighted_loss(pred, target, cross_entropy_weight=0.5, tversky_weight=0.5):
+    """``trainer/loss.py:48-57``."""
+    if cross_entropy_weight + tversky_weight != 1:
+        raise ValueError("Cross Entropy weight and Tversky weight should sum to 1")
+    ce = F.cross_entropy(pred, target, weight=class_dice_weights(pred, target))
+    return cross_entropy_weight * ce + tversky_weight * tversky_loss(pred, target)
+
+
+class AutoregressiveCriterion(nn.Module):
+    """``trainer/loss.py:86-118`` (stage-1 PU-Net training, train_1.py:75-77,134): per-frame loss summed over the
+    predicted frames.  inputs [B,T,C,H,W] logits, targets [B,T,H,W] class indices."""
+
+    def __init__(self, n_target_frames=1, loss_type="tversky"):
+        super().__init__()
+        if loss_type not in ("l1", "l2", "tversky"):
+            raise ValueError(f"Unknown loss type {loss_type}, supported ones are L1, L2, and tversky")
+        self.n_target_frames, self.loss_type = n_target_frames, loss_type
+
+    def forward(self, inputs, targets):
+        assert inputs.size(1) == self.n_target_frames and targets.size(1) == self.n_target_frames
+        total = 0
+        for t in range(self.n_target_frames):
+            x, y = inputs[:, t], targets[:, t]
+            if self.loss_type == "tversky":
+                total = total + cross_entropy_tversky_weighted_loss(x, y)
+            else:
+                onehot = F.one_hot(y, x.size(1)).movedim(-1, 1).to(x.dtype)
+                total = total + (F.l1_loss(x, onehot) if self.loss_type == "l1" else F.mse_loss(x, onehot))
+        return total
+
+
 def get_model(cfg):
     """``model/moe.py:25-47``."""
     if cfg.type in ("moe", "moe_alt"):

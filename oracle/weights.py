@@ -65,3 +65,13 @@ def make_inputs(batch, height, width, n_frames=4, n_commands=6, seed=1234):
     command = torch.nn.functional.one_hot(cmd_idx, n_commands).float()
     control = torch.rand(batch, 2, generator=g) * 2 - 1
     return dict(images=images, speed=speed, command=command, control=control, target_speed=target_speed)
+
+
+def make_seg_targets(batch, frames, height, width, classes=23, seed=4321, block=4):
+    """Synthetic future segmentation labels in the contract of ``model/data_loader.py`` (stage 1, ``load_measurements``
+    False): int64 class indices [B,F,H,W], piecewise constant over ``block`` x ``block`` pixels."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    coarse = torch.randint(0, classes, (batch, frames, (height + block - 1) // block, (width + block - 1) // block),
+                           generator=g)
+    return coarse.repeat_interleave(block, -2).repeat_interleave(block, -1)[..., :height, :width].contiguous()

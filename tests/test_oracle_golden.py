@@ -186,3 +186,53 @@ def test_pmoe_matches_reference(golden_dir):
     ac = _load(golden_dir, "micro")["action_loss_case"]
     torch.testing.assert_close(O.punet_loss(ac["actions"], ac["speeds"], ac["act"], ac["tgt"], [0.7, 0.3]), ac["punet_loss"])
     torch.testing.assert_close(O.pmoe_loss(ac["actions"], -1, ac["act"], ac["tgt"], [0.7, 0.3]), ac["pmoe_loss"])
+
+
+def _stage1_oracle(g, dtype=torch.float32):
+    m = g["meta"]
+    model = O.PredictiveUnet(past_frames=4, future_frames=m["future_frames"], model_path=None)
+    W.fill_state_dict(model, seed=m["weight_seed"])
+    model.train()            # train_1.py:122: model.train() also reaches the frozen ``unet``
+    model.to(dtype)
+    inp = W.make_inputs(m["batch"], m["size"], m["size"], seed=m["input_seed"])
+    tgt = W.make_seg_targets(m["batch"], m["future_frames"], m["size"], m["size"], 23, seed=m["target_seed"])
+    return model, inp["images"].to(dtype), tgt
+
+
+@pytest.mark.parametrize("name", ["s1_stage1_b3_32_f3", "s2_stage1_b2_64_f6"])
+def test_stage1_training_step_matches_reference(golden_dir, name):
+    """Stage-1 PU-Net training (train_1.py:129-141, punet.py:75-120, loss.py:86-118): restatement vs imported reference."""
+    g = _load(golden_dir, name)
+    model, images, tgt = _stage1_oracle(g)
+    assert list(model.state_dict().keys()) == g["state_dict_keys"]
+    assert {k: p.requires_grad for k, p in model.named_parameters()} == g["requires_grad"]
+    out = model(images)
+    out.retain_grad()
+    loss = O.AutoregressiveCriterion(g["meta"]["future_frames"], "tversky")(out, tgt)
+    loss.backward()
+    torch.testing.assert_close(out.detach()[..., ::4, ::4], g["out_sub"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(loss.detach(), g["loss"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out.grad[..., ::4, ::4], g["dout_sub"], rtol=1e-3, atol=1e-8)
+    named = dict(model.named_parameters())
+    assert {k for k, p in named.items() if p.grad is not None} == set(g["grad_norms"])
+    for k, sl in g["grad_slices"].items():
+        scale = g["grad_norms"][k] / max(1.0, named[k].numel() ** 0.5)
+        torch.testing.assert_close(named[k].grad.flatten()[:64], sl, rtol=2e-3, atol=2e-3 * scale + 1e-9)
+    sd = model.state_dict()
+    for k, v in g["bn_after_1"].items():
+        torch.testing.assert_close(sd[k], v, rtol=1e-4, atol=1e-5)
+
+
+def test_segmentation_criterion_matches_reference(golden_dir):
+    """AutoregressiveCriterion (loss.py:86-118; class_dice 6-17, tversky_loss 34-45, weighted CE 48-57)."""
+    cases = _load(golden_dir, "s0_segloss")
+    for nm, c in cases.items():
+        f = c["logits"].shape[1]
+        for lt in ("tversky", "l1", "l2"):
+            x = c["logits"].clone().requires_grad_(True)
+            loss = O.AutoregressiveCriterion(f, lt)(x, c["target"])
+            loss.backward()
+            torch.testing.assert_close(loss.detach(), c[lt]["loss"], rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(x.grad, c[lt]["dlogits"], rtol=1e-4, atol=1e-9)
+    with pytest.raises(ValueError):
+        O.AutoregressiveCriterion(1, "huber")
