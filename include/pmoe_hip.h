@@ -299,6 +299,39 @@ int pmoe_blend_bwd(const float* moe_actions, const float* punet_actions, const f
                    const float* out, const float* dout, float* dlat_w, float* dlat_b, float* dlong_w, float* dlong_b,
                    float* dpunet, int32_t B, void* stream);
 
+/* ---- stage-1 PU-Net training (trainer/train_1.py:129-141) ------------------------------------------
+ * Backward of nn.MaxPool2d(2,2) (blocks/unet.py:52-62): dx = scatter of dy to the FIRST maximum of each 2x2 window of x
+ * (torch's tie rule) + dskip, the gradient that reaches the same activation through the skip concatenation
+ * (unet.py:71-84; NULL = none).  x and dskip may be channel windows (ld, coff) of wider buffers; dx, dy are dense. */
+int pmoe_maxpool2s2_bwd(const void* x, int32_t x_ld, int32_t x_coff, const void* dy, const void* dskip, int32_t dskip_ld,
+                        int32_t dskip_coff, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                        void* stream);
+/* backward of pmoe_pixel_shuffle2 (nn.ConvTranspose2d(k=2,s=2) scatter, unet.py:34-44):
+ * dst[n,y,x,(dy*2+dx)*C + c] = src[n,2y+dy,2x+dx,src_coff + c];  src [N][2H][2W][src_ld], dst [N][H][W][dst_ld >= 4C] */
+int pmoe_pixel_unshuffle2(const void* src, int32_t src_ld, int32_t src_coff, void* dst, int32_t dst_ld, int32_t N, int32_t H,
+                          int32_t W, int32_t C, int32_t dtype, void* stream);
+/* gradient of torch.cat along channels (punet.py:104,113): dst[r, dst_coff + c] += src[r, src_coff + c] */
+int pmoe_add_window(const void* src, int32_t src_ld, int32_t src_coff, void* dst, int32_t dst_ld, int32_t dst_coff,
+                    int64_t rows, int32_t C, int32_t dtype, void* stream);
+/* module boundary of PredictiveUnet.forward (punet.py:117-120 returns NCHW f32): src T [N][HW][src_ld] channel window
+ * -> dst f32 [N][C][HW] */
+int pmoe_nhwc_to_nchw(const void* src, int32_t src_ld, int32_t src_coff, float* dst, int32_t N, int64_t HW, int32_t C,
+                      int32_t dtype, void* stream);
+/* AutoregressiveCriterion (trainer/loss.py:86-118).  logits f32 [B][F][C][H][W], target int64 [B][F][H][W], C <= 32.
+ * mode 0 'tversky': per frame ce_weight * cross_entropy(weight = class_dice, loss.py:6-17,48-57) + tversky_weight *
+ * tversky_loss (loss.py:34-45 -- its TP/FP/FN ratio is formed per (class, image column), as the reference does);
+ * mode 1 'l1' / mode 2 'l2': mean |x - onehot| / (x - onehot)^2 per frame.  loss[0] = sum over frames, loss[1+f] per frame.
+ * Scratch (f32): partT [F][pmoe_seg_loss_rows()][3][pmoe_seg_loss_cp(C)][W] (upper bound), partG [F][rows][4][32],
+ * coefG [F][32], coefT [F][2][cp][W]; coefG / coefT feed pmoe_seg_loss_bwd, which writes d loss / d logits scaled by
+ * dloss[0] (device scalar; NULL = 1). */
+int pmoe_seg_loss_rows(int32_t B, int32_t H, int32_t W);
+int pmoe_seg_loss_cp(int32_t C);
+int pmoe_seg_loss_fwd(const float* logits, const int64_t* target, int32_t B, int32_t F, int32_t C, int32_t H, int32_t W,
+                      int32_t mode, float ce_weight, float tversky_weight, float alpha, float beta, float* partT, float* partG,
+                      float* coefG, float* coefT, float* loss, void* stream);
+int pmoe_seg_loss_bwd(const float* logits, const int64_t* target, const float* coefG, const float* coefT, const float* dloss,
+                      float* dlogits, int32_t B, int32_t F, int32_t C, int32_t H, int32_t W, int32_t mode, void* stream);
+
 /* ---- fused optimizer tail of the stage-2 step (reference caller trainer/train_2.py:157-165,184 + conf
  * stage_2_pmoe.yaml:11,137-144): torch.nn.utils.clip_grad_norm_, torch.optim.Adam(amsgrad=True).step() and
  * torch.optim.swa_utils.AveragedModel.update_parameters, each as ONE launch over a chunk table instead of a few

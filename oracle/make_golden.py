@@ -393,7 +393,7 @@ def main():
         res = run_pmoe_case(ref_moe, ref_loss, "p5_pmoe_e2_b2_64_f2", 2, 64, 2, 2)
         torch.save(res, gold / "p5_pmoe_e2_b2_64_f2.pt")
         print("p5_pmoe_e2_b2_64_f2", float(res["loss"]), res["actions"].tolist())
-    for name, b, sz, f in [("s1_stage1_b3_32_f3", 3, 32, 3), ("s2_stage1_b2_64_f6", 2, 64, 6)]:
+    for name, b, sz, f in [("s1_stage1_b3_32_f3", 3, 32, 3), ("s2_stage1_b8_32_f2", 8, 32, 2)]:
         if only and name not in only:
             continue
         res = run_stage1_case(ref_loss, name, b, sz, f)

@@ -425,7 +425,7 @@ def cross_entropy_tversky_weighted_loss(pred, target, cross_entropy_weight=0.5, 
     """``trainer/loss.py:48-57``."""
     if cross_entropy_weight + tversky_weight != 1:
         raise ValueError("Cross Entropy weight and Tversky weight should sum to 1")
-    ce = F.cross_entropy(pred, target, weight=class_dice_weights(pred, target))
+    ce = F.cross_entropy(pred, target, weight=class_dice_weights(pred, target).to(pred.dtype))   # (cast: float64 checks)
     return cross_entropy_weight * ce + tversky_weight * tversky_loss(pred, target)
 
 

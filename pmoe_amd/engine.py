@@ -191,17 +191,22 @@ class ExpertGroupEngine:
                         l_act=spec["l_act"], dropout=spec["dropout"])
 
         self._mk = dict(conv=conv, bn=bn, eca=eca, mlp=mlp)
-        self.speed_enc = mlp("speed_encoder", [e.speed_encoder for e in ex])
-        self.cmd_enc = mlp("command_encoder", [e.command_encoder for e in ex])
-        self._collect_pre_backbone(ex)
-        self._collect_backbone([e.backbone for e in ex])
-        self._collect_heads(ex)
+        self._collect_network(ex)
         del self._mk
         if self.conv1 is not None:
             self.conv1.need_dgrad = self._stem_needs_dgrad()
         self.all_convs = [p[1] for p in self.params if p[0] == "w"]
         self.all_bns = [p[1] for p in self.params if p[0] == "gamma"]
         self.flat_params = [p for _, _, plist in self.params for p in plist]
+
+    def _collect_network(self, ex):
+        """layers in FORWARD order (the gradient arena is laid out in the reverse of this order)."""
+        mlp = self._mk["mlp"]
+        self.speed_enc = mlp("speed_encoder", [e.speed_encoder for e in ex])
+        self.cmd_enc = mlp("command_encoder", [e.command_encoder for e in ex])
+        self._collect_pre_backbone(ex)
+        self._collect_backbone([e.backbone for e in ex])
+        self._collect_heads(ex)
 
     def _collect_pre_backbone(self, ex):
         """hook: layers that run before the ResNet backbone (the frozen PU-Net of PUNetExpert)."""
@@ -409,6 +414,9 @@ class ExpertGroupEngine:
                          ks=layer.ks, stride=layer.stride, pad=layer.pad, x_shared=in_shared, x_coff=x.coff,
                          dy_coff=o.coff)
         parts = getattr(layer, "parts", None)
+        if hasattr(layer, "store_grads"):       # derived layouts (ConvTranspose2d as a 4*Cout-row 1x1 layer, engine_punet)
+            layer.store_grads(self, ws, cow, cpw)
+            return
         if parts is None:
             ops.unpack_conv_wgrad(ws, self._grad_slot("w", layer), E, layer.cout, layer.cin, layer.ks, cow, cpw)
         else:
@@ -418,16 +426,27 @@ class ExpertGroupEngine:
             self._grad_slot("w_part", (layer, "action_pred")).view(E, ra, layer.cin).copy_(full[:, 0:ra])
             self._grad_slot("w_part", (layer, "alpha")).view(E, layer.cout - ra, layer.cin).copy_(full[:, ra:])
         if layer.biases is not None:
-            rpe = self.B * dy.shape[1] * dy.shape[2]
-            part = torch.empty(E, 1, 2, layer.cout_st, dtype=F32, device=self.dev)
-            ops.colstats(rpe, dy, E, layer.cout_st, part, 1, ld=dy.shape[-1], coff=o.coff)
-            sums = part[:, 0, 0, :layer.cout]
+            sums = self._colsum(dy, self.B * dy.shape[1] * dy.shape[2], layer.cout_st, o.coff)[:, :layer.cout]
             if parts is None:
                 self._grad_slot("b", layer).view(E, layer.cout).copy_(sums)
             else:
                 ra = parts[0][2]
                 self._grad_slot("b_part", (layer, "action_pred")).view(E, ra).copy_(sums[:, 0:ra])
                 self._grad_slot("b_part", (layer, "alpha")).view(E, layer.cout - ra).copy_(sums[:, ra:])
+
+    def _colsum(self, t, rpe, C, coff=0):
+        """per-expert column sums [E,C] (f32) of the channel window [coff, coff+C) of ``t``: partial rows over enough
+        workgroups to stream at HBM rate, then fixed-order folds (bias gradients of conv layers with many pixels)."""
+        E = self.E
+        nparts = self._nparts(rpe)
+        part = torch.empty(E, nparts, 2, C, dtype=F32, device=self.dev)
+        ops.colstats(rpe, t, E, C, part, nparts, ld=t.shape[-1], coff=coff)
+        if nparts > 1:
+            part, nparts = self._fold_parts(part, nparts, 2 * C)
+            one = torch.empty(E, 1, 2, C, dtype=F32, device=self.dev)
+            ops.reduce_partials(part, one, E, nparts, 1, 2 * C)
+            part = one
+        return part[:, 0, 0]
 
     def _dgrad_block(self, x, layer, o, dy, flop):
         if x.needs_grad:
@@ -491,12 +510,19 @@ class ExpertGroupEngine:
             raise RuntimeError("fused stats width mismatch")
         scale, shift, mean, invstd = self._bn_coeffs(layer, rpe, stats, stats.shape[0] // E if stats is not None else 0, z)
         # out: write into the channel window [out_coff, out_coff + C) of a wider buffer (U-Net skip concatenation)
-        y = Var(torch.empty_like(z.t)) if out is None else out.window(out_coff, C_)
-        if out is not None and self.taping:
-            raise RuntimeError("BatchNorm into a channel window is forward-only (frozen U-Nets)")
+        # taped: the window gets its OWN (dense) gradient slot -- its consumers' backward fills it (U-Net skip: the
+        # max-pool backward adds the concatenation buffer's gradient window, engine_punet._maxpool2)
+        if out is None:
+            y = Var(torch.empty_like(z.t))
+        elif self.taping:
+            y = Var(out.t, C_, out_coff)
+        else:
+            y = out.window(out_coff, C_)
         ops.set_meta(name=layer.name, bytes=z.t.numel() * z.t.element_size() * (3 if res is not None else 2))
         ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, mean, rpe, E, C_, relu, y_coff=y.coff)
         y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
+        if out is not None and y.needs_grad:
+            out.needs_grad = True
         if self.taping and y.needs_grad:
             train = self.training
             self.tape.append(lambda: self._bn_bwd(z, layer, y, res, relu, scale, shift, mean, invstd, rpe, train))
@@ -518,8 +544,10 @@ class ExpertGroupEngine:
         ops.bn_bwd_reduce(dy, ysrc, z.t, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts)
         part, nparts = self._fold_parts(part, nparts, 2 * C_)
         c1, c2 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(2))
-        ops.bn_bwd_finalize(part, nparts, rpe, self._grad_slot("gamma", layer).view(E, C_),
-                            self._grad_slot("beta", layer).view(E, C_), c1, c2, E, C_)
+        dgamma, dbeta, store = self._bn_grad_views(layer)
+        ops.bn_bwd_finalize(part, nparts, rpe, dgamma, dbeta, c1, c2, E, C_)
+        if store is not None:
+            store()
         if not train:          # eval-mode BN is an affine map: no batch-statistics terms
             c1.zero_()
             c2.zero_()
@@ -543,6 +571,11 @@ class ExpertGroupEngine:
             if res.grad is not None:
                 raise RuntimeError("residual gradient slot already filled")
             res.set_grad(gm)
+
+    def _bn_grad_views(self, layer):
+        """[E,C] views for d gamma / d beta of ``layer`` (+ an optional store step; hook for channel-padded BatchNorms)."""
+        return (self._grad_slot("gamma", layer).view(self.E, layer.C), self._grad_slot("beta", layer).view(self.E, layer.C),
+                None)
 
     def _stem_tail(self, z2, stats):
         """relu(bn_c2(z2)) -> relu(bn1(.)) -> maxpool(3,2,1) without materialising the two intermediates

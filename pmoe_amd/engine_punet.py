@@ -29,7 +29,15 @@ class _UpConv(GroupedConv):
 
     @property
     def trainable(self):
-        return False
+        return self.mod.weight.requires_grad or self.mod.bias.requires_grad
+
+    def store_grads(self, eng, ws, cow, cpw):
+        """weight gradient of the 4*Cout-row 1x1 layer -> ConvTranspose2d layout [cin, cout, 2, 2] (a strided copy);
+        the bias gradient is taken from the un-shuffled output gradient in PUNetEngine._up_bwd."""
+        full = torch.empty(1, self.cout, self.cin, dtype=F32, device=eng.dev)
+        ops.unpack_conv_wgrad(ws, full, 1, self.cout, self.cin, 1, cow, cpw)
+        eng._grad_slot("wT", self).view(self.cin, self.c_up, 2, 2).copy_(
+            full.view(2, 2, self.c_up, self.cin).permute(3, 2, 0, 1))
 
     def pack_derived(self, dev):
         m = self.mod
@@ -39,13 +47,15 @@ class _UpConv(GroupedConv):
         # [cin, cout, 2, 2] -> [(dy, dx, cout), cin, 1, 1]: parameter re-layout of a frozen weight (host-side plumbing)
         w = m.weight.detach().permute(2, 3, 1, 0).reshape(self.cout, self.cin, 1, 1).contiguous()
         b = m.bias.detach().repeat(4).contiguous()
-        ops.pack_conv_weights(hip.ptr_table([w], dev), self.w_fwd, None, 1, self.cout, self.cin, 1, self.coutp, self.cinp,
-                              self.dg_rows, self.dg_red, self.w_fwd.dtype)
+        ops.pack_conv_weights(hip.ptr_table([w], dev), self.w_fwd, self.w_dg, 1, self.cout, self.cin, 1, self.coutp,
+                              self.cinp, self.dg_rows, self.dg_red, self.w_fwd.dtype)
         ops.pack_bias(hip.ptr_table([b], dev), self.bias_packed, 1, self.cout, self.coutp)
         self._derived_version = ver
 
 
 class PUNetEngine(ExpertGroupEngine):
+    _punet_trains = False
+
     def __init__(self, expert):
         self.return_inter = expert.return_inter
         super().__init__([expert], alt=False)
@@ -67,7 +77,10 @@ class PUNetEngine(ExpertGroupEngine):
                           bn2=self._padded_bn("punet.entry.bn2", eb.layer2.conv2[1]))
         self.pred_unet = self._collect_unet("punet.pred_unet", pu.pred_unet)
         for layer in self._punet_convs():
-            layer.need_dgrad = False
+            layer.need_dgrad = self._punet_trains        # stage 2 freezes the PU-Net: no data gradients at all
+        for U in (self.unet, self.pred_unet):
+            for up in U["up"]:
+                up.need_dgrad = self._punet_trains
 
     def _punet_convs(self):
         out = []
@@ -92,6 +105,17 @@ class PUNetEngine(ExpertGroupEngine):
         self.params.append(("gamma_real", layer, [mod.weight]))     # kept in the flat parameter list (frozen: no slot use)
         self.params.append(("beta_real", layer, [mod.bias]))
         return layer
+
+    def _bn_grad_views(self, layer):
+        creal = getattr(layer, "creal", None)
+        if creal is None:
+            return super()._bn_grad_views(layer)
+        dg, db = (torch.empty(1, layer.C, dtype=F32, device=self.dev) for _ in range(2))
+
+        def store():
+            self._grad_slot("gamma_real", layer).copy_(dg[0, :creal])
+            self._grad_slot("beta_real", layer).copy_(db[0, :creal])
+        return dg, db, store
 
     def _collect_unet(self, name, U):
         conv, bn = self._mk["conv"], self._mk["bn"]
@@ -166,11 +190,36 @@ class PUNetEngine(ExpertGroupEngine):
         a = self._conv_bn(x, blk["c1"], blk["bn1"], relu=True)
         return self._conv_bn(a, blk["c2"], blk["bn2"], relu=True, out=out)
 
-    def _maxpool2(self, x):
+    def _maxpool2(self, x, cat=None):
         n, h, w, _ = x.t.shape
         y = Var(self._new(n, h // 2, w // 2, x.c))
         ops.maxpool2_fwd(x.t, y.t, c=x.c, x_coff=x.coff)      # x may be the skip window of a concatenation buffer
+        y.needs_grad = x.needs_grad
+        if self.taping and y.needs_grad:
+            def bwd():
+                # gradient of the skip activation = pooled path + its half of the concatenation buffer's gradient
+                skip = cat.grad if cat is not None else None
+                if y.grad is None:
+                    return
+                dx = self._new(n, h, w, x.c)
+                ops.maxpool2_bwd(x.t, y.grad, dx, dskip=skip, c=x.c, x_coff=x.coff, dskip_coff=x.coff)
+                x.set_grad(dx)
+            self.tape.append(bwd)
         return y
+
+    def _up_bwd(self, t, up, cat):
+        """backward of the ConvTranspose2d scatter: un-shuffle the 'up' half of the concatenation gradient into the
+        4*Cout-row layout of the 1x1 layer; its per-channel sum is the ConvTranspose2d bias gradient."""
+        g = cat.grad
+        if g is None:
+            return
+        n, h2, w2, ld = g.shape
+        c = up.c_up
+        if up.mod.bias.requires_grad:
+            self._grad_slot("bT", up).copy_(self._colsum(g, n * h2 * w2, c, coff=c)[0])
+        dt = torch.empty_like(t.t)
+        ops.pixel_unshuffle2(g, dt, c, src_coff=c)
+        t.set_grad(dt)
 
     def _unet_fwd(self, U, x):
         """blocks/unet.py:49-95.  x [B,H,W,16] (3 real channels) -> masks [B,H,W,r16(num_classes)] (+ bottleneck)."""
@@ -186,13 +235,16 @@ class PUNetEngine(ExpertGroupEngine):
             cat = Var(self._new(n, hh, ww, 2 * c))          # torch.cat([x_k, up], 1) buffer (unet.py:72)
             a = self._conv3(h, U["dwn"][i], out=cat)       # the block's last BatchNorm writes the skip half directly
             cats.append(cat)
-            h = self._maxpool2(a)
+            h = self._maxpool2(a, cat)
             hh, ww = hh // 2, ww // 2
         x5 = h = self._conv3(h, U["dwn"][4])
         for j in range(4):
             cat, up = cats[3 - j], U["up"][j]
             t = self._conv(h, up, bias=True)                                  # [n, h, w, 4*Cout]
             ops.pixel_shuffle2(t.t, cat.t, up.c_up, dst_coff=up.c_up)
+            if self.taping and t.needs_grad:
+                cat.needs_grad = True
+                self.tape.append(lambda t=t, up=up, cat=cat: self._up_bwd(t, up, cat))
             h = self._conv3(cat, U["up_forw"][j])
         return self._conv(h, U["out"], bias=True), x5
 
@@ -228,15 +280,33 @@ class PUNetEngine(ExpertGroupEngine):
             x0 = Var(torch.zeros(Bsz, H, W, r16(F_ * nc), dtype=self.dtype, device=self.dev))
         inter = None
         for f in range(F_):
+            if self.taping:
+                self._step_begin(f)
             cat = Var(torch.zeros(Bsz, H, W, r16(T * nc), dtype=self.dtype, device=self.dev))
-            for k, m in enumerate(masks[-T:]):
+            srcs = masks[-T:]
+            for k, m in enumerate(srcs):
                 ops.copy_window(m.t, 0, cat.t, k * nc, nc)
+            cat.needs_grad = any(m.needs_grad for m in srcs)
+            if self.taping and cat.needs_grad:
+                # gradient of torch.cat (punet.py:104,113): each window is ADDED to its mask's gradient (a predicted mask
+                # feeds up to T later steps and the loss)
+                def cat_bwd(cat=cat, srcs=srcs):
+                    if cat.grad is None:
+                        return
+                    for k, m in enumerate(srcs):
+                        if m.needs_grad:
+                            ops.add_window(cat.grad, k * nc, m.grad, 0, nc)
+                self.tape.append(cat_bwd)
             e = self._entry_fwd(cat)
             m, inter = self._unet_fwd(self.pred_unet, e)
             masks.append(m)
             if x0 is not None:
                 ops.copy_window(m.t, 0, x0.t, f * nc, nc)         # torch.stack(outs,1).view(B,-1,H,W)  (punet.py:120, moe.py:311)
+        self._pred_masks = masks[T:] if self.taping else None
         return x0, inter
+
+    def _step_begin(self, f):
+        """hook: start of autoregressive step ``f`` while taping (the stage-1 engine accumulates shared-weight gradients)."""
 
     # ------------------------------------------------------------------ network
     def forward(self, images, speed, command, training, taping, dtype, base_seed=0):
@@ -287,3 +357,96 @@ class PUNetEngine(ExpertGroupEngine):
             head.set_grad(dhead)
         if dspeeds is not None:
             sp.set_grad(dspd)
+
+
+class PredictiveUnetEngine(PUNetEngine):
+    """``PredictiveUnet`` on its own (``model/punet.py:75-120``): stage-1 training (``trainer/train_1.py:129-141``,
+    SURVEY.md section 8f N4) and plain segmentation-forecast inference.
+
+    ``entry_block`` and ``pred_unet`` train, ``unet`` stays frozen (punet.py:46-48).  The autoregressive loop applies
+    the SAME weights ``future_frames`` times, so backward is back-propagation through time: every step's closures write
+    the gradient arena, and a closure recorded at the start of each step adds the arena into an accumulator and clears it
+    (the last one to run adds the accumulator back), so the layer backward code stays "write, don't accumulate".
+    A predicted mask receives gradient from the loss and from up to ``past_frames`` later steps through the channel
+    concatenation (``add_window``)."""
+    _punet_trains = True
+
+    def __init__(self, punet):
+        import types
+        self.return_inter = bool(punet.inter_repr)
+        ExpertGroupEngine.__init__(self, [types.SimpleNamespace(punet=punet)], alt=False)
+
+    def _collect_network(self, ex):
+        self._collect_pre_backbone(ex)
+        self.conv1 = self.eca1 = self.head = None
+        self.blocks = []
+        for blk in self.unet["dwn"] + self.unet["up_forw"]:          # frozen, fed by images: no data gradients
+            blk["c1"].need_dgrad = blk["c2"].need_dgrad = False
+        self.unet["out"].need_dgrad = False
+        for up in self.unet["up"]:
+            up.need_dgrad = False
+
+    def _step_begin(self, f):
+        first = f == 0
+
+        def flush():
+            n = self._arena_numel
+            if first:
+                ops.add_window(self._acc.view(1, n), 0, self._arena.view(1, n), 0, n)
+                self._acc = None
+                self._accum_done = True
+            else:
+                ops.add_window(self._arena.view(1, n), 0, self._acc.view(1, n), 0, n)
+                self._arena.zero_()
+        self.tape.append(flush)
+
+    def _final_prefix(self):
+        # slots are final only after the last accumulation (data-parallel buckets all fly at the end of backward)
+        return super()._final_prefix() if self._accum_done else 0
+
+    def forward(self, images, training, taping, dtype):
+        """images [B,T,C,H,W] f32 -> logits [B,F,classes,H,W] f32 (or the bottleneck feature [B,512] with ``inter_repr``)."""
+        pu = self.pu
+        if taping and self.return_inter:
+            raise NotImplementedError("PredictiveUnet(inter_repr=True) is inference-only (punet.py:99: 'not suitable for "
+                                      "training')")
+        for p in pu.unet.parameters():
+            if p.requires_grad:
+                raise NotImplementedError("PredictiveUnet.unet must stay frozen (punet.py:46-48); stage-0 U-Net training is "
+                                          "out of scope (SURVEY.md section 8)")
+        Bsz = self._begin(images, training, taping, dtype, 0)
+        self._shadows_in()
+        x0, inter = self._punet_fwd(images)
+        self._shadows_out()
+        self._bump_batch_counters()
+        H, W = images.shape[-2:]
+        if self.return_inter:
+            feat = Var(self._new(Bsz, 1, 1, inter.c))
+            self._gap_to(inter, feat, 0)
+            out = feat.t.view(Bsz, -1).float()
+        else:
+            F_, nc = pu.n_future_frames, pu.num_classes
+            out = torch.empty(Bsz, F_ * nc, H, W, dtype=F32, device=self.dev)
+            ops.nhwc_to_nchw(x0.t, out, F_ * nc)
+            out = out.view(Bsz, F_, nc, H, W)
+        state = dict(tape=self.tape, tail=self._pred_masks, B=self.B, N=self.N, dev=self.dev, dtype=self.dtype)
+        self.tape = self._pred_masks = None
+        return out, state
+
+    def _tail_bwd(self, masks, dout):
+        """d loss / d logits [B,F,classes,H,W] f32 -> the initial gradient of every predicted mask (NHWC, zero padded)."""
+        if dout is None:
+            return
+        Bsz, F_, nc, H, W = dout.shape
+        g = self._new(Bsz, H, W, r16(F_ * nc))
+        ops.nchw_to_nhwc(dout.contiguous().float().view(Bsz, F_ * nc, H, W), g)
+        for f, m in enumerate(masks):
+            mg = torch.zeros_like(m.t)
+            ops.copy_window(g, f * nc, mg, 0, nc)
+            m.set_grad(mg)
+
+    def backward(self, tape_state, *douts):
+        self._accum_done = False
+        n = sum(p.numel() for p in self.flat_params)
+        self._acc = torch.zeros(n, dtype=F32, device=tape_state["dev"])
+        return super().backward(tape_state, *douts)

@@ -103,6 +103,14 @@ SIGNATURES = {
     "pmoe_action_loss": [_P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P],
     "pmoe_blend_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P],
     "pmoe_blend_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "pmoe_maxpool2s2_bwd": [_P, _I, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P],
+    "pmoe_pixel_unshuffle2": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_add_window": [_P, _I, _I, _P, _I, _I, _L, _I, _I, _P],
+    "pmoe_nhwc_to_nchw": [_P, _I, _I, _P, _I, _L, _I, _I, _P],
+    "pmoe_seg_loss_rows": [_I, _I, _I],
+    "pmoe_seg_loss_cp": [_I],
+    "pmoe_seg_loss_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
+    "pmoe_seg_loss_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_resample_u8_horizontal": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "pmoe_resample_u8_vertical_to_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "pmoe_mt_grad_norm": [_P, _P, _P, _I, _F, _P, _P, _I, _P],

@@ -81,3 +81,43 @@ def pmoe_loss(actions, speed_pred, actions_gt, speed_gt, loss_coefs):
     if actions.shape != actions_gt.shape or actions.dim() != 2 or actions.shape[1] != 2:
         raise ValueError("pmoe_loss: actions and actions_gt must both be [B,2]")
     return _ActionLossFn.apply(actions, None, actions_gt, None, 1.0, 0.0)
+
+
+class _SegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, mode):
+        lg = logits.contiguous().float()
+        tg = target.contiguous()
+        loss, coefG, coefT = ops.seg_loss_fwd(lg, tg, mode)
+        ctx.mode, ctx.saved = mode, (lg, tg, coefG, coefT)
+        ctx.frame_losses = loss[1:]
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, tg, coefG, coefT = ctx.saved
+        ctx.saved = None
+        dl = torch.empty_like(lg)
+        ops.seg_loss_bwd(lg, tg, coefG, coefT, g.contiguous().float().view(1), dl, ctx.mode)
+        return dl, None, None
+
+
+class AutoregressiveCriterion(torch.nn.Module):
+    """Drop-in for ``trainer/loss.py:86-118`` (stage-1 PU-Net training, train_1.py:75-77,134): the per-frame loss summed
+    over the predicted frames, in three HIP launches forward and one backward.  ``inputs`` [B,T,C,H,W] logits (f32, as
+    ``PredictiveUnet.forward`` returns them), ``targets`` [B,T,H,W] int64 class indices.  ``'tversky'`` is
+    ``0.5 * cross_entropy(weight = 1 - class dice) + 0.5 * tversky_loss`` exactly as the reference computes it,
+    including its per-(class, image column) Tversky ratio (loss.py:40)."""
+
+    def __init__(self, n_target_frames: int = 1, loss_type: str = "tversky"):
+        super().__init__()
+        if loss_type not in ops.SEG_MODES:
+            raise ValueError(f"Unknown loss type {loss_type}, supported ones are L1, L2, and tversky")
+        self.n_target_frames, self.loss_type = n_target_frames, loss_type
+
+    def forward(self, inputs, targets):
+        assert inputs.size(1) == self.n_target_frames
+        assert targets.size(1) == self.n_target_frames
+        if targets.dtype != torch.int64:
+            raise ValueError("AutoregressiveCriterion: targets must be int64 class indices (data_loader.py segmentation masks)")
+        return _SegLossFn.apply(inputs, targets, self.loss_type)

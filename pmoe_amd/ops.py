@@ -395,6 +395,83 @@ def copy_window(src, src_coff, dst, dst_coff, c):
                                   dst_coff, rows, c, dt(src), stream_ptr()), "pmoe_copy_window")
 
 
+def maxpool2_bwd(x, dy, dx, dskip=None, c=None, x_coff=0, dskip_coff=0):
+    """Backward of MaxPool2d(2,2) over the channel window [x_coff, x_coff+c) of ``x``: ``dx`` (dense [N,H,W,c]) = dy at
+    the first maximum of every 2x2 window + the same window of ``dskip`` (skip-concatenation gradient) if given."""
+    n, h, w_, ld = _nhwc(x, "x")
+    c = ld if c is None else c
+    if tuple(dx.shape) != (n, h, w_, c) or tuple(dy.shape) != (n, h // 2, w_ // 2, c):
+        raise ValueError(f"maxpool2_bwd: dx must be {(n, h, w_, c)} and dy {(n, h // 2, w_ // 2, c)}")
+    if dskip is not None and tuple(dskip.shape[:3]) != (n, h, w_):
+        raise ValueError("maxpool2_bwd: dskip must share x's geometry")
+    check(load().pmoe_maxpool2s2_bwd(ptr(x, "x"), ld, x_coff, ptr(dy, "dy", x.dtype), ptr(dskip, "dskip", x.dtype),
+                                     dskip.shape[-1] if dskip is not None else 0, dskip_coff, ptr(dx, "dx", x.dtype), n, h,
+                                     w_, c, dt(x), stream_ptr()), "pmoe_maxpool2s2_bwd")
+
+
+def pixel_unshuffle2(src, dst, c, src_coff=0):
+    """dst[n,y,x,(dy*2+dx)*c + k] = src[n,2y+dy,2x+dx,src_coff + k]  (backward of pixel_shuffle2)."""
+    n, h2, w2, sld = _nhwc(src, "src")
+    if tuple(dst.shape[:3]) != (n, h2 // 2, w2 // 2) or dst.shape[-1] < 4 * c:
+        raise ValueError("pixel_unshuffle2: dst must be [N,H/2,W/2,>=4c]")
+    check(load().pmoe_pixel_unshuffle2(ptr(src, "src"), sld, src_coff, ptr(dst, "dst", src.dtype), dst.shape[-1], n, h2 // 2,
+                                       w2 // 2, c, dt(src), stream_ptr()), "pmoe_pixel_unshuffle2")
+
+
+def add_window(src, src_coff, dst, dst_coff, c):
+    """dst[..., dst_coff:dst_coff+c] += src[..., src_coff:src_coff+c] over all leading rows."""
+    rows = src.numel() // src.shape[-1]
+    if dst.numel() // dst.shape[-1] != rows:
+        raise ValueError("add_window: row counts differ")
+    check(load().pmoe_add_window(ptr(src, "src"), src.shape[-1], src_coff, ptr(dst, "dst", src.dtype), dst.shape[-1],
+                                 dst_coff, rows, c, dt(src), stream_ptr()), "pmoe_add_window")
+
+
+def nhwc_to_nchw(src, dst, c, src_coff=0):
+    """src [N,H,W,ld] (bf16/f32) channel window -> dst f32 [N,c,H,W]."""
+    n, h, w_, ld = _nhwc(src, "src")
+    if tuple(dst.shape) != (n, c, h, w_):
+        raise ValueError(f"nhwc_to_nchw: dst must be {(n, c, h, w_)}, got {tuple(dst.shape)}")
+    check(load().pmoe_nhwc_to_nchw(ptr(src, "src"), ld, src_coff, ptr(dst, "dst", torch.float32), n, h * w_, c, dt(src),
+                                   stream_ptr()), "pmoe_nhwc_to_nchw")
+
+
+SEG_MODES = {"tversky": 0, "l1": 1, "l2": 2}
+
+
+def seg_loss_fwd(logits, target, mode, ce_weight=0.5, tversky_weight=0.5, alpha=0.5, beta=0.5):
+    """AutoregressiveCriterion forward.  logits f32 [B,F,C,H,W], target int64 [B,F,H,W] -> (loss[1+F], coefG, coefT)."""
+    if logits.dim() != 5 or tuple(target.shape) != (logits.shape[0], logits.shape[1]) + tuple(logits.shape[3:]):
+        raise ValueError(f"seg_loss: logits [B,F,C,H,W] and target [B,F,H,W] expected, got {tuple(logits.shape)} / "
+                         f"{tuple(target.shape)}")
+    b, f, c, h, w_ = logits.shape
+    f32, dev = torch.float32, logits.device
+    lib = load()
+    rows, cp = lib.pmoe_seg_loss_rows(b, h, w_), lib.pmoe_seg_loss_cp(c)
+    if rows < 1 or cp < 1:
+        raise ValueError(f"seg_loss: unsupported shape (C={c} must be 2..32)")
+    m = SEG_MODES[mode]
+    partG = torch.empty(f, rows, 4, 32, dtype=f32, device=dev)
+    loss = torch.empty(1 + f, dtype=f32, device=dev)
+    partT = coefG = coefT = None
+    if m == 0:
+        partT = torch.empty(f, rows, 3, cp, w_, dtype=f32, device=dev)
+        coefG = torch.empty(f, 32, dtype=f32, device=dev)
+        coefT = torch.empty(f, 2, cp, w_, dtype=f32, device=dev)
+    check(lib.pmoe_seg_loss_fwd(ptr(logits, "logits", f32), ptr(target, "target", torch.int64), b, f, c, h, w_, m, ce_weight,
+                                tversky_weight, alpha, beta, ptr(partT), ptr(partG), ptr(coefG), ptr(coefT), ptr(loss),
+                                stream_ptr()), "pmoe_seg_loss_fwd")
+    return loss, coefG, coefT
+
+
+def seg_loss_bwd(logits, target, coefG, coefT, dloss, dlogits, mode):
+    b, f, c, h, w_ = logits.shape
+    f32 = torch.float32
+    check(load().pmoe_seg_loss_bwd(ptr(logits, "logits", f32), ptr(target, "target", torch.int64), ptr(coefG), ptr(coefT),
+                                   ptr(dloss, "dloss", f32), ptr(dlogits, "dlogits", f32), b, f, c, h, w_, SEG_MODES[mode],
+                                   stream_ptr()), "pmoe_seg_loss_bwd")
+
+
 def action_head_fwd(head, spd, actions, speeds, B):
     f32 = torch.float32
     check(load().pmoe_action_head_fwd(ptr(head, "head"), head.shape[-1], ptr(spd, "spd", head.dtype), spd.shape[-1],
@@ -436,5 +513,6 @@ def blend_bwd(moe_act, pu_act, lat_w, long_w, out, dout, dlat_w, dlat_b, dlong_w
 
 
 for _n in ("maxpool2_fwd", "pixel_shuffle2", "copy_window", "action_head_fwd", "action_head_bwd", "action_loss",
-           "blend_fwd", "blend_bwd"):
+           "blend_fwd", "blend_bwd", "maxpool2_bwd", "pixel_unshuffle2", "add_window", "nhwc_to_nchw", "seg_loss_fwd",
+           "seg_loss_bwd"):
     globals()[_n] = _timed(globals()[_n])

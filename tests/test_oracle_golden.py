@@ -199,7 +199,7 @@ def _stage1_oracle(g, dtype=torch.float32):
     return model, inp["images"].to(dtype), tgt
 
 
-@pytest.mark.parametrize("name", ["s1_stage1_b3_32_f3", "s2_stage1_b2_64_f6"])
+@pytest.mark.parametrize("name", ["s1_stage1_b3_32_f3", "s2_stage1_b8_32_f2"])
 def test_stage1_training_step_matches_reference(golden_dir, name):
     """Stage-1 PU-Net training (train_1.py:129-141, punet.py:75-120, loss.py:86-118): restatement vs imported reference."""
     g = _load(golden_dir, name)
