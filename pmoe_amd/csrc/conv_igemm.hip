@@ -410,6 +410,8 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
     static int cfg42 = -1;      // PMOE_CONV_CFG42=0 switches back to the 4-wave tile (A/B measurements)
     if (cfg42 < 0) { const char* ev = getenv("PMOE_CONV_CFG42"); cfg42 = ev ? atoi(ev) : 1; }
     const bool big = wide && cfg42 && sizeof(T) == 2 && (long long)a.ipe * a.Ho * a.Wo >= 4096;   // not the MLP GEMMs
+    // (measured on the stage-1 U-Net at B = 10, where the 28x28 / 14x14 layers give < 256 workgroups: falling back to the
+    // 128-pixel 4-wave tile to double the workgroup count is SLOWER, 41.9 vs 32.3 ms of conv time per step)
     const int BM = wide ? (big ? 256 : 128) : 256, BN = wide ? 128 : 64;
     auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     // candidate chunk widths (bytes per pixel row in LDS), widest first

@@ -90,6 +90,16 @@ def main():
             d[1] += 1
         for k, (ms_, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:24]:
             print(f"  {k:24s} {ms_:8.2f} ms {n:5d} launches")
+        layers = {}
+        for name, meta, ms_ in rows:
+            if name in ("conv2d", "conv2d_wgrad") and "name" in meta:
+                key = (name, meta["name"].replace("punet.", ""))
+                d = layers.setdefault(key, [0.0, 0, 0.0])
+                d[0] += ms_
+                d[1] += 1
+                d[2] += meta.get("flop", 0.0)
+        for (op, nm), (ms_, n, fl) in sorted(layers.items(), key=lambda kv: -kv[1][0])[:40]:
+            print(f"  {op:13s} {nm:28s} {ms_:7.2f} ms {n:4d} launches {fl / ms_ / 1e9:7.0f} TFLOP/s")
 
 if __name__ == "__main__":
     main()
