@@ -70,6 +70,13 @@ class PredictiveUnet(B._Held):
                 self.__dict__["_eng"] = eng
         return new
 
+    def enable_data_parallel(self, group=None, n_buckets=6):
+        """Average parameter gradients over ``group`` (default WORLD) inside backward (pmoe_amd.parallel).  The roll-out
+        accumulates shared-weight gradients until its first step has run, so every bucket flies at the end of backward."""
+        eng = self._engine()
+        eng.dp_group, eng.dp_enabled, eng.dp_buckets = group, True, n_buckets
+        return self
+
     def forward(self, img_list):
         """``punet.py:75-120``: img_list [B,T,C,H,W] -> logits of the ``future_frames`` predicted masks [B,F,classes,H,W]
         (f32), or the bottleneck feature [B,512] when ``inter_repr`` (inference only)."""
