@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--dropout", type=float, default=0.3, help="stage_2*.yaml value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage1", action="store_true", help="skip the stage-1 PU-Net training step (section 8f N4)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--measure-overlap", action="store_true",
                     help="also time the step with weight gradients on a side stream (co-running kernels: keep it out of "
@@ -94,6 +95,38 @@ def cpu_baseline(args):
     return {"value": round(Bc * iters / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"{iters} x (fwd+moe_loss+bwd) at batch {Bc}, {args.size}x{args.size}, "
             f"E={args.experts}, fp32, torch {torch.__version__} CPU"}
+
+
+def stage1_step(dev, batch=10, size=224, frames=6, steps=3):
+    import tempfile
+    from pmoe_amd.loss import AutoregressiveCriterion
+    from pmoe_amd.model import blocks as B
+    from pmoe_amd.model.punet import PredictiveUnet
+    from pmoe_amd.optim import FusedAdam
+    path = os.path.join(tempfile.mkdtemp(), "unet.pth")
+    torch.save({"unet": B.UNet().state_dict()}, path)          # the constructor reads a stage-0 checkpoint (punet.py:40)
+    pu = PredictiveUnet(4, frames, model_name="unet", model_path=path).to(dev)
+    pu.train()
+    opt = FusedAdam([p for p in pu.parameters() if p.requires_grad], lr=1e-4)
+    crit = AutoregressiveCriterion(frames, "tversky")
+    img = torch.rand(batch, 4, 3, size, size, device=dev)
+    tgt = torch.randint(0, 23, (batch, frames, size, size), device=dev)
+
+    def one():
+        loss = crit(pu(img), tgt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": round(ms, 2), "samples_per_s": round(batch / ms * 1e3, 1),
+            "what": f"PredictiveUnet fwd + AutoregressiveCriterion('tversky') + bwd through the roll-out + Adam, B={batch} "
+                    f"{size}x{size} T=4 F={frames} bf16 (conf/stage_1.yaml)"}
 
 
 def main():
@@ -328,6 +361,12 @@ def main():
         fence()
         eng.overlap_wgrad = False
         out["overlap_wgrad_ms_per_step"] = round((time.perf_counter() - t0) / n_ov * 1e3, 3)
+
+    # ---- next-row N4: one stage-1 PU-Net training step at the reference's own configuration
+    # (conf/stage_1.yaml: batch 10, 224x224, 4 past / 6 predicted frames, 'tversky' criterion; train_1.py:129-141)
+    if rank == 0 and world == 1 and not args.no_stage1:
+        log("stage-1 PU-Net training step")
+        out["stage1_step"] = stage1_step(dev)
 
     log("H1 done; CPU baseline")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

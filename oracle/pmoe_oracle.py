@@ -304,7 +304,9 @@ class PredictiveUnet(nn.Module):
     def forward(self, img_list):
         assert img_list.shape[-4] == self.n_past_frames, "Number of images should match number of past frames"
         masks = [self.unet(img_list[:, i]) for i in range(self.n_past_frames)]
-        assert self.n_future_frames > 0 and not self.unet_inter_repr
+        assert not self.unet_inter_repr
+        if self.n_future_frames == 0:          # punet.py:91-96: segmentation of the current frame
+            return masks[-1]
         outs, inter = [], None
         for _ in range(self.n_future_frames):
             m = self.pred_unet(self.entry_block(torch.cat(masks[-self.n_past_frames:], dim=-3)))

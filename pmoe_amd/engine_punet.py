@@ -264,8 +264,8 @@ class PUNetEngine(ExpertGroupEngine):
         Bsz, T = images.shape[0], images.shape[1]
         if T != pu.n_past_frames:
             raise AssertionError("Number of images should match number of past frames")      # punet.py:84-86
-        if pu.n_future_frames == 0:
-            raise NotImplementedError("PU-Net with future_frames=0 (plain segmentation output) is not on the HIP path")
+        if pu.n_future_frames == 0 and not self._punet_trains:
+            raise NotImplementedError("PUNetExpert needs future_frames > 0 (moe.py:286-289 sizes its stem from it)")
         H, W = images.shape[-2:]
         nc, cpad = pu.num_classes, r16(pu.in_features)
         masks = []
@@ -275,6 +275,9 @@ class PUNetEngine(ExpertGroupEngine):
             out = self._unet_fwd(self.unet, xi)[0]
             masks.append(out)
         F_ = pu.n_future_frames
+        if F_ == 0:                                    # punet.py:91-96: segmentation of the current frame
+            self._pred_masks = None
+            return masks[-1], None
         x0 = None
         if not self.return_inter:
             x0 = Var(torch.zeros(Bsz, H, W, r16(F_ * nc), dtype=self.dtype, device=self.dev))
@@ -407,6 +410,9 @@ class PredictiveUnetEngine(PUNetEngine):
     def forward(self, images, training, taping, dtype):
         """images [B,T,C,H,W] f32 -> logits [B,F,classes,H,W] f32 (or the bottleneck feature [B,512] with ``inter_repr``)."""
         pu = self.pu
+        if pu.unet_inter_repr:
+            raise NotImplementedError("PredictiveUnet(unet_inter_repr=True) is never configured by the reference "
+                                      "(punet.py:33-39 passes the default)")
         if taping and self.return_inter:
             raise NotImplementedError("PredictiveUnet(inter_repr=True) is inference-only (punet.py:99: 'not suitable for "
                                       "training')")
@@ -426,16 +432,17 @@ class PredictiveUnetEngine(PUNetEngine):
             out = feat.t.view(Bsz, -1).float()
         else:
             F_, nc = pu.n_future_frames, pu.num_classes
-            out = torch.empty(Bsz, F_ * nc, H, W, dtype=F32, device=self.dev)
-            ops.nhwc_to_nchw(x0.t, out, F_ * nc)
-            out = out.view(Bsz, F_, nc, H, W)
+            out = torch.empty(Bsz, max(F_, 1) * nc, H, W, dtype=F32, device=self.dev)
+            ops.nhwc_to_nchw(x0.t, out, max(F_, 1) * nc)
+            if F_ > 0:
+                out = out.view(Bsz, F_, nc, H, W)
         state = dict(tape=self.tape, tail=self._pred_masks, B=self.B, N=self.N, dev=self.dev, dtype=self.dtype)
         self.tape = self._pred_masks = None
         return out, state
 
     def _tail_bwd(self, masks, dout):
         """d loss / d logits [B,F,classes,H,W] f32 -> the initial gradient of every predicted mask (NHWC, zero padded)."""
-        if dout is None:
+        if dout is None or not masks:
             return
         Bsz, F_, nc, H, W = dout.shape
         g = self._new(Bsz, H, W, r16(F_ * nc))

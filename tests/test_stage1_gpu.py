@@ -264,6 +264,20 @@ def test_stage1_eval_forward_and_no_grad(tmp_path):
     assert ((out.cpu() - ref).abs() / (1 + ref.abs())).max().item() <= 1e-4
 
 
+def test_predictive_unet_without_future_frames(tmp_path):
+    """future_frames = 0 (punet.py:91-96): the frozen U-Net's mask of the current frame; nothing trains, nothing is taped."""
+    g = torch.load(GOLDEN / "s1_stage1_b3_32_f3.pt", weights_only=False)
+    g = dict(g, meta=dict(g["meta"], future_frames=0), state_dict_keys=g["state_dict_keys"])
+    oracle, model, images, _ = _build(tmp_path, g, torch.float32)
+    oracle.eval()
+    model.eval()
+    with torch.no_grad():
+        ref = oracle(images)
+    out = model(images.to(DEV))           # grad mode on, but no path from a trainable parameter to the output
+    assert out.shape == ref.shape == (3, 23, 32, 32)
+    assert ((out.cpu() - ref).abs() / (1 + ref.abs())).max().item() <= 1e-4
+
+
 def test_stage1_training_step_bf16(tmp_path):
     """bf16 storage through 4 + F chained train-mode U-Nets on tiny feature maps is ill conditioned (tests/punet_parity.py);
     held to: finite results, loss within 3 %, aligned gradients overall."""
