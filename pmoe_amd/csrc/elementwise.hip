@@ -564,6 +564,24 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+// same, 64 pixels x Cp channels per workgroup through LDS: reads coalesced along the pixel axis of every channel plane,
+// writes one contiguous 64*Cp-element run of the NHWC tensor (the per-pixel scalar stores above are strided by Cp)
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_tiled_kernel(const float* __restrict__ src, T* __restrict__ dst, int B,
+                                                                int C, long long HW, int Cp) {
+    extern __shared__ float tile[];          // [64][Cp + 1]
+    const long long nblk = (HW + 63) / 64;
+    const int b = (int)(blockIdx.x / nblk);
+    const long long p0 = (blockIdx.x % nblk) * 64;
+    const int np = (int)((HW - p0) < 64 ? (HW - p0) : 64);
+    const int CS = Cp + 1, p = threadIdx.x & 63;
+    for (int c = threadIdx.x >> 6; c < Cp; c += 4)
+        if (p < np) tile[p * CS + c] = c < C ? src[((size_t)b * C + c) * HW + p0 + p] : 0.f;
+    __syncthreads();
+    T* d = dst + ((size_t)b * HW + p0) * Cp;
+    for (int i = threadIdx.x; i < np * Cp; i += 256) d[i] = from_f32<T>(tile[(i / Cp) * CS + (i % Cp)]);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) pad_rows_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int K,
                                                       int Kp) {
@@ -760,9 +778,15 @@ int pmoe_eca_bwd_apply(const void* dy, const float* gate, const float* dgap, voi
 
 int pmoe_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cp,
                       int32_t dtype, void* stream) {
+    if (B < 1 || C < 1 || H < 1 || W < 1 || Cp < C) return PMOE_ERR_ARG;
+    const long long HW = (long long)H * W, nblk = (HW + 63) / 64 * B;
     DISPATCH_DT(dtype, {
-        hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for((long long)B * H * W, 8192)), dim3(256), 0,
-                           (hipStream_t)stream, src, (T*)dst, B, C, H, W, Cp);
+        if (Cp <= 240 && nblk <= 0x7fffffffLL)
+            hipLaunchKernelGGL((nchw_to_nhwc_tiled_kernel<T>), dim3((unsigned)nblk), dim3(256), 64 * (Cp + 1) * sizeof(float),
+                               (hipStream_t)stream, src, (T*)dst, B, C, HW, Cp);
+        else
+            hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for((long long)B * H * W, 8192)), dim3(256), 0,
+                               (hipStream_t)stream, src, (T*)dst, B, C, H, W, Cp);
         return (int)hipGetLastError();
     });
 }

@@ -662,7 +662,10 @@ class ExpertGroupEngine:
         return y
 
     def _gap_parts(self, hw):
-        return min(16, max(1, hw // 1024))
+        # partial rows per image: >= 1024 pixels each, and enough workgroups (images x parts) to stream at HBM rate when
+        # the batch is small (stage-1 U-Net, B = 10: 16 parts left 160 workgroups on 256 CUs)
+        want = max(16, -(-2048 // max(1, self.N)))
+        return max(1, min(want, hw // 1024))
 
     def _eca(self, x, layer, shared, tape=True):
         """y[n] = x[n or n % B] * sigmoid(conv1d(GAP(x)))  (EfficientBlock, basics.py:69-76)."""

@@ -112,6 +112,13 @@ def test_unshuffle_add_window_and_nchw(dtype):
     want = a + b_
     ops.add_window(a, 0, b_, 0, 4096)
     assert torch.equal(b_, want)
+    # NCHW f32 -> NHWC (zero padded): tiled kernel with a ragged last block, and the wide-row fall-back
+    for (c, cp, h, w) in [(138, 144, 20, 13), (250, 256, 5, 9), (3, 16, 1, 1)]:
+        img = torch.randn(n, c, h, w, generator=g)
+        dst = torch.full((n, h, w, cp), 7.0, dtype=dtype, device=DEV)
+        ops.nchw_to_nhwc(img.to(DEV), dst)
+        assert torch.equal(dst[..., :c].float().cpu(), img.permute(0, 2, 3, 1).to(dtype).float())
+        assert dst[..., c:].abs().max().item() == 0
     # NHWC (padded) -> NCHW f32
     x = torch.randn(n, 7, 11, 144, generator=g).to(DEV, dtype)
     out = torch.empty(n, 138, 7, 11, dtype=torch.float32, device=DEV)
