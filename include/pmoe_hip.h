@@ -313,6 +313,12 @@ int pmoe_pixel_unshuffle2(const void* src, int32_t src_ld, int32_t src_coff, voi
 /* gradient of torch.cat along channels (punet.py:104,113): dst[r, dst_coff + c] += src[r, src_coff + c] */
 int pmoe_add_window(const void* src, int32_t src_ld, int32_t src_coff, void* dst, int32_t dst_ld, int32_t dst_coff,
                     int64_t rows, int32_t C, int32_t dtype, void* stream);
+/* torch.cat of K <= 8 equally wide channel windows in one launch (punet.py:104,113 four 23-class masks; moe.py:311-313
+ * view(B,-1,H,W) of the F predicted masks): dst[r, j] = srcs[j / c][r, src_coff + j % c] for j < K*c and 0 for
+ * K*c <= j < dst_c (dst_c a multiple of the 16-byte vector, <= dst_ld).  srcs is a HOST array of K device pointers,
+ * every source [rows][src_ld]. */
+int pmoe_cat_windows(const void* const* srcs, int32_t K, int32_t c, int32_t src_ld, int32_t src_coff, void* dst,
+                     int32_t dst_ld, int32_t dst_c, int64_t rows, int32_t dtype, void* stream);
 /* module boundary of PredictiveUnet.forward (punet.py:117-120 returns NCHW f32): src T [N][HW][src_ld] channel window
  * -> dst f32 [N][C][HW] */
 int pmoe_nhwc_to_nchw(const void* src, int32_t src_ld, int32_t src_coff, float* dst, int32_t N, int64_t HW, int32_t C,

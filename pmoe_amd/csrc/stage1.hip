@@ -109,6 +109,30 @@ __global__ void __launch_bounds__(256) add_window_kernel(const T* __restrict__ s
     }
 }
 
+// torch.cat of K equally wide channel windows (punet.py:104,113: four 23-class masks -> 92 channels; moe.py:311-313: F masks
+// -> F*23 channels) in ONE launch: thread = one 16-byte vector of the destination row, gathered element-wise from the K
+// sources (c is not a multiple of the vector width, so the per-source copies are 2-byte strided accesses), zero padding
+// included.  dst[r, j] = src[j / c][r, src_coff + j % c] for j < K*c, 0 for K*c <= j < dst_c.
+struct CatSrcs { const void* p[8]; };
+template <typename T>
+__global__ void __launch_bounds__(256) cat_windows_kernel(CatSrcs srcs, int K, int c, int src_ld, int src_coff,
+                                                         T* __restrict__ dst, int dst_ld, int dst_c, long long rows) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int CV = dst_c / VE;
+    const long long total = rows * CV;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        const long long r = i / CV;
+        float v[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const int j = cv * VE + e, k = j / c;
+            v[e] = k < K ? to_f32(reinterpret_cast<const T*>(srcs.p[k])[(size_t)r * src_ld + src_coff + (j - k * c)]) : 0.f;
+        }
+        stg16(dst + (size_t)r * dst_ld + cv * VE, pack16<T>(v));
+    }
+}
+
 // src T [N][HW][ld] channel window [coff, coff+C)  ->  dst f32 [N][C][HW]: 64 pixels x C channels per workgroup through LDS
 template <typename T>
 __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__ src, int ld, int coff,
@@ -406,6 +430,23 @@ int pmoe_add_window(const void* src, int32_t src_ld, int32_t src_coff, void* dst
         else
             hipLaunchKernelGGL((add_window_kernel<T, 1>), dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream,
                                (const T*)src, src_ld, src_coff, (T*)dst, dst_ld, dst_coff, (long long)rows, C);
+        return (int)hipGetLastError();
+    });
+}
+
+int pmoe_cat_windows(const void* const* srcs, int32_t K, int32_t c, int32_t src_ld, int32_t src_coff, void* dst,
+                     int32_t dst_ld, int32_t dst_c, int64_t rows, int32_t dtype, void* stream) {
+    if (!srcs || K < 1 || K > 8 || c < 1 || src_coff < 0 || src_coff + c > src_ld || rows < 0 || dst_c > dst_ld ||
+        (long long)K * c > dst_c)
+        return PMOE_ERR_ARG;
+    if (rows == 0) return 0;
+    CatSrcs cs;
+    for (int k = 0; k < 8; ++k) cs.p[k] = k < K ? srcs[k] : nullptr;       /* srcs is a HOST array of device pointers */
+    DISPATCH_DT(dtype, {
+        constexpr int VE = 16 / (int)sizeof(T);
+        if (dst_c % VE || dst_ld % VE) return PMOE_ERR_ARG;
+        hipLaunchKernelGGL((cat_windows_kernel<T>), dim3(grid_for(rows * (dst_c / VE))), dim3(256), 0, (hipStream_t)stream, cs,
+                           K, c, src_ld, src_coff, (T*)dst, dst_ld, dst_c, (long long)rows);
         return (int)hipGetLastError();
     });
 }

@@ -257,6 +257,15 @@ class PUNetEngine(ExpertGroupEngine):
         z = self._conv(a, eb["conv2"], bias=False)       # 3 real channels: centred colstats pass (no fused epilogue stats)
         return self._bn(z, eb["bn2"], relu=True)
 
+    def _cat_masks(self, srcs, dst, nc):
+        """torch.cat of class masks along channels (zero padded to the 16-wide row): one gather launch for up to 8 masks."""
+        if len(srcs) <= 8:
+            ops.cat_windows(srcs, dst, nc)
+            return
+        dst.zero_()
+        for k, t in enumerate(srcs):
+            ops.copy_window(t, 0, dst, k * nc, nc)
+
     def _punet_fwd(self, images):
         """punet.py:75-120: T past frames through ``unet``, then F autoregressive steps of
         cat(4 masks) -> entry_block -> pred_unet.  Returns x0 [B,H,W,r16(F*classes)] or the bottleneck feature."""
@@ -278,17 +287,13 @@ class PUNetEngine(ExpertGroupEngine):
         if F_ == 0:                                    # punet.py:91-96: segmentation of the current frame
             self._pred_masks = None
             return masks[-1], None
-        x0 = None
-        if not self.return_inter:
-            x0 = Var(torch.zeros(Bsz, H, W, r16(F_ * nc), dtype=self.dtype, device=self.dev))
         inter = None
         for f in range(F_):
             if self.taping:
                 self._step_begin(f)
-            cat = Var(torch.zeros(Bsz, H, W, r16(T * nc), dtype=self.dtype, device=self.dev))
+            cat = Var(self._new(Bsz, H, W, r16(T * nc)))
             srcs = masks[-T:]
-            for k, m in enumerate(srcs):
-                ops.copy_window(m.t, 0, cat.t, k * nc, nc)
+            self._cat_masks([m.t for m in srcs], cat.t, nc)
             cat.needs_grad = any(m.needs_grad for m in srcs)
             if self.taping and cat.needs_grad:
                 # gradient of torch.cat (punet.py:104,113): each window is ADDED to its mask's gradient (a predicted mask
@@ -303,8 +308,10 @@ class PUNetEngine(ExpertGroupEngine):
             e = self._entry_fwd(cat)
             m, inter = self._unet_fwd(self.pred_unet, e)
             masks.append(m)
-            if x0 is not None:
-                ops.copy_window(m.t, 0, x0.t, f * nc, nc)         # torch.stack(outs,1).view(B,-1,H,W)  (punet.py:120, moe.py:311)
+        x0 = None
+        if not self.return_inter:                  # torch.stack(outs,1).view(B,-1,H,W)  (punet.py:120, moe.py:311)
+            x0 = Var(self._new(Bsz, H, W, r16(F_ * nc)))
+            self._cat_masks([m.t for m in masks[T:]], x0.t, nc)
         self._pred_masks = masks[T:] if self.taping else None
         return x0, inter
 

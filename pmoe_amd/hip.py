@@ -106,6 +106,7 @@ SIGNATURES = {
     "pmoe_maxpool2s2_bwd": [_P, _I, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P],
     "pmoe_pixel_unshuffle2": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_add_window": [_P, _I, _I, _P, _I, _I, _L, _I, _I, _P],
+    "pmoe_cat_windows": [C.POINTER(C.c_void_p), _I, _I, _I, _I, _P, _I, _I, _L, _I, _P],
     "pmoe_nhwc_to_nchw": [_P, _I, _I, _P, _I, _L, _I, _I, _P],
     "pmoe_seg_loss_rows": [_I, _I, _I],
     "pmoe_seg_loss_cp": [_I],

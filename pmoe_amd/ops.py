@@ -427,6 +427,24 @@ def add_window(src, src_coff, dst, dst_coff, c):
                                  dst_coff, rows, c, dt(src), stream_ptr()), "pmoe_add_window")
 
 
+def cat_windows(srcs, dst, c, src_coff=0, dst_c=None):
+    """dst[..., k*c:(k+1)*c] = srcs[k][..., src_coff:src_coff+c] for all k (len(srcs) <= 8), zeros up to ``dst_c``
+    (default: the whole row of ``dst``) -- torch.cat along channels in one launch."""
+    k = len(srcs)
+    if not 1 <= k <= 8:
+        raise ValueError("cat_windows: 1..8 sources")
+    s0 = srcs[0]
+    rows = s0.numel() // s0.shape[-1]
+    for t in srcs:
+        if t.shape != s0.shape or t.dtype != dst.dtype:
+            raise ValueError("cat_windows: sources must share shape and the destination's dtype")
+    if dst.numel() // dst.shape[-1] != rows:
+        raise ValueError("cat_windows: row counts differ")
+    arr = (C.c_void_p * k)(*[ptr(t, "src").value for t in srcs])
+    check(load().pmoe_cat_windows(arr, k, c, s0.shape[-1], src_coff, ptr(dst, "dst"), dst.shape[-1],
+                                  dst.shape[-1] if dst_c is None else dst_c, rows, dt(dst), stream_ptr()), "pmoe_cat_windows")
+
+
 def nhwc_to_nchw(src, dst, c, src_coff=0):
     """src [N,H,W,ld] (bf16/f32) channel window -> dst f32 [N,c,H,W]."""
     n, h, w_, ld = _nhwc(src, "src")
@@ -514,5 +532,5 @@ def blend_bwd(moe_act, pu_act, lat_w, long_w, out, dout, dlat_w, dlat_b, dlong_w
 
 for _n in ("maxpool2_fwd", "pixel_shuffle2", "copy_window", "action_head_fwd", "action_head_bwd", "action_loss",
            "blend_fwd", "blend_bwd", "maxpool2_bwd", "pixel_unshuffle2", "add_window", "nhwc_to_nchw", "seg_loss_fwd",
-           "seg_loss_bwd"):
+           "seg_loss_bwd", "cat_windows"):
     globals()[_n] = _timed(globals()[_n])

@@ -112,6 +112,15 @@ def test_unshuffle_add_window_and_nchw(dtype):
     want = a + b_
     ops.add_window(a, 0, b_, 0, 4096)
     assert torch.equal(b_, want)
+    # torch.cat of K class masks in one launch (zero padded row)
+    ms = [torch.randn(n, h, w, 32, generator=g).to(DEV, dtype) for _ in range(6)]
+    for K, width in ((4, 96), (6, 144), (1, 32)):
+        cat = torch.full((n, h, w, width), 3.0, dtype=dtype, device=DEV)
+        ops.cat_windows(ms[:K], cat, 23)
+        want = torch.zeros(n, h, w, width, dtype=dtype, device=DEV)
+        for k in range(K):
+            want[..., k * 23:(k + 1) * 23] = ms[k][..., :23]
+        assert torch.equal(cat, want)
     # NCHW f32 -> NHWC (zero padded): tiled kernel with a ragged last block, and the wide-row fall-back
     for (c, cp, h, w) in [(138, 144, 20, 13), (250, 256, 5, 9), (3, 16, 1, 1)]:
         img = torch.randn(n, c, h, w, generator=g)
