@@ -382,6 +382,12 @@ int pmoe_resample_u8_horizontal(const uint8_t* src, uint8_t* dst, int32_t n_img,
 int pmoe_resample_u8_vertical_to_f32(const uint8_t* src, float* dst_nchw, int32_t n_img, int32_t Hin, int32_t W,
                                      int32_t C, int32_t Hout, const int32_t* bounds, const int32_t* coeffs,
                                      int32_t ksize, void* stream);
+/* stage-1 label pipeline (data_loader.py:282-286,305-309: Crop -> Resize -> MaskPILToTensor on a single-channel class-id
+ * image): the same vertical pass writing the 8-bit result as int64 [n][C][Hout][W].  (The reference resizes its label
+ * images with BILINEAR like the frames -- class ids are blended at region borders; reproduced as is.) */
+int pmoe_resample_u8_vertical_to_i64(const uint8_t* src, int64_t* dst_nchw, int32_t n_img, int32_t Hin, int32_t W,
+                                     int32_t C, int32_t Hout, const int32_t* bounds, const int32_t* coeffs,
+                                     int32_t ksize, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,19 @@ CASES = [  # name, H0, W0, crop(top, bottom), size(h, w), seed
 ]
 
 
+MASK_CASES = [  # name, H0, W0, crop, size, seed   (stage-1 label images: data_loader.py:282-286, conf/stage_1.yaml:41-46)
+    ("mask_600x800_to_224", 600, 800, (125, 90), (224, 224), 21),
+    ("mask_odd_301x203_to_97x65", 301, 203, (7, 3), (97, 65), 22),
+]
+
+
+def mask(H0, W0, seed, classes=23, block=9):
+    """single-channel class-id image, piecewise constant (what cv2.imread(..., IMREAD_UNCHANGED) returns for a label PNG)"""
+    rng = np.random.default_rng(seed)
+    coarse = rng.integers(0, classes, ((H0 + block - 1) // block, (W0 + block - 1) // block), dtype=np.uint8)
+    return np.ascontiguousarray(np.repeat(np.repeat(coarse, block, 0), block, 1)[:H0, :W0])
+
+
 def frame(H0, W0, seed):
     return np.random.default_rng(seed).integers(0, 256, (H0, W0, 3), dtype=np.uint8)
 
@@ -32,6 +45,12 @@ def main():
         img = Image.fromarray(fr[crop[0]:-crop[1]])
         res = np.asarray(img.resize((size[1], size[0]), Image.BILINEAR))
         out[name] = res
+        out[name + "__meta"] = np.array([H0, W0, crop[0], crop[1], size[0], size[1], seed])
+    for name, H0, W0, crop, size, seed in MASK_CASES:
+        # Crop (augmenter.py:43-49: Image.fromarray of the row slice -> mode 'L') -> Resize -> MaskPILToTensor (np.array)
+        img = Image.fromarray(mask(H0, W0, seed)[crop[0]:-crop[1]])
+        assert img.mode == "L"
+        out[name] = np.asarray(img.resize((size[1], size[0]), Image.BILINEAR))
         out[name + "__meta"] = np.array([H0, W0, crop[0], crop[1], size[0], size[1], seed])
     np.savez_compressed(REPO / "tests" / "golden" / "prep.npz", **out)
     print("wrote tests/golden/prep.npz", {k: v.shape for k, v in out.items() if not k.endswith("__meta")})

@@ -79,3 +79,18 @@ def preprocess_frame(frame, crop, size):
         _, b, k = precompute_coeffs(img.shape[0], h)
         img = resample_axis(img, b, k, axis=0)
     return np.ascontiguousarray(img.transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0)
+
+
+def preprocess_mask(mask, crop, size):
+    """single-channel class-id image uint8 [H0, W0] -> int64 [h, w]: Crop -> Resize (BILINEAR on a mode-'L' PIL image, as
+    the reference's ``transform_mask`` does, data_loader.py:282-286) -> MaskPILToTensor (augmenter.py:52-54)."""
+    top, bottom = crop
+    img = mask[top:mask.shape[0] - bottom][:, :, None]
+    h, w = size
+    if img.shape[1] != w:
+        _, b, k = precompute_coeffs(img.shape[1], w)
+        img = resample_axis(img, b, k, axis=1)
+    if img.shape[0] != h:
+        _, b, k = precompute_coeffs(img.shape[0], h)
+        img = resample_axis(img, b, k, axis=0)
+    return np.ascontiguousarray(img[:, :, 0]).astype(np.int64)

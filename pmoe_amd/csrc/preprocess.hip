@@ -35,8 +35,14 @@ __global__ void __launch_bounds__(256) resample_h_kernel(const uint8_t* __restri
     }
 }
 
-// src [n][Hin][W][C] uint8 -> dst [n][C][Hout][W] f32 = value / 255  (ToTensor: CHW, [0,1])
-__global__ void __launch_bounds__(256) resample_v_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int n_img,
+// src [n][Hin][W][C] uint8 -> dst [n][C][Hout][W]: f32 = value / 255 (ToTensor: CHW, [0,1]) or int64 = value
+// (MaskPILToTensor, model/augmenter.py:52-54: segmentation labels of stage-1 training)
+template <typename OUT> __device__ __forceinline__ OUT px_out(uint8_t v);
+template <> __device__ __forceinline__ float px_out<float>(uint8_t v) { return (float)v / 255.0f; }
+template <> __device__ __forceinline__ long long px_out<long long>(uint8_t v) { return (long long)v; }
+
+template <typename OUT>
+__global__ void __launch_bounds__(256) resample_v_kernel(const uint8_t* __restrict__ src, OUT* __restrict__ dst, int n_img,
                                                         int Hin, int W, int C, int Hout, const int32_t* __restrict__ bounds,
                                                         const int32_t* __restrict__ kk, int ksize) {
     const long long total = (long long)n_img * Hout * W;
@@ -51,7 +57,7 @@ __global__ void __launch_bounds__(256) resample_v_kernel(const uint8_t* __restri
         for (int c = 0; c < C; ++c) {
             int ss = 1 << (PREC - 1);
             for (int y = 0; y < cnt; ++y) ss += (int)p[(size_t)y * W * C + c] * k[y];
-            dst[(((size_t)n * C + c) * Hout + yy) * W + xx] = (float)clip8(ss) / 255.0f;
+            dst[(((size_t)n * C + c) * Hout + yy) * W + xx] = px_out<OUT>(clip8(ss));
         }
     }
 }
@@ -79,8 +85,18 @@ int pmoe_resample_u8_vertical_to_f32(const uint8_t* src, float* dst_nchw, int32_
                                      void* stream) {
     if (!src || !dst_nchw || !bounds || !coeffs || n_img < 1 || Hin < 1 || W < 1 || C < 1 || Hout < 1 || ksize < 1)
         return PMOE_ERR_ARG;
-    hipLaunchKernelGGL(resample_v_kernel, dim3(grid_for((long long)n_img * Hout * W)), dim3(256), 0, (hipStream_t)stream, src,
-                       dst_nchw, n_img, Hin, W, C, Hout, bounds, coeffs, ksize);
+    hipLaunchKernelGGL(resample_v_kernel<float>, dim3(grid_for((long long)n_img * Hout * W)), dim3(256), 0,
+                       (hipStream_t)stream, src, dst_nchw, n_img, Hin, W, C, Hout, bounds, coeffs, ksize);
+    return (int)hipGetLastError();
+}
+
+int pmoe_resample_u8_vertical_to_i64(const uint8_t* src, int64_t* dst_nchw, int32_t n_img, int32_t Hin, int32_t W, int32_t C,
+                                     int32_t Hout, const int32_t* bounds, const int32_t* coeffs, int32_t ksize,
+                                     void* stream) {
+    if (!src || !dst_nchw || !bounds || !coeffs || n_img < 1 || Hin < 1 || W < 1 || C < 1 || Hout < 1 || ksize < 1)
+        return PMOE_ERR_ARG;
+    hipLaunchKernelGGL(resample_v_kernel<long long>, dim3(grid_for((long long)n_img * Hout * W)), dim3(256), 0,
+                       (hipStream_t)stream, src, (long long*)dst_nchw, n_img, Hin, W, C, Hout, bounds, coeffs, ksize);
     return (int)hipGetLastError();
 }
 

@@ -114,6 +114,7 @@ SIGNATURES = {
     "pmoe_seg_loss_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_resample_u8_horizontal": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "pmoe_resample_u8_vertical_to_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "pmoe_resample_u8_vertical_to_i64": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "pmoe_mt_grad_norm": [_P, _P, _P, _I, _F, _P, _P, _I, _P],
     "pmoe_mt_adam": [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P],
     "pmoe_mt_swa_update": [_P, _P, _P, _I, _L, _P],

@@ -67,6 +67,22 @@ class FramePreprocessor:
             raise RuntimeError("FramePreprocessor: frames must be on the MI355X (cuda) device; pmoe_amd has no CPU path")
         if frames.dim() < 3:
             raise ValueError("FramePreprocessor: expected [..., H0, W0, C]")
+        return self._run(frames, labels=False)
+
+    def labels(self, masks):
+        """Label pipeline of stage-1 training (``data_loader.py:282-286,305-309``: ``Crop`` -> ``Resize`` ->
+        ``MaskPILToTensor``): ``masks`` uint8 class-id images ``[..., H0, W0]`` on the device -> int64 ``[..., h, w]``.
+        Like the reference, the resize is BILINEAR (a mode-'L' PIL image): ids are blended at region borders."""
+        if not isinstance(masks, torch.Tensor) or masks.dtype != torch.uint8:
+            raise TypeError("FramePreprocessor.labels: expected a uint8 tensor [..., H0, W0]")
+        if not masks.is_cuda:
+            raise RuntimeError("FramePreprocessor: masks must be on the MI355X (cuda) device; pmoe_amd has no CPU path")
+        if masks.dim() < 2:
+            raise ValueError("FramePreprocessor.labels: expected [..., H0, W0]")
+        out = self._run(masks.unsqueeze(-1), labels=True)
+        return out.squeeze(-3)
+
+    def _run(self, frames, labels):
         lead = frames.shape[:-3]
         H0, W0, Cc = frames.shape[-3:]
         rows = H0 - self.top - self.bottom
@@ -79,10 +95,10 @@ class FramePreprocessor:
         kh, bh, ch = self._table(W0, w, dev)
         kv, bv, cv = self._table(rows, h, dev)
         tmp = torch.empty(n, rows, w, Cc, dtype=torch.uint8, device=dev)
-        out = torch.empty(n, Cc, h, w, dtype=torch.float32, device=dev)
+        out = torch.empty(n, Cc, h, w, dtype=torch.int64 if labels else torch.float32, device=dev)
         p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
         check(load().pmoe_resample_u8_horizontal(p(src), p(tmp), n, H0, W0, self.top, rows, Cc, w, p(bh), p(ch), kh,
                                                  stream_ptr()), "pmoe_resample_u8_horizontal")
-        check(load().pmoe_resample_u8_vertical_to_f32(p(tmp), p(out), n, rows, w, Cc, h, p(bv), p(cv), kv, stream_ptr()),
-              "pmoe_resample_u8_vertical_to_f32")
+        vert = load().pmoe_resample_u8_vertical_to_i64 if labels else load().pmoe_resample_u8_vertical_to_f32
+        check(vert(p(tmp), p(out), n, rows, w, Cc, h, p(bv), p(cv), kv, stream_ptr()), "pmoe_resample_u8_vertical")
         return out.view(*lead, Cc, h, w)

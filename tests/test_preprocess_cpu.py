@@ -3,8 +3,8 @@
 import numpy as np
 import pytest
 
-from oracle.make_prep_golden import CASES, frame
-from oracle.preprocess_oracle import precompute_coeffs, preprocess_frame
+from oracle.make_prep_golden import CASES, MASK_CASES, frame, mask
+from oracle.preprocess_oracle import precompute_coeffs, preprocess_frame, preprocess_mask
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -16,6 +16,15 @@ def test_oracle_matches_pillow_fixture(golden_dir, case):
     want = g[name].transpose(2, 0, 1).astype(np.float32) / np.float32(255.0)      # ToTensor
     assert got.dtype == np.float32 and got.shape == (3,) + tuple(size)
     assert np.array_equal(got, want)                                              # bit exact
+
+
+@pytest.mark.parametrize("case", MASK_CASES, ids=[c[0] for c in MASK_CASES])
+def test_oracle_matches_pillow_mask_fixture(golden_dir, case):
+    """stage-1 label images (data_loader.py:282-286): Crop -> Resize -> MaskPILToTensor."""
+    name, H0, W0, crop, size, seed = case
+    g = np.load(golden_dir / "prep.npz")
+    got = preprocess_mask(mask(H0, W0, seed), crop, size)
+    assert got.dtype == np.int64 and np.array_equal(got, g[name].astype(np.int64))
 
 
 def test_coefficients_are_normalised_fixed_point():
