@@ -265,6 +265,8 @@ def main():
         def symbol(code):
             four = code >= 4000
             code %= 4000
+            if code == 3000:
+                return "gemm_skinny_kernel", "gemm_skinny_kernel", 1
             if code >= 2000:
                 return (f"conv_igemm_lite_kernel<{args.dtype},{code - 2000}>" + (" (4 parity-class launches per stride-2 dgrad)" if four else ""),
                         f"_Z22conv_igemm_lite_kernelI{tname}Li{code - 2000}EEv8ConvArgs", 4 if four else 1)

@@ -515,6 +515,7 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
     if (a.dilate && a.ks == 1 && a.pad == 0 && a.res_mode == PMOE_RES_ADD && a.res == a.out && a.res_ld == a.out_ld &&
         a.res_coff == a.out_coff && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f)
         return launch_stride2_1x1_inplace(a, dtype, st);
+    if (gemm_skinny_ok(a, dtype)) return gemm_skinny_launch(a, st);
     ResPlan plan;
     if (conv_res_plan(a, dtype, &plan)) return conv_res_launch(a, plan, st);
     if (dtype == PMOE_DT_BF16) return launch_dtype<bf16>(a, st, nullptr);
@@ -522,12 +523,13 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
     return PMOE_ERR_ARG;
 }
 
-// which kernel a descriptor runs on (no launch): 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; 2000 + LOG_RB =
+// which kernel a descriptor runs on (no launch): 3000 = gemm_skinny_kernel; 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; 2000 + LOG_RB =
 // conv_igemm_lite_kernel<T, LOG_RB>; LOG_RB*100 + WM*10 + WN = conv_igemm_kernel<T, LOG_RB, WM, WN>; + 4000 = the four
 // parity-class launches of a stride-2 data gradient
 int conv_igemm_plan(const ConvArgs& a, int dtype) {
     ConvArgs c = a;
     int extra = 0;
+    if (gemm_skinny_ok(a, dtype)) return 3000;           // gemm_skinny_kernel
     if (a.dilate && a.ks == 3 && a.pad == 1 && a.kh == 3) {
         c.dilate = 0; c.stride = 1; c.pad = 0; c.kh = c.kw = 2;
         c.Ho = a.Ho / 2; c.Wo = a.Wo / 2; c.OH = a.Ho; c.OW = a.Wo; c.out_step = 2;

@@ -1,0 +1,161 @@
+// Grouped "skinny" GEMM for the expert MLPs (make_mlp, blocks/basics.py:10-44; heads moe.py:70-72): per expert
+//   Y[m][n] = epilogue( sum_k X[m][k] * W[n][k] ),   m < images-per-expert (the batch, 64), n = 16..1536, k = 16..1536
+// i.e. the 1x1 "convolutions" over 1x1 images of the grouped engine.  On the generic implicit-GEMM kernel these are a
+// serial chain of 8..24 channel chunks on 16 workgroups (~90 us per launch: 2 TFLOP/s).  Here one workgroup owns a
+// 64-row x 64-column tile of ONE expert and its 4 waves split K between them: every wave streams its k-slices of both
+// operands straight from global memory in MFMA-fragment shape (16 bytes per lane, K-contiguous rows of the packed
+// weights / of the activation rows), with no LDS staging and no barrier in the loop -- all loads of a wave are
+// independent -- and the four partial tiles meet once in LDS for the epilogue (bias / act' / activation / dropout /
+// residual, the same arithmetic as conv_igemm.hip's epilogue).  bf16 operands, f32 accumulation.
+#include <stdlib.h>
+#include "common.h"
+#include "kernels.h"
+
+static constexpr int BM = 64, BN = 64, NW = 4, VE = 8;
+
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* stg = reinterpret_cast<float*>(smem);            // [NW][BM][BN] f32, 16-byte units XOR-swizzled by row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int e = blockIdx.z, m0 = blockIdx.y * BM, cout0 = blockIdx.x * BN;
+    const bf16* W = (const bf16*)a.w + ((size_t)e * a.CoutP + cout0) * a.Cin;
+    const bf16* X = (const bf16*)a.in;
+
+    const bf16* pa[2];
+    const bf16* pb[2];
+    bool bok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        pa[t] = W + (size_t)(t * 32 + l31) * a.Cin + h * 8;
+        const int m = m0 + t * 32 + l31;
+        bok[t] = m < a.ipe;
+        const int n = (a.in_shared ? 0 : e * a.ipe) + (bok[t] ? m : 0);
+        pb[t] = X + (size_t)n * a.in_ld + a.in_coff + h * 8;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    const v4i zero = {0, 0, 0, 0};
+    // wave w takes the 16-wide k-slices w, w+4, w+8, ...
+#pragma unroll 4
+    for (int k = wave * 16; k < a.Cin; k += NW * 16) {
+        v4i af[2], bfr[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            af[t] = ldg16(pa[t] + k);
+            bfr[t] = bok[t] ? ldg16(pb[t] + k) : zero;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[nt]),
+                                                                      __builtin_bit_cast(bf16x8, bfr[mt]), acc[nt][mt], 0, 0, 0);
+    }
+    // ---- partial tiles -> LDS: D[cout][m], row m of wave w at stg[w][m][.]
+    constexpr int UPR = BN / 4;
+    float* mine = stg + wave * (BM * BN);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int p = mt * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u = nt * 8 + 2 * g + h;
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[nt][mt][4 * g + i];
+                *reinterpret_cast<f32x4*>(mine + p * BN + ((u ^ (p & (UPR - 1))) << 2)) = v;
+            }
+        }
+    __syncthreads();
+    // ---- epilogue (conv_igemm.hip's, on 1x1 images: output pixel index = image index)
+    constexpr int CPO = BN / VE, PROWS = 256 / CPO;
+    const int cc = tid % CPO, pr = tid / CPO;
+    const int cout = cout0 + cc * VE;
+    const bool cvalid = cout < a.Cout;
+    float bias[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) bias[i] = (a.bias && cvalid) ? a.bias[(size_t)e * a.CoutP + cout + i] : 0.f;
+    const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    bf16* out = (bf16*)a.out;
+    const bf16* res = (const bf16*)a.res;
+    for (int p = pr; p < BM; p += PROWS) {
+        const int m = m0 + p;
+        if (!cvalid || m >= a.ipe) continue;
+        float v[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) v[i] = bias[i];
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int k = 0; k < VE / 4; ++k) {
+                const int u = cc * (VE / 4) + k;
+                const f32x4 tt = *reinterpret_cast<const f32x4*>(stg + w * (BM * BN) + p * BN + ((u ^ (p & (UPR - 1))) << 2));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * k + i] += tt[i];
+            }
+        const size_t opix = (size_t)e * a.ipe + m;
+        if (a.res_mode) {
+            float rv[VE];
+            unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cout), rv);
+            if (a.res_mode == PMOE_RES_ADD) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] += rv[i];
+            } else if (a.res_mode == PMOE_RES_DRELU) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] = rv[i] > 0.f ? v[i] * keep_scale : 0.f;
+            } else if (a.res_mode == PMOE_RES_DELU) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    const float y = rv[i] * (1.f / keep_scale);
+                    const float d = y > 0.f ? 1.f : y + 1.f;
+                    v[i] = (a.drop_p > 0.f && rv[i] == 0.f) ? 0.f : v[i] * d * keep_scale;
+                }
+            }
+        }
+        if (a.act == PMOE_ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) v[i] = fmaxf(v[i], 0.f);
+        } else if (a.act == PMOE_ACT_ELU) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) v[i] = v[i] > 0.f ? v[i] : expm1f(v[i]);
+        }
+        if (a.drop_p > 0.f && a.res_mode < PMOE_RES_DRELU) {
+            const unsigned long long base = (unsigned long long)opix * (unsigned)a.Cout + cout;
+#pragma unroll
+            for (int i = 0; i < VE; ++i) v[i] = hash_uniform(a.seed, base + i) >= a.drop_p ? v[i] * keep_scale : 0.f;
+        }
+        stg16(out + opix * a.out_ld + a.out_coff + cout, pack16<bf16>(v));
+    }
+}
+
+// 1x1 images, 1x1 filter, bf16, no fused statistics, dense output lattice: the expert MLP layers and their data gradients
+bool gemm_skinny_ok(const ConvArgs& a, int dtype) {
+    static int on = -1;          // PMOE_GEMM_SKINNY=0: back to the generic implicit-GEMM kernel (A/B measurements)
+    if (on < 0) { const char* ev = getenv("PMOE_GEMM_SKINNY"); on = ev ? atoi(ev) : 1; }
+    return on && dtype == PMOE_DT_BF16 && a.H == 1 && a.W == 1 && a.Ho == 1 && a.Wo == 1 && a.ks == 1 && a.kh == 1 && a.kw == 1 &&
+           a.stride == 1 && a.pad == 0 && !a.dilate && !a.use_tapmap && a.out_step == 1 && !a.stats && a.Cin > 0 &&
+           a.Cin % 16 == 0 && a.CoutP % BN == 0 && a.Cout % VE == 0 && a.ipe > 0 && a.N % a.ipe == 0 && a.in_ld % VE == 0 &&
+           a.in_coff % VE == 0 && a.out_ld % VE == 0 && a.out_coff % VE == 0 &&
+           (!a.res_mode || (a.res && a.res_ld % VE == 0 && a.res_coff % VE == 0));
+}
+
+int gemm_skinny_launch(const ConvArgs& a, hipStream_t st) {
+    const dim3 grid(a.CoutP / BN, (a.ipe + BM - 1) / BM, a.N / a.ipe);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_RET(hipFuncSetAttribute((const void*)gemm_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(NW * BM * BN * sizeof(float))));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_skinny_kernel, grid, dim3(256), NW * BM * BN * sizeof(float), st, a);
+    return (int)hipGetLastError();
+}

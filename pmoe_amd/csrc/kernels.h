@@ -44,6 +44,10 @@ struct WgradArgs {
     int lTW, lTH, TN, n_groups, tiles_y, tiles_x, mb_per_wg;
 };
 
+// grouped skinny GEMM for the expert MLP layers (gemm_skinny.hip)
+bool gemm_skinny_ok(const ConvArgs& a, int dtype);
+int gemm_skinny_launch(const ConvArgs& a, hipStream_t st);
+
 struct ResPlan;
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st);
 int conv_igemm_mblocks(const ConvArgs& a, int dtype);

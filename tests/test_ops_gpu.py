@@ -184,6 +184,63 @@ def test_conv_shared_input_and_epilogues(dtype):
     close(out3.view(E * ipe, Nn), lin * torch.where(y_saved > 0, torch.ones_like(y_saved), y_saved + 1), dtype, "delu")
 
 
+@pytest.mark.parametrize("case", [(4, 64, 512, 512), (4, 64, 1536, 512), (2, 37, 512, 5), (3, 70, 512, 1536), (1, 130, 48, 64)])
+def test_expert_mlp_gemm_shapes_bf16(case):
+    """The grouped skinny GEMM (csrc/gemm_skinny.hip) that serves the expert MLP layers in bf16: batch rows per expert that
+    are not a multiple of its 64-row tile, K split over the 4 waves (48 .. 1536), 5-row head, bias + ELU + dropout, and the
+    activation-derivative epilogue of the data gradient reading the saved (dropped) output."""
+    E, ipe, K, Nn = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(K + Nn)
+    x = rnd((E * ipe, K), g, dtype)
+    ws = [rnd((Nn, K, 1, 1), g, dtype, K ** -0.5) for _ in range(E)]
+    bs = [rnd((Nn,), g, torch.float32, 0.3) for _ in range(E)]
+    wf, wd, _ = pack(ws, 1, dtype, want_dgrad=True)
+    bias = torch.empty(E, r64(Nn), device=DEV)
+    ops.pack_bias(hip.ptr_table([b.to(DEV) for b in bs], DEV), bias, E, Nn, r64(Nn))
+    xd = x.to(dtype).to(DEV).view(E * ipe, 1, 1, K).contiguous()
+    cst = r16(Nn)
+    lin = torch.cat([x[e * ipe:(e + 1) * ipe] @ ws[e][:, :, 0, 0].t() + bs[e] for e in range(E)])
+    out = torch.full((E * ipe, 1, 1, cst), 9.0, dtype=dtype, device=DEV)
+    ops.conv2d(xd, wf, out, cin=K, cout=cst, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, bias=bias, act=hip.ACT_ELU)
+    close(out.view(E * ipe, cst)[:, :Nn], F.elu(lin), dtype, "mlp elu")
+    if cst > Nn:
+        assert out.view(E * ipe, cst)[:, Nn:].abs().max().item() == 0           # padded columns of the head stay zero
+    # dropout: same seed -> same mask, survivors scaled by 1/(1-p)
+    a = torch.empty_like(out)
+    b = torch.empty_like(out)
+    ops.conv2d(xd, wf, a, cin=K, cout=cst, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, bias=bias, act=hip.ACT_ELU,
+               drop_p=0.3, seed=77)
+    ops.conv2d(xd, wf, b, cin=K, cout=cst, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, bias=bias, act=hip.ACT_ELU,
+               drop_p=0.3, seed=77)
+    assert torch.equal(a, b)
+    av, ov = a.view(E * ipe, cst)[:, :Nn].float(), out.view(E * ipe, cst)[:, :Nn].float()
+    kept = av != 0
+    if Nn >= 64:
+        assert abs(kept.float().mean().item() - 0.7) < 0.03
+    torch.testing.assert_close(av[kept], (ov / 0.7)[kept], rtol=1e-2, atol=1e-2)
+    # data gradient through the dropped ELU layer: dx = (dy * elu'(z) * mask / (1-p)) @ W
+    dy = rnd((E * ipe, Nn), g, dtype)
+    dyd = torch.zeros(E * ipe, 1, 1, cst, dtype=dtype, device=DEV)
+    dyd.view(E * ipe, cst)[:, :Nn] = dy.to(dtype).to(DEV)
+    dx = torch.empty(E * ipe, 1, 1, r16(K), dtype=dtype, device=DEV)
+    ops.conv2d(dyd, wd, dx, cin=cst, cout=r16(K), coutp=r64(K), ipe=ipe, ks=1, stride=1, pad=0)
+    ref_dx = torch.cat([dy[e * ipe:(e + 1) * ipe] @ ws[e][:, :, 0, 0] for e in range(E)])
+    close(dx.view(E * ipe, -1)[:, :K], ref_dx, dtype, "mlp dgrad")
+    if K % 16 == 0 and Nn >= 16:
+        # ... with the activation derivative of the PREVIOUS layer's saved output in the epilogue (RES_DELU, dropout 0.3)
+        ysaved = torch.empty(E * ipe, 1, 1, r16(K), dtype=dtype, device=DEV)
+        yprev = rnd((E * ipe, K), g, dtype)
+        mask = torch.rand(E * ipe, K, generator=g) >= 0.3
+        ys = (torch.where(yprev > 0, yprev, torch.expm1(yprev)) * mask / 0.7).to(dtype).float()
+        ysaved.view(E * ipe, -1)[:, :K] = ys.to(dtype).to(DEV)
+        ops.conv2d(dyd, wd, dx, cin=cst, cout=r16(K), coutp=r64(K), ipe=ipe, ks=1, stride=1, pad=0, res=ysaved,
+                   res_mode=hip.RES_DELU, drop_p=0.3)
+        yy = ys * 0.7
+        want = torch.where(ys == 0, torch.zeros_like(ref_dx), ref_dx * torch.where(yy > 0, torch.ones_like(yy), yy + 1) / 0.7)
+        close(dx.view(E * ipe, -1)[:, :K], want, dtype, "mlp dgrad + delu'")
+
+
 def test_dropout_epilogue_statistics():
     g = torch.Generator().manual_seed(5)
     E, ipe, K, Nn = 1, 64, 16, 512
