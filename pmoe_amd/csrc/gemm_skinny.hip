@@ -1,6 +1,9 @@
 // Grouped "skinny" GEMM for the expert MLPs (make_mlp, blocks/basics.py:10-44; heads moe.py:70-72): per expert
 //   Y[m][n] = epilogue( sum_k X[m][k] * W[n][k] ),   m < images-per-expert (the batch, 64), n = 16..1536, k = 16..1536
-// i.e. the 1x1 "convolutions" over 1x1 images of the grouped engine.  On the generic implicit-GEMM kernel these are a
+// i.e. the 1x1 "convolutions" over 1x1 images of the grouped engine -- and, with a loop over the filter taps (row m = output
+// pixel, its operand row = the tap-shifted input pixel, zero outside the image), the 3x3 / 1x1 convolutions of feature maps
+// with at most PMOE_SKINNY_MAXROWS (default 2048) pixels per expert (closed-loop inference at B = 1: layer3 / layer4; the 14x14
+// bottleneck of the stage-1 U-Net at B = 10; beyond that the LDS-staged kernels win: measured).  On the generic implicit-GEMM kernel these are a
 // serial chain of 8..24 channel chunks on 16 workgroups (~90 us per launch: 2 TFLOP/s).  Here one workgroup owns a
 // 64-row x 64-column tile of ONE expert and its 4 waves split K between them: every wave streams its k-slices of both
 // operands straight from global memory in MFMA-fragment shape (16 bytes per lane, K-contiguous rows of the packed
@@ -11,27 +14,34 @@
 #include "common.h"
 #include "kernels.h"
 
-static constexpr int BM = 64, BN = 64, NW = 4, VE = 8;
+static constexpr int BM = 64, BN = 64, VE = 8;
+static constexpr int NREG = 4;          // partial-tile regions in LDS (4 x 16 KiB); 8-wave workgroups fold waves 4-7 onto 0-3 first
 
-__global__ void __launch_bounds__(256) gemm_skinny_kernel(const ConvArgs a) {
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) gemm_skinny_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* stg = reinterpret_cast<float*>(smem);            // [NW][BM][BN] f32, 16-byte units XOR-swizzled by row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int e = blockIdx.z, m0 = blockIdx.y * BM, cout0 = blockIdx.x * BN;
-    const bf16* W = (const bf16*)a.w + ((size_t)e * a.CoutP + cout0) * a.Cin;
+    const int TAPS = a.ks * a.ks;
+    const int HWo = a.Ho * a.Wo, rows_pe = a.ipe * HWo;          // output rows (pixels) of one expert: contiguous in NHWC
+    const bf16* W = (const bf16*)a.w + ((size_t)e * a.CoutP + cout0) * TAPS * a.Cin;
     const bf16* X = (const bf16*)a.in;
 
     const bf16* pa[2];
-    const bf16* pb[2];
+    int nimg[2], iy0[2], ix0[2];
     bool bok[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        pa[t] = W + (size_t)(t * 32 + l31) * a.Cin + h * 8;
+        pa[t] = W + (size_t)(t * 32 + l31) * TAPS * a.Cin + h * 8;
         const int m = m0 + t * 32 + l31;
-        bok[t] = m < a.ipe;
-        const int n = (a.in_shared ? 0 : e * a.ipe) + (bok[t] ? m : 0);
-        pb[t] = X + (size_t)n * a.in_ld + a.in_coff + h * 8;
+        bok[t] = m < rows_pe;
+        const int mm = bok[t] ? m : 0;
+        const int nl = mm / HWo, rem = mm - nl * HWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        nimg[t] = (a.in_shared ? 0 : e * a.ipe) + nl;
+        iy0[t] = oy * a.stride - a.pad;
+        ix0[t] = ox * a.stride - a.pad;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -42,42 +52,62 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const ConvArgs a) {
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
     const v4i zero = {0, 0, 0, 0};
-    // wave w takes the 16-wide k-slices w, w+4, w+8, ...
-#pragma unroll 4
-    for (int k = wave * 16; k < a.Cin; k += NW * 16) {
-        v4i af[2], bfr[2];
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int r = tap / a.ks, q = tap - r * a.ks;
+        const bf16* pb[2];
+        bool ok[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            af[t] = ldg16(pa[t] + k);
-            bfr[t] = bok[t] ? ldg16(pb[t] + k) : zero;
+            const int iy = iy0[t] + r, ix = ix0[t] + q;
+            ok[t] = bok[t] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            pb[t] = X + (((size_t)nimg[t] * a.H + (ok[t] ? iy : 0)) * a.W + (ok[t] ? ix : 0)) * a.in_ld + a.in_coff + h * 8;
         }
+        const int woff = tap * a.Cin;
+        // wave w takes the 16-wide k-slices w, w+4, w+8, ... of every tap
+#pragma unroll 4
+        for (int k = wave * 16; k < a.Cin; k += NW * 16) {
+            v4i af[2], bfr[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int t = 0; t < 2; ++t) {
+                af[t] = ldg16(pa[t] + woff + k);
+                bfr[t] = ok[t] ? ldg16(pb[t] + k) : zero;
+            }
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[nt]),
-                                                                      __builtin_bit_cast(bf16x8, bfr[mt]), acc[nt][mt], 0, 0, 0);
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[nt]),
+                                                                          __builtin_bit_cast(bf16x8, bfr[mt]), acc[nt][mt], 0, 0, 0);
+        }
     }
     // ---- partial tiles -> LDS: D[cout][m], row m of wave w at stg[w][m][.]
     constexpr int UPR = BN / 4;
-    float* mine = stg + wave * (BM * BN);
+    float* mine = stg + (wave % NREG) * (BM * BN);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int round = 0; round < NW / NREG; ++round) {
+        // round 0: the upper waves (or all, with 4 waves) store; round 1: waves 0-3 add their own tile on top
+        const bool my_turn = (NW == NREG) || (round == 0 ? wave >= NREG : wave < NREG);
+        if (my_turn) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int p = mt * 32 + l31;
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int u = nt * 8 + 2 * g + h;
-                f32x4 v;
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int p = mt * 32 + l31;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[nt][mt][4 * g + i];
-                *reinterpret_cast<f32x4*>(mine + p * BN + ((u ^ (p & (UPR - 1))) << 2)) = v;
-            }
+                    for (int g = 0; g < 4; ++g) {
+                        const int u = nt * 8 + 2 * g + h;
+                        f32x4* dst = reinterpret_cast<f32x4*>(mine + p * BN + ((u ^ (p & (UPR - 1))) << 2));
+                        f32x4 v = (NW > NREG && round == 1) ? *dst : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += acc[nt][mt][4 * g + i];
+                        *dst = v;
+                    }
+                }
         }
-    __syncthreads();
+        __syncthreads();
+    }
     // ---- epilogue (conv_igemm.hip's, on 1x1 images: output pixel index = image index)
-    constexpr int CPO = BN / VE, PROWS = 256 / CPO;
+    constexpr int CPO = BN / VE, PROWS = NW * 64 / CPO;
     const int cc = tid % CPO, pr = tid / CPO;
     const int cout = cout0 + cc * VE;
     const bool cvalid = cout < a.Cout;
@@ -89,12 +119,12 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const ConvArgs a) {
     const bf16* res = (const bf16*)a.res;
     for (int p = pr; p < BM; p += PROWS) {
         const int m = m0 + p;
-        if (!cvalid || m >= a.ipe) continue;
+        if (!cvalid || m >= rows_pe) continue;
         float v[VE];
 #pragma unroll
         for (int i = 0; i < VE; ++i) v[i] = bias[i];
 #pragma unroll
-        for (int w = 0; w < NW; ++w)
+        for (int w = 0; w < NREG; ++w)
 #pragma unroll
             for (int k = 0; k < VE / 4; ++k) {
                 const int u = cc * (VE / 4) + k;
@@ -102,7 +132,7 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[4 * k + i] += tt[i];
             }
-        const size_t opix = (size_t)e * a.ipe + m;
+        const size_t opix = (size_t)e * rows_pe + m;            // dense NHWC output: pixel index = expert base + row
         if (a.res_mode) {
             float rv[VE];
             unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cout), rv);
@@ -137,25 +167,42 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(const ConvArgs a) {
     }
 }
 
-// 1x1 images, 1x1 filter, bf16, no fused statistics, dense output lattice: the expert MLP layers and their data gradients
+// bf16, no fused statistics, dense output lattice, and FEW output rows per expert: the expert MLP layers (1x1 "images") and
+// their data gradients, and the 3x3 / 1x1 convolutions of tiny feature maps at tiny batches (closed-loop inference, B = 1:
+// layer3 / layer4 are 14x14 / 7x7 -- on the generic kernel a serial chain of 36..72 tap-chunks on a dozen workgroups)
 bool gemm_skinny_ok(const ConvArgs& a, int dtype) {
-    static int on = -1;          // PMOE_GEMM_SKINNY=0: back to the generic implicit-GEMM kernel (A/B measurements)
-    if (on < 0) { const char* ev = getenv("PMOE_GEMM_SKINNY"); on = ev ? atoi(ev) : 1; }
-    return on && dtype == PMOE_DT_BF16 && a.H == 1 && a.W == 1 && a.Ho == 1 && a.Wo == 1 && a.ks == 1 && a.kh == 1 && a.kw == 1 &&
-           a.stride == 1 && a.pad == 0 && !a.dilate && !a.use_tapmap && a.out_step == 1 && !a.stats && a.Cin > 0 &&
-           a.Cin % 16 == 0 && a.CoutP % BN == 0 && a.Cout % VE == 0 && a.ipe > 0 && a.N % a.ipe == 0 && a.in_ld % VE == 0 &&
-           a.in_coff % VE == 0 && a.out_ld % VE == 0 && a.out_coff % VE == 0 &&
+    static int on = -1, maxrows = 0;   // PMOE_GEMM_SKINNY=0: back to the generic implicit-GEMM kernel (A/B measurements)
+    if (on < 0) {
+        const char* ev = getenv("PMOE_GEMM_SKINNY");
+        on = ev ? atoi(ev) : 1;
+        const char* mr = getenv("PMOE_SKINNY_MAXROWS");
+        maxrows = mr ? atoi(mr) : 2048;
+    }
+    if (!on || dtype != PMOE_DT_BF16 || a.stats || a.dilate || a.use_tapmap || a.out_step != 1) return false;
+    if ((a.ks != 1 && a.ks != 3) || a.kh != a.ks || a.kw != a.ks || (a.stride != 1 && a.stride != 2)) return false;
+    const bool mlp = a.H == 1 && a.W == 1 && a.Ho == 1 && a.Wo == 1 && a.ks == 1;
+    if (!mlp && (long long)a.ipe * a.Ho * a.Wo > maxrows) return false;
+    if (a.Ho != (a.H + 2 * a.pad - a.ks) / a.stride + 1 || a.Wo != (a.W + 2 * a.pad - a.ks) / a.stride + 1) return false;
+    return a.Cin > 0 && a.Cin % 16 == 0 && a.CoutP % BN == 0 && a.Cout % VE == 0 && a.ipe > 0 && a.N % a.ipe == 0 &&
+           a.in_ld % VE == 0 && a.in_coff % VE == 0 && a.out_ld % VE == 0 && a.out_coff % VE == 0 &&
            (!a.res_mode || (a.res && a.res_ld % VE == 0 && a.res_coff % VE == 0));
 }
 
-int gemm_skinny_launch(const ConvArgs& a, hipStream_t st) {
-    const dim3 grid(a.CoutP / BN, (a.ipe + BM - 1) / BM, a.N / a.ipe);
+template <int NW> static int skinny_launch_nw(const ConvArgs& a, const dim3& grid, hipStream_t st) {
     static bool attr_set = false;
+    const int smem = NREG * BM * BN * (int)sizeof(float);
     if (!attr_set) {
-        HIP_RET(hipFuncSetAttribute((const void*)gemm_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(NW * BM * BN * sizeof(float))));
+        HIP_RET(hipFuncSetAttribute((const void*)gemm_skinny_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_skinny_kernel, grid, dim3(256), NW * BM * BN * sizeof(float), st, a);
+    hipLaunchKernelGGL(gemm_skinny_kernel<NW>, grid, dim3(NW * 64), smem, st, a);
     return (int)hipGetLastError();
+}
+
+int gemm_skinny_launch(const ConvArgs& a, hipStream_t st) {
+    const dim3 grid(a.CoutP / BN, (a.ipe * a.Ho * a.Wo + BM - 1) / BM, a.N / a.ipe);
+    static int nw8 = -1;            // PMOE_SKINNY_NW8: reduction length (taps * Cin) from which 8 waves split K (default 0 = never: measured no faster)
+    if (nw8 < 0) { const char* ev = getenv("PMOE_SKINNY_NW8"); nw8 = ev ? atoi(ev) : 0; }
+    if (nw8 > 0 && a.ks * a.ks * a.Cin >= nw8) return skinny_launch_nw<8>(a, grid, st);
+    return skinny_launch_nw<4>(a, grid, st);
 }

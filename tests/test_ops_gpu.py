@@ -241,6 +241,42 @@ def test_expert_mlp_gemm_shapes_bf16(case):
         close(dx.view(E * ipe, -1)[:, :K], want, dtype, "mlp dgrad + delu'")
 
 
+@pytest.mark.parametrize("case", [(3, 1, 512, 512, 7, 7, 3, 1), (3, 1, 256, 256, 14, 14, 3, 1), (2, 1, 128, 256, 14, 14, 3, 2),
+                                  (2, 2, 128, 256, 10, 6, 1, 2), (1, 3, 64, 128, 9, 5, 3, 1), (4, 1, 256, 512, 13, 13, 3, 2)])
+def test_small_feature_map_convs_bf16(case):
+    """Convolutions with at most 256 output pixels per expert (closed-loop inference, B = 1: layer3 / layer4) run on the
+    tap-looping skinny kernel: 3x3 / 1x1, stride 1 / 2, zero padding at the borders, folded-BatchNorm epilogue (bias +
+    residual add + ReLU), and the stride-1 data gradient."""
+    E, ipe, cin, cout, H, W, ks, stride = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(sum(case))
+    pad = ks // 2
+    N = E * ipe
+    x = rnd((N, cin, H, W), g, dtype)
+    ws = [rnd((cout, cin, ks, ks), g, dtype, (2.0 / (cin * ks * ks)) ** 0.5) for _ in range(E)]
+    bs = [rnd((cout,), g, torch.float32, 0.2) for _ in range(E)]
+    Ho, Wo = ops.conv_out_size(H, ks, stride, pad), ops.conv_out_size(W, ks, stride, pad)
+    assert ipe * Ho * Wo <= 256
+    res = rnd((N, cout, Ho, Wo), g, dtype)
+    ref = torch.cat([F.conv2d(x[e * ipe:(e + 1) * ipe], ws[e], bs[e], stride=stride, padding=pad) for e in range(E)])
+    wf, wd, _ = pack(ws, ks, dtype, want_dgrad=True)
+    bias = torch.empty(E, r64(cout), device=DEV)
+    ops.pack_bias(hip.ptr_table([b.to(DEV) for b in bs], DEV), bias, E, cout, r64(cout))
+    xd = nhwc(x, r16(cin), dtype)
+    out = torch.full((N, Ho, Wo, r16(cout)), 5.0, dtype=dtype, device=DEV)
+    ops.conv2d(xd, wf, out, cin=r16(cin), cout=r16(cout), coutp=r64(cout), ipe=ipe, ks=ks, stride=stride, pad=pad, bias=bias,
+               act=hip.ACT_RELU, res=nhwc(res, r16(cout), dtype), res_mode=hip.RES_ADD)
+    close(from_nhwc(out, cout), torch.relu(ref + res), dtype, "small-map conv + bias + res + relu")
+    if stride == 1:
+        dy = rnd((N, cout, Ho, Wo), g, dtype)
+        xr = x.clone().requires_grad_(True)
+        torch.cat([F.conv2d(xr[e * ipe:(e + 1) * ipe], ws[e], stride=1, padding=pad) for e in range(E)]).backward(dy)
+        dx = torch.empty(N, H, W, r16(cin), dtype=dtype, device=DEV)
+        ops.conv2d(nhwc(dy, r16(cout), dtype), wd, dx, cin=r16(cout), cout=r16(cin), coutp=r64(cin), ipe=ipe, ks=ks, stride=1,
+                   pad=ks - 1 - pad)
+        close(from_nhwc(dx, cin), xr.grad, dtype, "small-map dgrad")
+
+
 def test_dropout_epilogue_statistics():
     g = torch.Generator().manual_seed(5)
     E, ipe, K, Nn = 1, 64, 16, 512

@@ -13,7 +13,7 @@ from pmoe_amd.utils import stage2_model_cfg  # noqa: E402
 
 
 def main():
-    E = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    E = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
     model = get_model(stage2_model_cfg("moe", E, dropout=0.3)).cuda().eval()
     img = torch.rand(1, 4, 3, 224, 224, device="cuda")
     spd = torch.rand(1, 1, device="cuda")
@@ -49,6 +49,14 @@ def main():
     print(f"E={E} B=1 224x224 eval  HIP graph: {graphed:.3f} ms/tick ({eager / graphed:.1f}x)", flush=True)
     a = gm.sample(img, spd, cmd)
     assert a.shape == (1, 2)
+    if "--profile" in sys.argv:
+        from pmoe_amd import ops
+        ops.profile_begin()
+        tick()
+        rows = ops.profile_end()
+        print(f"  {len(rows)} launches, {sum(r[2] for r in rows):.3f} ms of kernel time")
+        for name, meta, ms in sorted(rows, key=lambda r: -r[2])[:16]:
+            print(f"  {name:22s} {meta.get('name', ''):28s} {ms * 1e3:7.1f} us  kernel={meta.get('kernel', '')}")
 
 
 if __name__ == "__main__":
