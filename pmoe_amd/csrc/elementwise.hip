@@ -566,17 +566,19 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
 
 // same, 64 pixels x Cp channels per workgroup through LDS: reads coalesced along the pixel axis of every channel plane,
 // writes one contiguous 64*Cp-element run of the NHWC tensor (the per-pixel scalar stores above are strided by Cp)
-template <typename T>
+template <typename T, int PIX>
 __global__ void __launch_bounds__(256) nchw_to_nhwc_tiled_kernel(const float* __restrict__ src, T* __restrict__ dst, int B,
                                                                 int C, long long HW, int Cp) {
-    extern __shared__ float tile[];          // [64][Cp + 1]
-    const long long nblk = (HW + 63) / 64;
+    extern __shared__ float tile[];          // [PIX][Cp + 1]
+    const long long nblk = (HW + PIX - 1) / PIX;
     const int b = (int)(blockIdx.x / nblk);
-    const long long p0 = (blockIdx.x % nblk) * 64;
-    const int np = (int)((HW - p0) < 64 ? (HW - p0) : 64);
-    const int CS = Cp + 1, p = threadIdx.x & 63;
-    for (int c = threadIdx.x >> 6; c < Cp; c += 4)
+    const long long p0 = (blockIdx.x % nblk) * PIX;
+    const int np = (int)((HW - p0) < PIX ? (HW - p0) : PIX);
+    const int CS = Cp + 1;
+    for (int i = threadIdx.x; i < PIX * Cp; i += 256) {
+        const int c = i / PIX, p = i - c * PIX;          // consecutive threads: consecutive pixels of one channel plane
         if (p < np) tile[p * CS + c] = c < C ? src[((size_t)b * C + c) * HW + p0 + p] : 0.f;
+    }
     __syncthreads();
     T* d = dst + ((size_t)b * HW + p0) * Cp;
     for (int i = threadIdx.x; i < np * Cp; i += 256) d[i] = from_f32<T>(tile[(i / Cp) * CS + (i % Cp)]);
@@ -779,11 +781,14 @@ int pmoe_eca_bwd_apply(const void* dy, const float* gate, const float* dgap, voi
 int pmoe_nchw_to_nhwc(const float* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cp,
                       int32_t dtype, void* stream) {
     if (B < 1 || C < 1 || H < 1 || W < 1 || Cp < C) return PMOE_ERR_ARG;
-    const long long HW = (long long)H * W, nblk = (HW + 63) / 64 * B;
+    const long long HW = (long long)H * W, nblk = (HW + 63) / 64 * B, nblk4 = (HW + 255) / 256 * B;
     DISPATCH_DT(dtype, {
-        if (Cp <= 240 && nblk <= 0x7fffffffLL)
-            hipLaunchKernelGGL((nchw_to_nhwc_tiled_kernel<T>), dim3((unsigned)nblk), dim3(256), 64 * (Cp + 1) * sizeof(float),
-                               (hipStream_t)stream, src, (T*)dst, B, C, HW, Cp);
+        if (Cp <= 32 && nblk4 <= 0x7fffffffLL)           // few channels (camera frames): 256 pixels per workgroup
+            hipLaunchKernelGGL((nchw_to_nhwc_tiled_kernel<T, 256>), dim3((unsigned)nblk4), dim3(256),
+                               256 * (Cp + 1) * sizeof(float), (hipStream_t)stream, src, (T*)dst, B, C, HW, Cp);
+        else if (Cp <= 240 && nblk <= 0x7fffffffLL)
+            hipLaunchKernelGGL((nchw_to_nhwc_tiled_kernel<T, 64>), dim3((unsigned)nblk), dim3(256),
+                               64 * (Cp + 1) * sizeof(float), (hipStream_t)stream, src, (T*)dst, B, C, HW, Cp);
         else
             hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for((long long)B * H * W, 8192)), dim3(256), 0,
                                (hipStream_t)stream, src, (T*)dst, B, C, H, W, Cp);
