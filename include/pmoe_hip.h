@@ -75,6 +75,7 @@ int pmoe_conv2d_igemm(const pmoe_conv_desc* d, void* stream);
 int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
 /* which kernel instantiation pmoe_conv2d_igemm would run for this descriptor (nothing is launched; used by bench.py
  * to attribute measured launch times to kernel symbols that a rocprofv3 kernel trace shows):
+ *   3000                     gemm_skinny_kernel<4|8>               (expert MLP layers / <= 2048 output pixels per expert, bf16)
  *   1000 + LOG_RB            conv3x3_res_kernel<LOG_RB>            (resident-filter kernel, conv_res.hip)
  *   2000 + LOG_RB            conv_igemm_lite_kernel<T, LOG_RB>     (8-wave 256 x 128 tile, two workgroups per CU)
  *   LOG_RB*100 + WM*10 + WN  conv_igemm_kernel<T, LOG_RB, WM, WN>  (halo-patch implicit GEMM, conv_igemm.hip)

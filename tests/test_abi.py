@@ -81,5 +81,7 @@ def test_conv_plan_reports_the_kernel_instantiation():
     assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1005                 # 12(16)-channel stem on the resident kernel
     assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 2007                # conv_igemm_lite_kernel<bf16,7>: 2 workgroups / CU
     assert plan(256, 256, 32, 3, 1, torch.float32) == 722                  # f32: 4-wave 128x128 tile, 32-channel chunks
-    assert plan(1536, 512, 1, 1, 1, torch.bfloat16) == 722                 # expert MLP GEMM: 4-wave tile
+    assert plan(1536, 512, 1, 1, 1, torch.bfloat16) == 3000                # expert MLP GEMM: gemm_skinny_kernel
+    assert plan(1536, 512, 1, 1, 1, torch.float32) == 722                  # ... in f32: generic 4-wave tile
+    assert plan(512, 512, 14, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # B=1 inference layer4: tap-looping skinny kernel
     assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 4741   # stride-2 dgrad: 4 class launches <7,4,1>
