@@ -35,6 +35,16 @@ template <> struct Mma<float> {
     }
 };
 
+// -DPMOE_STAMP (tools/stamp_conv.py only, never the product build): per-wave cycle accounting of the main loop with
+// s_memtime (scalar registers: no VGPR cost).  The five sums land in a.stats instead of the BatchNorm partial sums.
+#ifdef PMOE_STAMP
+#define STAMP_INIT unsigned long long st_prev = __builtin_amdgcn_s_memtime(); unsigned st_acc[5] = {0, 0, 0, 0, 0};
+#define LAP(i) { const unsigned long long st_t = __builtin_amdgcn_s_memtime(); st_acc[i] += (unsigned)(st_t - st_prev); st_prev = st_t; }
+#else
+#define STAMP_INIT
+#define LAP(i)
+#endif
+
 // LITE: the 8-wave tile without chunk prefetch and stagger and with the epilogue staged in two halves -- few enough
 // registers (launch bound: 2 workgroups per CU) and LDS for TWO resident workgroups, whose prologues / epilogues / barriers
 // then overlap each other's MFMAs.
@@ -148,6 +158,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     };
 
     const int nchunks = a.Cin / CK;
+    STAMP_INIT
     int cur = 0;
     auto wtap = [&](int i) { return a.use_tapmap ? a.tapmap[i] : i; };
     w_issue(0, wtap(0));
@@ -167,6 +178,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         if (LITE || !a.prefetch || ch == 0) {
             load_patch(patch, c0);
             __syncthreads();
+            LAP(0)                                       // halo patch of this chunk staged (incl. its barrier)
         }
         const bool more = !LITE && a.prefetch && ch + 1 < nchunks;
         if (more) nxt.issue(in, geo, c0 + CK, tid);      // in flight under this chunk's taps of MFMAs
@@ -216,9 +228,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                             for (int mt = 0; mt < 2; ++mt) Mma<T>::run(af[nt], bfr[mt], acc[nt][mt]);
                     }
                 }
+                LAP(1)                                   // fragment reads + MFMA issue of this tap
                 if (!last) w_commit(cur ^ 1);
                 if (more && tap == NTAP - 1) nxt.template commit<0>(patch0 + ((ch + 1) & 1) * PB, NPIX, tid);
+                LAP(2)                                   // wait for the next tap's weights + their LDS writes
                 __syncthreads();
+                LAP(3)                                   // barrier
                 cur ^= 1;
             }
         }
@@ -319,16 +334,26 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                     v[i] = hash_uniform(a.seed, base + i) >= a.drop_p ? v[i] * keep_scale : 0.f;
             }
             const v4i pk = pack16<T>(v);
+#ifndef PMOE_STAMP
             if (a.stats) {
                 float rr[VE];
                 unpack16<T>(pk, rr);
 #pragma unroll
                 for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
             }
+#endif
             stg16(out + opix * a.out_ld + a.out_coff + cout, pk);
         }
     }
   }
+#ifdef PMOE_STAMP
+    LAP(4)                                               // epilogue
+    if (a.stats && lane == 0) {
+        float* o = a.stats + ((size_t)blockIdx.x * (WM * WN) + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = (float)st_acc[i];
+    }
+    return;
+#endif
     if (a.stats) {
         // BatchNorm partial sums of this tile: lanes sharing a channel vector combine by xor-shuffle,
         // waves through LDS; one [2][CoutP] row per m-block, reduced later in fixed order.
@@ -437,6 +462,9 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         static int stg_on = -1;     // PMOE_CONV_STAGGER=0: A/B switch
         if (stg_on < 0) { const char* ev = getenv("PMOE_CONV_STAGGER"); stg_on = ev ? atoi(ev) : 1; }
         a.stagger = stg_on && big && !lite;
+        // (LITE with every load of a chunk's halo patch in flight at once -- one L2 round trip instead of two -- measured
+        // within noise, +-2 %, and tools/stamp_conv.py still showed 28 % of the wave cycles in patch staging: the cost is
+        // not the number of round trips)
         static int pf_on = -1;      // PMOE_CONV_PREFETCH=0: A/B switch
         if (pf_on < 0) { const char* ev = getenv("PMOE_CONV_PREFETCH"); pf_on = ev ? atoi(ev) : 1; }
         // (also the expert MLP GEMMs: 1x1 "images", K = 512..1536 in 64-channel chunks -- a latency chain of 8..24 chunks)

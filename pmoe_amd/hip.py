@@ -11,7 +11,8 @@ from pathlib import Path
 
 import torch
 
-_LIB_PATH = Path(__file__).resolve().parent / "libpmoe_hip.so"
+# PMOE_HIP_LIB: a differently built library (tools/stamp_conv.py loads its cycle-stamped build this way)
+_LIB_PATH = Path(os.environ.get("PMOE_HIP_LIB") or Path(__file__).resolve().parent / "libpmoe_hip.so")
 _lib = None
 
 DT_BF16, DT_F32 = 0, 1

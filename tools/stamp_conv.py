@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Where do the waves of the dominant conv kernel spend their cycles?  Builds a CYCLE-STAMPED variant of conv_igemm.hip
+(-DPMOE_STAMP: s_memtime laps in scalar registers around the five phases of the main loop; never the product build), loads it
+through PMOE_HIP_LIB and runs single launches at the headline shapes.
+
+  python tools/stamp_conv.py --build          # here (hipcc cross-compiles): pmoe_amd/libpmoe_hip_stamp.so
+  python tools/stamp_conv.py [l3 l4 l2]       # on the GPU box: per-phase share of wave cycles, forward and data gradient
+"""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+LIB = ROOT / "pmoe_amd" / "libpmoe_hip_stamp.so"
+PHASES = ["halo patch staging (+ its barrier)", "fragment reads + MFMA issue", "weight-tile wait + LDS write", "per-tap barrier",
+          "epilogue"]
+
+
+def build():
+    csrc, bld = ROOT / "pmoe_amd" / "csrc", ROOT / "build"
+    subprocess.check_call([str(ROOT / "build.sh")])
+    obj = bld / "conv_igemm_stamp.o"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+                           "-Wno-unused-result", "-DPMOE_STAMP", "-c", str(csrc / "conv_igemm.hip"), "-o", str(obj)])
+    others = [str(o) for o in sorted(bld.glob("*.o")) if o.name not in ("conv_igemm.o", "conv_igemm_stamp.o")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), str(obj)] + others)
+    print("built", LIB)
+
+
+def main():
+    if "--build" in sys.argv:
+        return build()
+    os.environ["PMOE_HIP_LIB"] = str(LIB)
+    sys.path.insert(0, str(ROOT))
+    import torch
+    from pmoe_amd import hip, ops
+    hip.load()
+    E, B = 4, 64
+    shapes = {"l2": (128, 128, 64), "l3": (256, 256, 32), "l4": (512, 512, 16)}
+    dt = torch.bfloat16
+    for name in [a for a in sys.argv[1:] if a in shapes] or ["l3", "l4"]:
+        cin, cout, H = shapes[name]
+        N = E * B
+        x = torch.randn(N, H, H, cin, device="cuda").to(dt)
+        ws = [torch.randn(cout, cin, 3, 3, device="cuda") * 0.05 for _ in range(E)]
+        wf = torch.empty(E, cout, 9, cin, dtype=dt, device="cuda")
+        wd = torch.empty(E, cin, 9, cout, dtype=dt, device="cuda")
+        ops.pack_conv_weights(hip.ptr_table(ws, "cuda"), wf, wd, E, cout, cin, 3, cout, cin, cin, cout, dt)
+        y = torch.empty(N, H, H, cout, dtype=dt, device="cuda")
+        rows = ops.conv2d_stat_rows(N, H, H, H, H, cin, cout, cout, B, 3, 1, 1, dt)
+        plan = ops.conv2d_plan(N, H, H, H, H, cin, cout, cout, B, 3, 1, 1, dt) if hasattr(ops, "conv2d_plan") else None
+        for what, (src, w) in {"forward": (x, wf), "data gradient": (y, wd)}.items():
+            stats = torch.full((rows, 2, cout), -1.0, device="cuda")
+            for _ in range(3):          # warm caches / clocks, keep the last
+                stats.fill_(-1.0)
+                ops.conv2d(src, w, y if what == "forward" else x, cin=cin if what == "forward" else cout,
+                           cout=cout if what == "forward" else cin, coutp=cout if what == "forward" else cin, ipe=B, ks=3,
+                           stride=1, pad=1, stats=stats)
+            torch.cuda.synchronize()
+            v = stats.flatten().cpu()
+            nwg = rows * (cout // 128)
+            rec = v[:nwg * 8 * 8].view(nwg * 8, 8)[:, :5]
+            assert (rec >= 0).all(), "stamped library not loaded or a different kernel ran"
+            tot = rec.sum(1)
+            share = (rec / tot[:, None]).mean(0)
+            print(f"{name} {what}: kernel plan {plan}, {nwg} workgroups x 8 waves, {tot.mean().item():.0f} stamped cycles per wave "
+                  f"(min {tot.min().item():.0f}, max {tot.max().item():.0f})")
+            for ph, s in zip(PHASES, share.tolist()):
+                print(f"    {100 * s:5.1f} %  {ph}")
+
+
+if __name__ == "__main__":
+    main()
