@@ -63,6 +63,15 @@ def main():
             rec = v[:nwg * 8 * 8].view(nwg * 8, 8)[:, :5]
             assert (rec >= 0).all(), "stamped library not loaded or a different kernel ran"
             tot = rec.sum(1)
+            t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+            for _ in range(10):
+                ops.conv2d(src, w, y if what == "forward" else x, cin=cin if what == "forward" else cout,
+                           cout=cout if what == "forward" else cin, coutp=cout if what == "forward" else cin, ipe=B, ks=3,
+                           stride=1, pad=1, stats=stats)
+            t1.record(); torch.cuda.synchronize()
+            ms = t0.elapsed_time(t1) / 10
+            print(f"{name} {what}: {ms:.3f} ms per launch = {2.0 * N * H * H * cin * cout * 9 / ms / 1e9:.0f} TFLOP/s (stamped build)")
             share = (rec / tot[:, None]).mean(0)
             print(f"{name} {what}: kernel plan {plan}, {nwg} workgroups x 8 waves, {tot.mean().item():.0f} stamped cycles per wave "
                   f"(min {tot.min().item():.0f}, max {tot.max().item():.0f})")
