@@ -65,7 +65,7 @@ def build_pair(g, dtype, dropout=0.0):
     return ocfg, oracle, model, inp
 
 
-def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, fwd_tol_mult=1.0):
+def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, fwd_tol_mult=1.0, f64_oracle=True):
     g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
     ocfg, oracle, model, inp = build_pair(g, dtype)
     dev = {k: v.to("cuda") for k, v in inp.items()}
@@ -113,11 +113,16 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
             # conditioning-aware bound: the same oracle in float64 tells how far two exact-f32 evaluations of this
             # tensor can drift apart; the HIP f32 path must stay within 4x that (floor 5e-3) of the f64 truth
             import copy
-            o64 = copy.deepcopy(oracle).double()
-            o64.zero_grad()
-            d64, s64 = o64(inp["images"].double(), inp["speed"].double(), inp["command"].double())
-            O.moe_loss(d64, s64, inp["control"].double(), inp["target_speed"].double(), ocfg.loss_coefs).backward()
-            g64 = {k: p.grad.float() for k, p in o64.named_parameters()}
+            if f64_oracle:
+                o64 = copy.deepcopy(oracle).double()
+                o64.zero_grad()
+                d64, s64 = o64(inp["images"].double(), inp["speed"].double(), inp["command"].double())
+                O.moe_loss(d64, s64, inp["control"].double(), inp["target_speed"].double(), ocfg.loss_coefs).backward()
+                g64 = {k: p.grad.float() for k, p in o64.named_parameters()}
+            else:
+                # the largest cases skip the float64 evaluation (it is most of their run time): the f32 oracle stands in
+                # as the truth with its typical own drift (5e-3) assumed, i.e. a flat 2e-2 per-tensor bound
+                g64 = {k: p.grad for k, p in onamed.items()}
             # Isolated ReLU-mask flips: any two f32 implementations disagree on the sign of a few pre-activations
             # that sit within ~1e-7 of zero (expected 0.2-2 per pass here).  At the 4x4 / 8x8 layers of these B=2
             # goldens one flip moves ONE channel's BatchNorm gradient by ~25 % and every upstream tensor of THAT
@@ -134,7 +139,7 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
             for k, p in named.items():
                 if g64[k].norm().item() < 1e-6 * total_ref:
                     continue
-                e_ref = rel_l2(onamed[k].grad, g64[k])
+                e_ref = rel_l2(onamed[k].grad, g64[k]) if f64_oracle else 5e-3
                 e_hip = rel_l2(p.grad, g64[k])
                 ex = expert_of(k)
                 per_expert.setdefault(ex, []).append((e_hip, e_hip <= max(5e-3, 4 * e_ref), k))

@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 from tests.parity_util import GOLDEN, build_pair, rel_err, run_parity_case  # noqa: E402
 
 
-@pytest.mark.parametrize("name", ["g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g1_moe_e4_b2_128", "g3_moe_e8_b2_128",
-                                  "g10_moe_e4_b32_64"])
+@pytest.mark.parametrize("name", ["g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g3_moe_e8_b2_128", "g10_moe_e4_b32_64"])
 def test_train_parity_f32(name):
-    run_parity_case(name, torch.float32, check_grads=True)
+    """(g1 -- same shapes as g3 with E=4 -- is covered by the bf16 case and the 5-step trajectory test; the two largest cases
+    skip the float64 oracle, which is most of their run time on the box's host cores: see parity_util.run_parity_case)"""
+    run_parity_case(name, torch.float32, check_grads=True, f64_oracle=name not in ("g3_moe_e8_b2_128", "g10_moe_e4_b32_64"))
 
 
 def test_train_parity_f32_shared_trunk():

@@ -26,7 +26,7 @@ def test_punet_inter_train_parity_f32(tmp_path):
     assert r["golden_slices_worst"] <= 5e-3 and r["bn_running_worst"] <= 1e-4, r
 
 
-@pytest.mark.parametrize("name", ["p1_punet_b2_64_f2", "p4_punet_b3_96_f3"])
+@pytest.mark.parametrize("name", ["p4_punet_b3_96_f3"])          # (p1, the smaller sibling, runs in bf16 below)
 def test_punet_train_parity_f32(tmp_path, name):
     """PUNetExpert with the 138/69-channel ResNet stem in train mode: forward within 5x the f32 oracle's own drift from
     float64, the typical gradient tensor within 4x that drift, directions and total norm preserved, frozen PU-Net

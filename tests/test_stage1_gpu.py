@@ -265,16 +265,12 @@ def test_stage1_bptt_tight_with_eval_mode_batchnorm(tmp_path, frames):
     errs.sort()
     print("eval-mode BPTT", frames, "median", errs[len(errs) // 2], "worst", errs[-1])
     assert errs[-1][0] <= 1.0 and errs[len(errs) // 2][1] <= 2e-3, (errs[len(errs) // 2], errs[-1])
-
-
-def test_stage1_bptt_bf16_with_eval_mode_batchnorm(tmp_path):
-    """bf16 storage (the bench configuration) in the well-conditioned setting of the test above: logits within the bf16
-    forward tolerance 3e-2 * (1 + |ref|), gradients aligned with the float64 oracle."""
-    g = torch.load(GOLDEN / "s1_stage1_b3_32_f3.pt", weights_only=False)
-    oracle, model, images, target = _build(tmp_path, g, torch.bfloat16)
-    oracle.eval()
-    model.eval()
-    out64, loss64, _, g64, _ = _oracle_run(oracle, images, target, 3, torch.float64)
+    if frames != 3:
+        return
+    # bf16 storage (the bench configuration) in the same well-conditioned setting, against the same float64 oracle: logits
+    # within the bf16 forward tolerance 3e-2 * (1 + |ref|), gradients aligned
+    model.zero_grad()
+    model.compute_dtype = torch.bfloat16
     out = model(images.to(DEV))
     loss = AutoregressiveCriterion(3, "tversky")(out, target.to(DEV))
     loss.backward()
@@ -283,8 +279,7 @@ def test_stage1_bptt_bf16_with_eval_mode_batchnorm(tmp_path):
                  for k, p in model.named_parameters() if p.grad is not None and p.numel() >= 256)
     tot = sum(p.grad.norm().item() ** 2 for p in model.parameters() if p.grad is not None) ** 0.5
     ref = sum(v.norm().item() ** 2 for v in g64.values()) ** 0.5
-    print("bf16 eval-mode BPTT: fwd", fwd, "loss", loss.item(), loss64.item(), "median cos", cos[len(cos) // 2], "min", cos[0],
-          "norm", tot, ref)
+    print("bf16 eval-mode BPTT: fwd", fwd, "loss", loss.item(), loss64.item(), "median cos", cos[len(cos) // 2], "min", cos[0])
     assert fwd <= 3e-2 and abs(loss.item() - loss64.item()) <= 1e-2 * (1 + abs(loss64.item()))
     assert cos[len(cos) // 2] >= 0.95 and abs(tot - ref) <= 0.1 * ref
 
