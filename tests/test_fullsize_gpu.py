@@ -124,3 +124,60 @@ def test_bf16_path_agrees_with_exact_f32_path_at_full_size():
     tot_b = sum(v.norm().item() ** 2 for v in gb.values()) ** 0.5
     tot_f = sum(v.norm().item() ** 2 for v in gf.values()) ** 0.5
     assert abs(tot_b - tot_f) <= 0.2 * tot_f
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 3's per-GPU shard (E=8, B=64) and config 4 (PU-Net expert, T=4, F=6, B=64, 256x256) at full size
+def test_eight_experts_full_size_properties():
+    """E=8, B=64, 256x256 (the shard one GPU of the 8-GPU config runs): deterministic forward, exact x2 loss scaling."""
+    torch.manual_seed(0)
+    m = get_model(stage2_model_cfg("moe", 8, dropout=0.0)).cuda()
+    m.compute_dtype = torch.bfloat16
+    m.train()
+    batch = _batch()
+    sd = copy.deepcopy(m.state_dict())
+    o1, l1, g1 = _step(m, batch, (0.7, 0.3))
+    m.load_state_dict(sd)
+    o2, l2, g2 = _step(m, batch, (1.4, 0.6))
+    assert o1[0].shape == (B, 8) and o1[1].shape == (B, 8, 2)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    assert abs(l2.item() - 2 * l1.item()) <= 1e-6 * abs(l1.item())
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        assert (g2[k] - 2 * g1[k]).norm() <= 2e-5 * g1[k].norm() + 1e-12, k
+
+
+def test_punet_expert_full_size_properties(tmp_path):
+    """Config 4 (`punet`: frozen PU-Net -> 138-channel ResNet stem -> tanh head) at B=64, 256x256, bf16: deterministic
+    forward, loss linear in its coefficients (exact factor 2 through every backward kernel), frozen PU-Net without
+    gradients, train-mode BatchNorm buffers of the frozen U-Nets updated (4 passes of `unet`, F of `pred_unet`)."""
+    from pmoe_amd.loss import punet_loss
+    from tests.punet_util import build_product
+    torch.manual_seed(0)
+    m = build_product(tmp_path, dict(type="punet", n_experts=2, future_frames=6)).cuda()
+    m.compute_dtype = torch.bfloat16
+    m.train()
+    images, speed, command, control, target = _batch()
+
+    def step(coefs):
+        m.zero_grad(set_to_none=True)
+        a, s = m(images, speed, command)
+        loss = punet_loss(a, s, control, target, list(coefs))
+        loss.backward()
+        return a.detach().clone(), s.detach().clone(), loss.detach().clone(), \
+            {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    sd = copy.deepcopy(m.state_dict())
+    a1, s1, l1, g1 = step((0.7, 0.3))
+    nb = int(m.state_dict()["punet.unet.dwn_1.1.num_batches_tracked"]) - int(sd["punet.unet.dwn_1.1.num_batches_tracked"])
+    nbp = int(m.state_dict()["punet.pred_unet.dwn_1.1.num_batches_tracked"]) - int(sd["punet.pred_unet.dwn_1.1.num_batches_tracked"])
+    assert (nb, nbp) == (4, 6)
+    m.load_state_dict(sd)
+    a2, s2, l2, g2 = step((1.4, 0.6))
+    assert a1.shape == (B, 2) and a1.abs().max() <= 1 and torch.equal(a1, a2) and torch.equal(s1, s2)
+    assert abs(l2.item() - 2 * l1.item()) <= 1e-6 * abs(l1.item())
+    assert g1 and not any(k.startswith("punet.") for k in g1), "the frozen PU-Net must not receive gradients"
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        assert (g2[k] - 2 * g1[k]).norm() <= 2e-5 * g1[k].norm() + 1e-12, k
