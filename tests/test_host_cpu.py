@@ -96,3 +96,30 @@ def test_product_never_imports_the_oracle():
     root = pathlib.Path(__file__).resolve().parents[1] / "pmoe_amd"
     for f in root.rglob("*.py"):
         assert "oracle" not in f.read_text(), f
+
+
+def test_stage1_entry_points_have_no_cpu_path(tmp_path):
+    """PredictiveUnet.forward / AutoregressiveCriterion fail loudly on CPU tensors, keep the reference's
+    state_dict layout and argument checks, and survive copy.deepcopy (AveragedModel, train_1.py:113)."""
+    import copy
+
+    import pytest
+    import torch
+
+    from pmoe_amd.loss import AutoregressiveCriterion
+    from pmoe_amd.model import blocks as B
+    from pmoe_amd.model.punet import PredictiveUnet
+    torch.save({"unet": B.UNet().state_dict()}, tmp_path / "unet.pth")
+    m = PredictiveUnet(4, 2, model_name="unet", model_path=str(tmp_path / "unet.pth"))
+    assert [k.split(".")[0] for k in m.state_dict()][0] == "unet" and any(k.startswith("pred_unet.up_1.") for k in m.state_dict())
+    assert not any(p.requires_grad for p in m.unet.parameters()) and all(p.requires_grad for p in m.pred_unet.parameters())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.rand(1, 4, 3, 32, 32))
+    with pytest.raises(AssertionError):
+        m(torch.rand(1, 3, 3, 32, 32))                     # punet.py:84-86: number of past frames
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        AutoregressiveCriterion(2)(torch.randn(1, 2, 23, 8, 8), torch.zeros(1, 2, 8, 8, dtype=torch.long))
+    with pytest.raises(ValueError):
+        AutoregressiveCriterion(1, "dice")
+    m2 = copy.deepcopy(m)
+    assert list(m2.state_dict().keys()) == list(m.state_dict().keys()) and "_eng" not in m2.__dict__
