@@ -85,3 +85,14 @@ def test_conv_plan_reports_the_kernel_instantiation():
     assert plan(1536, 512, 1, 1, 1, torch.float32) == 722                  # ... in f32: generic 4-wave tile
     assert plan(512, 512, 14, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # B=1 inference layer4: tap-looping skinny kernel
     assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 4741   # stride-2 dgrad: 4 class launches <7,4,1>
+
+
+def test_cycle_stamped_tools_build_compiles(tmp_path):
+    """tools/stamp_conv.py's -DPMOE_STAMP variant of the dominant conv kernel (never the product build) keeps compiling."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = REPO / "pmoe_amd" / "csrc" / "conv_igemm.hip"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-DPMOE_STAMP",
+                           "-c", str(src), "-o", str(tmp_path / "conv_igemm_stamp.o")], stderr=subprocess.DEVNULL)
+    assert (tmp_path / "conv_igemm_stamp.o").stat().st_size > 0
