@@ -140,7 +140,7 @@ class ExpertGroupEngine:
         self.fold_bn_eval = True      # inference: eval-mode BatchNorm folded into the conv weights / epilogue
         self.pooled_stem_bwd = True   # stem-tail BatchNorm reductions from the pooled tensors (train mode)
         self.fold_eca_gate = True     # ECA gate folded into per-image conv weights (no gated activation in memory)
-        self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tools/probe_layers.py)
+        self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tests/experiments/probe_layers.py)
         self._collect()
 
     # ------------------------------------------------------------------ structure

@@ -4,10 +4,10 @@ parameter matrix and every layer output rounded to bf16 (f32 arithmetic in betwe
 max |got - ref| / (1 + |ref|) on probs / mean / std / speeds -- the same metric tests/parity_util.py applies to the HIP
 path.  Measured (build container): B=32 64x64 (golden g10): 6.1e-3 / 3.6e-2 / 2.2e-2 / 2.4e-2 (HIP bf16 path on the same
 case: worst 3.5e-2); B=2 128x128 (g1): 1.7e-3 / 1.1e-2 / 7.0e-3 / 1.1e-2; B=16 128x128: 4.1e-3 / 1.6e-2 / 9.0e-3 / 1.1e-2.
-  python tools/bf16_forward_emulation.py"""
+  python tests/experiments/bf16_forward_emulation.py"""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import torch, torch.nn as nn
 from oracle import pmoe_oracle as O, weights as W
 class RoundBF16(torch.autograd.Function):

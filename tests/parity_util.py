@@ -17,9 +17,9 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 #   f32 : max|got-ref| <= 1e-4 * max|ref|                      (measured ~2e-6)
 #   bf16: |got-ref| <= 3e-2*(1+|ref|) elementwise.  The 1e-2 of north_star is NOT met end to end on these
 #         tiny-batch goldens (measured up to 2.8e-2); the same CPU oracle with bf16-rounded layer outputs is
-#         off by the same amount (tools/bf16_conditioning.py), i.e. it is the storage format, not the kernels:
+#         off by the same amount (tests/experiments/bf16_conditioning.py), i.e. it is the storage format, not the kernels:
 #         every bf16 kernel meets 1e-2 on its own (tests/test_ops_gpu.py).
-# Gradients -- the random-weight 20-layer ReLU/BN network is chaotic for gradients: tools/bf16_conditioning.py
+# Gradients -- the random-weight 20-layer ReLU/BN network is chaotic for gradients: tests/experiments/bf16_conditioning.py
 # shows the CPU oracle in f32 vs f64 differs by up to 2e-2 rel-L2 on some tensors, and the oracle with
 # bf16-rounded activations differs from f64 by a MEDIAN of 0.4 rel-L2 (DESIGN.md "numerics").  So:
 #   f32 : every parameter gradient within max(5e-3, 4x the f32-oracle's own drift from the f64 oracle) of the
@@ -126,7 +126,7 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
             # Isolated ReLU-mask flips: any two f32 implementations disagree on the sign of a few pre-activations
             # that sit within ~1e-7 of zero (expected 0.2-2 per pass here).  At the 4x4 / 8x8 layers of these B=2
             # goldens one flip moves ONE channel's BatchNorm gradient by ~25 % and every upstream tensor of THAT
-            # expert by ~1 % (tools/probe_layers.py pinpoints the channel; DESIGN.md "numerics").  All experts run
+            # expert by ~1 % (tests/experiments/probe_layers.py pinpoints the channel; DESIGN.md "numerics").  All experts run
             # through the same launches of the same kernels, so the algorithm is proven by the experts that are
             # flip-free: at least half of the experts must meet the tight conditioning-aware bound on EVERY
             # tensor; the others may only deviate by what a flip explains (<= 0.15, median <= 3e-2).

@@ -34,7 +34,7 @@ def test_train_parity_bf16(name):
 
 def test_train_parity_bf16_realistic_batch():
     """B=32 batch statistics (g10).  The CPU oracle with its parameters and layer outputs rounded to bf16 is 3.6e-2 off
-    the float64 oracle on `mean` for this case (tools/bf16_forward_emulation.py); the HIP bf16 path measures 3.5e-2 --
+    the float64 oracle on `mean` for this case (tests/experiments/bf16_forward_emulation.py); the HIP bf16 path measures 3.5e-2 --
     the storage format, not the kernels -- hence 1.25 x the 3e-2 bf16 forward bound here."""
     run_parity_case("g10_moe_e4_b32_64", torch.bfloat16, check_grads=True, fwd_tol_mult=1.25)
 
