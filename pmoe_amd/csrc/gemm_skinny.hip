@@ -2,7 +2,7 @@
 //   Y[m][n] = epilogue( sum_k X[m][k] * W[n][k] ),   m < images-per-expert (the batch, 64), n = 16..1536, k = 16..1536
 // i.e. the 1x1 "convolutions" over 1x1 images of the grouped engine -- and, with a loop over the filter taps (row m = output
 // pixel, its operand row = the tap-shifted input pixel, zero outside the image), the 3x3 / 1x1 convolutions of feature maps
-// with at most PMOE_SKINNY_MAXROWS (default 2048) pixels per expert (closed-loop inference at B = 1: layer3 / layer4; the 14x14
+// with at most PMOE_SKINNY_MAXROWS (default 3200) pixels per expert (closed-loop inference at B = 1: layer2 .. layer4; the 14x14
 // bottleneck of the stage-1 U-Net at B = 10; beyond that the LDS-staged kernels win: measured).  On the generic implicit-GEMM kernel these are a
 // serial chain of 8..24 channel chunks on 16 workgroups (~90 us per launch: 2 TFLOP/s).  Here one workgroup owns a
 // 64-row x 64-column tile of ONE expert and its 4 waves split K between them: every wave streams its k-slices of both
@@ -176,7 +176,7 @@ bool gemm_skinny_ok(const ConvArgs& a, int dtype) {
         const char* ev = getenv("PMOE_GEMM_SKINNY");
         on = ev ? atoi(ev) : 1;
         const char* mr = getenv("PMOE_SKINNY_MAXROWS");
-        maxrows = mr ? atoi(mr) : 2048;
+        maxrows = mr ? atoi(mr) : 3200;
     }
     if (!on || dtype != PMOE_DT_BF16 || a.stats || a.dilate || a.use_tapmap || a.out_step != 1) return false;
     if ((a.ks != 1 && a.ks != 3) || a.kh != a.ks || a.kw != a.ks || (a.stride != 1 && a.stride != 2)) return false;

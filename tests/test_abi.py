@@ -84,6 +84,8 @@ def test_conv_plan_reports_the_kernel_instantiation():
     assert plan(1536, 512, 1, 1, 1, torch.bfloat16) == 3000                # expert MLP GEMM: gemm_skinny_kernel
     assert plan(1536, 512, 1, 1, 1, torch.float32) == 722                  # ... in f32: generic 4-wave tile
     assert plan(512, 512, 14, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # B=1 inference layer4: tap-looping skinny kernel
+    assert plan(128, 128, 56, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # ... layer2 (3136 pixels per expert <= 3200)
+    assert plan(128, 128, 64, 3, 1, torch.bfloat16, B=1, E=3) == 2007      # 4096 pixels per expert: LITE tile
     assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 4741   # stride-2 dgrad: 4 class launches <7,4,1>
 
 
