@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/pmoe_amd/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p ../../build
 pids=()
 for f in conv_igemm conv_res conv_wgrad gemm_skinny elementwise stem_tail heads punet stage1 optim preprocess api; do

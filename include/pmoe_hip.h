@@ -67,6 +67,13 @@ typedef struct pmoe_conv_desc {
     float drop_p;         /* >0: inverted dropout on the output (nn.Dropout, basics.py:39)         */
     uint64_t seed;
     int32_t dtype;
+    /* BASELINE config 5 (e4m3 weights on the fp8 matrix cores; forward convolutions, dtype BF16, cin % 64 == 0):
+     * w_fp8 = 1: `w` holds OCP e4m3 bytes [E][coutp][ks*ks][cin] from pmoe_pack_conv_weights_fp8; the bf16 activations
+     * are converted to e4m3(x * in_scale) on their way into LDS, the accumulators are multiplied by out_scale[e][cout]
+     * (= weight scale / in_scale) before bias / residual / activation. */
+    int32_t w_fp8;
+    float in_scale;
+    const float* out_scale;
 } pmoe_conv_desc;
 
 int pmoe_conv2d_igemm(const pmoe_conv_desc* d, void* stream);
@@ -83,7 +90,9 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
 int pmoe_conv2d_plan(const pmoe_conv_desc* d);
 
 /* Weight gradient of the same layers (autograd of nn.Conv2d / nn.Linear at the call sites above).
- * Accumulates into dw_ws [E][ks*ks][coutp][cinp] f32 with atomics: zero it first. */
+ * WRITES dw_ws [E][ks*ks][coutp][cinp] f32 (every element stored once; coutp / cinp = cout / cin rounded up to the
+ * kernel's channel tile: 64 for bf16, 32 for f32).  Deterministic: the pixel (GEMM-K) split over workgroups goes through
+ * per-workgroup slabs in `part_ws` that a second launch folds in fixed order -- no float atomics, bit-reproducible. */
 typedef struct pmoe_wgrad_desc {
     const void* x;        /* layer input  [Nin][H][W][x_ld]  */
     const void* dy;       /* output grad  [N][Ho][Wo][dy_ld] */
@@ -96,8 +105,13 @@ typedef struct pmoe_wgrad_desc {
     int32_t dtype;
     int32_t per_image;    /* 1: dw_ws is [N][ks*ks][coutp][cinp], one slab per image (used to derive the ECA
                            * gate gradient of the stem from per-image filter gradients); needs ho*wo >= 256 */
+    float* part_ws;       /* K-split scratch, pmoe_conv2d_wgrad_ws_floats() floats (may be null when that is 0) */
+    int64_t part_ws_floats;
 } pmoe_wgrad_desc;
 int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
+/* floats of part_ws the launch needs for this descriptor (0: single K slice or per_image); <0 = error.  Pointers in the
+ * descriptor are not read. */
+int64_t pmoe_conv2d_wgrad_ws_floats(const pmoe_wgrad_desc* d);
 
 /* Master weights live in the reference's own layout (one f32 OIHW / [out][in] tensor per expert,
  * state_dict keys of SURVEY.md section 8b); these repack all E experts of a layer in one launch.
@@ -108,6 +122,15 @@ int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
 int pmoe_pack_conv_weights(const void* const* src_ptrs, void* fwd, void* dgrd, int32_t E, int32_t cout,
                            int32_t cin, int32_t ks, int32_t coutp, int32_t cinp, int32_t cinp2, int32_t coutp2,
                            int32_t dtype, void* stream);
+/* BASELINE config 5: the same master weights quantised to OCP e4m3 with ONE POWER-OF-TWO scale per output channel,
+ * s = 2^ceil(log2(max|W[co]| / 448)), q = e4m3(W / s) round-to-nearest-even (the CPU statement of this policy is
+ * oracle/fp8_policy.py).  fwd_e4m3 [E][coutp][ks*ks][cinp] bytes; dgrd_bf16 [E][cinp2][ks*ks flipped][coutp2] = q * s
+ * (exact in bf16: the data gradient sees exactly the weights the forward used -- straight-through estimator);
+ * wscale / oscale [E][coutp] f32 = s and s / in_scale (pmoe_conv_desc.out_scale).  Replaces the weight operand of the
+ * nn.Conv2d call sites model/blocks/basics.py:93-100,113-120 and model/blocks/backbone.py:57-70. */
+int pmoe_pack_conv_weights_fp8(const void* const* src_ptrs, void* fwd_e4m3, void* dgrd_bf16, float* wscale, float* oscale,
+                               float in_scale, int32_t E, int32_t cout, int32_t cin, int32_t ks, int32_t coutp, int32_t cinp,
+                               int32_t cinp2, int32_t coutp2, void* stream);
 /* Inference (callers autoagents/image_agent.py:127-177, the validation loop train_2.py:245-275):
  * eval-mode BatchNorm folded into the preceding convolution, bn(conv(x, W)) = conv(x, W * s) + (beta - mean * s) with
  * s = gamma / sqrt(running_var + eps).  scale / shift / mean: [E][cout] f32 as produced by pmoe_bn_finalize(training=0);
@@ -249,7 +272,8 @@ int pmoe_pad_rows(const float* src, void* dst, int32_t B, int32_t K, int32_t Kp,
 
 /* ---- gate softmax + Gaussian-mixture head (moe.py:98-100,150-153) and moe_loss (trainer/loss.py:121-132)
  * head [E*B][head_ld] T: cols 0..1 mean, 2..3 raw std, 4 raw alpha; spd [E*B][spd_ld] T col 0.
- * probs [B][E], mean/std [B][E][2], speeds [B][E][1] f32.  alpha_relu: BaseExpert (1) vs BaseExpertAlt (0).
+ * probs [B][E], mean/std [B][E][2], speeds [B][E][1] f32.  alpha_relu: bit 0 = ReLU on alpha (BaseExpert, moe.py:100) vs none
+ * (BaseExpertAlt, moe.py:127); bit 1 = no softmax, `probs` receives alpha itself (a lone BaseExpert.forward, moe.py:74-101).
  * One 64-lane wave handles 64/G samples, G = pow2 >= E lanes per sample, xor-shuffle reductions over E.
  * shared = 1 is MixtureOfExpertsShared (moe.py:180-233): head [B][head_ld] with cols 4e..4e+3 = mean/raw std of
  * expert e and col 4E+e = its alpha (softmax without ReLU); spd [B][spd_ld] col 0; speeds is then [B][1]. */

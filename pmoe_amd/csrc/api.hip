@@ -13,6 +13,7 @@ static ConvArgs to_args(const pmoe_conv_desc* d) {
     a.ks = d->ks; a.stride = d->stride; a.pad = d->pad; a.dilate = d->dilate;
     a.act = d->act; a.res_mode = d->res ? d->res_mode : PMOE_RES_NONE;
     a.drop_p = d->drop_p; a.seed = d->seed;
+    a.oscale = d->out_scale; a.in_scale = d->in_scale; a.w_fp8 = d->w_fp8;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = 0;
     a.kh = a.kw = d->ks; a.use_tapmap = 0; a.tapmap[0] = a.tapmap[1] = a.tapmap[2] = a.tapmap[3] = 0;
     a.out_step = 1; a.out_offy = a.out_offx = 0; a.OH = d->ho; a.OW = d->wo; a.prefetch = 0; a.stagger = 0;
@@ -68,22 +69,36 @@ int pmoe_conv2d_plan(const pmoe_conv_desc* d) {
     return conv_igemm_plan(to_args(d), d->dtype);
 }
 
-int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream) {
-    if (!d || !d->x || !d->dy || !d->dw_ws || d->ipe <= 0) return PMOE_ERR_ARG;
+static int to_wgrad_args(const pmoe_wgrad_desc* d, WgradArgs& a) {
+    if (!d || d->ipe <= 0) return PMOE_ERR_ARG;
     const int ve = d->dtype == PMOE_DT_BF16 ? 8 : 4;
     if (d->x_ld % ve || d->x_coff % ve || d->dy_ld % ve || d->dy_coff % ve) return PMOE_ERR_ARG;
     if (d->x_coff + d->cin > d->x_ld || d->dy_coff + d->cout > d->dy_ld) return PMOE_ERR_ARG;
     if (d->ho != (d->h + 2 * d->pad - d->ks) / d->stride + 1) return PMOE_ERR_ARG;
     if (d->wo != (d->w_ + 2 * d->pad - d->ks) / d->stride + 1) return PMOE_ERR_ARG;
-    WgradArgs a;
-    a.x = d->x; a.dy = d->dy; a.dw = d->dw_ws;
+    a.x = d->x; a.dy = d->dy; a.dw = d->dw_ws; a.part = d->part_ws; a.part_floats = d->part_ws_floats;
     a.N = d->n; a.H = d->h; a.W = d->w_; a.Cin = d->cin; a.CinP = d->cinp;
     a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout; a.CoutP = d->coutp;
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.dy_ld = d->dy_ld; a.dy_coff = d->dy_coff;
     a.ipe = d->ipe; a.x_shared = d->x_shared;
     a.ks = d->ks; a.stride = d->stride; a.pad = d->pad; a.per_image = d->per_image;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = a.mb_per_wg = 0;
+    return 0;
+}
+
+int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream) {
+    WgradArgs a;
+    const int rc = to_wgrad_args(d, a);
+    if (rc) return rc;
+    if (!d->x || !d->dy || !d->dw_ws) return PMOE_ERR_ARG;
     return conv_wgrad_launch(a, d->dtype, (hipStream_t)stream);
+}
+
+int64_t pmoe_conv2d_wgrad_ws_floats(const pmoe_wgrad_desc* d) {
+    WgradArgs a;
+    const int rc = to_wgrad_args(d, a);
+    if (rc) return rc;
+    return conv_wgrad_ws_floats(a, d->dtype);
 }
 
 }  // extern "C"

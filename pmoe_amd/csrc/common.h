@@ -14,6 +14,28 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #include "../../include/pmoe_hip.h"   // dtype / error / activation codes shared with the C ABI
 
+// OCP e4m3 ("fp8") storage tag: conv weights quantised by pmoe_pack_conv_weights_fp8, activations converted on the way
+// into LDS (conv_common.h); gfx950's v_cvt_pk_fp8_f32 / v_mfma_*_fp8_fp8 use the OCP encoding (not MI300's fnuz).
+struct fp8 { unsigned char v; };
+#define PMOE_FP8_MAX 448.0f
+
+// 16 bf16 (two 16-byte vectors) -> 16 e4m3 bytes: x * scale, clamped to the finite e4m3 range, round to nearest even
+__device__ __forceinline__ v4i cvt16_bf16_to_fp8(const v4i& lo, const v4i& hi, float scale) {
+    v4i out;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned w0 = (unsigned)(d < 2 ? lo[2 * d] : hi[2 * d - 4]), w1 = (unsigned)(d < 2 ? lo[2 * d + 1] : hi[2 * d - 3]);
+        float f0 = __builtin_bit_cast(float, w0 << 16) * scale, f1 = __builtin_bit_cast(float, w0 & 0xffff0000u) * scale;
+        float f2 = __builtin_bit_cast(float, w1 << 16) * scale, f3 = __builtin_bit_cast(float, w1 & 0xffff0000u) * scale;
+        f0 = fminf(fmaxf(f0, -PMOE_FP8_MAX), PMOE_FP8_MAX); f1 = fminf(fmaxf(f1, -PMOE_FP8_MAX), PMOE_FP8_MAX);
+        f2 = fminf(fmaxf(f2, -PMOE_FP8_MAX), PMOE_FP8_MAX); f3 = fminf(fmaxf(f3, -PMOE_FP8_MAX), PMOE_FP8_MAX);
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(f2, f3, pk, true);
+        out[d] = pk;
+    }
+    return out;
+}
+
 template <typename T> struct VecOf;                       // 16-byte vector of T
 template <> struct VecOf<bf16> { static constexpr int N = 8; };
 template <> struct VecOf<float> { static constexpr int N = 4; };
@@ -73,6 +95,23 @@ static inline int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
     return ((1 << l) == v) ? l : -1;
+}
+
+// One-time (per device, thread-safe) opt-in of a kernel to more than 64 KiB of dynamic LDS.  The flag is a bit per device
+// ordinal: a process that drives several GPUs sets the attribute on each; two racing first calls both set it (idempotent).
+#include <atomic>
+template <auto KERNEL> static inline hipError_t ensure_dyn_lds(int bytes) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    return hipSuccess;
 }
 
 #define HIP_RET(expr)                       \

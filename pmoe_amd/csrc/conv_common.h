@@ -29,20 +29,25 @@ struct PatchGeom {
     int step;                      // source pixels per patch pixel (2 for a strided 1x1 conv: only the used pixels are staged)
 };
 
-// Stage channels [c0, c0 + RB/sizeof(T)) of the halo patch into LDS.  thread -> (16-byte chunk,
+// Stage channels [c0, c0 + RB/sizeof(TL)) of the halo patch into LDS.  thread -> (16-byte chunk,
 // pixel slot); the pixel -> (image,row,col) decode advances incrementally (no divisions in the loop).
-template <typename T, int LOG_RB, int NTHR, int MODE>
-__device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const PatchGeom& g, int c0, int tid) {
+// TL = element type of the LDS image: T itself, or fp8 (bf16 activations converted x * in_scale -> e4m3 between the global
+// load and the LDS store: a 16-byte LDS chunk then holds 16 channels = two 16-byte loads).
+template <typename T, int LOG_RB, int NTHR, int MODE, typename TL = T>
+__device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const PatchGeom& g, int c0, int tid,
+                                                float in_scale = 1.f) {
     constexpr int RB = 1 << LOG_RB, CPR = RB / 16, LOG_CPR = LOG_RB - 4;
     constexpr int PSTEP = NTHR / CPR;
-    constexpr int VE = 16 / (int)sizeof(T);
+    constexpr int VE = 16 / (int)sizeof(TL);
+    constexpr bool CVT = sizeof(TL) != sizeof(T);
+    static_assert(!CVT || (sizeof(T) == 2 && sizeof(TL) == 1), "conversion on load: bf16 -> fp8 only");
     const int pj = tid & (CPR - 1);
     int pp = tid >> LOG_CPR;
     int ix = pp % g.PW;
     const int row = pp / g.PW;
     int iy = row % g.PH, pn = row / g.PH;
     while (pp < g.NPIX) {
-        v4i v[4];
+        v4i v[4], v2[CVT ? 4 : 1];
         int dst[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -59,9 +64,12 @@ __device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const 
                     ok = ok && (unsigned)Y < (unsigned)g.H && (unsigned)X < (unsigned)g.W;
                 }
                 v[u] = v4i{0, 0, 0, 0};
+                if (CVT) v2[u] = v4i{0, 0, 0, 0};
                 if (ok) {
                     const int nin = g.shared ? (n - g.e_first_img) : n;
-                    v[u] = ldg16(in + (((size_t)nin * g.H + Y) * g.W + X) * g.ld + g.coff + c0 + pj * VE);
+                    const T* src = in + (((size_t)nin * g.H + Y) * g.W + X) * g.ld + g.coff + c0 + pj * VE;
+                    v[u] = ldg16(src);
+                    if (CVT) v2[u] = ldg16(src + 8);
                 }
                 dst[u] = pp * RB + ((pj ^ swz_chunk<LOG_RB, MODE>(pp)) << 4);
                 pp += PSTEP;
@@ -74,7 +82,10 @@ __device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (dst[u] >= 0) *reinterpret_cast<v4i*>(patch + dst[u]) = v[u];
+            if (dst[u] >= 0) {
+                if (CVT) *reinterpret_cast<v4i*>(patch + dst[u]) = cvt16_bf16_to_fp8(v[u], v2[u], in_scale);
+                else *reinterpret_cast<v4i*>(patch + dst[u]) = v[u];
+            }
     }
 }
 

@@ -35,6 +35,17 @@ template <> struct Mma<float> {
     }
 };
 
+template <> struct Mma<fp8> {
+    // 16 bytes = 16 e4m3 per lane-half: two K=16 MFMAs (bf16 rate), each takes 8 bytes of both operands.  A and B use the
+    // same byte -> k assignment, so the order of k inside the 32-channel step is immaterial.
+    static __device__ __forceinline__ void run(const v4i& a, const v4i& b, f32x16& c) {
+        typedef long l2 __attribute__((ext_vector_type(2)));
+        const l2 la = __builtin_bit_cast(l2, a), lb = __builtin_bit_cast(l2, b);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(la[0], lb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(la[1], lb[1], c, 0, 0, 0);
+    }
+};
+
 // -DPMOE_STAMP (tools/stamp_conv.py only, never the product build): per-wave cycle accounting of the main loop with
 // s_memtime (scalar registers: no VGPR cost).  The five sums land in a.stats instead of the BatchNorm partial sums.
 #ifdef PMOE_STAMP
@@ -48,13 +59,18 @@ template <> struct Mma<float> {
 // LITE: the 8-wave tile without chunk prefetch and stagger and with the epilogue staged in two halves -- few enough
 // registers (launch bound: 2 workgroups per CU) and LDS for TWO resident workgroups, whose prologues / epilogues / barriers
 // then overlap each other's MFMAs.
-template <typename T, int LOG_RB, int WM, int WN, bool LITE>
+// TL: element type of the MFMA operands in LDS (and of the packed weights in HBM): T, or fp8 -- e4m3 weights with a
+// per-output-channel scale (pmoe_pack_conv_weights_fp8), bf16 activations converted x * in_scale -> e4m3 by the patch
+// loader, v_mfma_f32_32x32x16_fp8_fp8, accumulators multiplied by a.oscale[e][cout] in the epilogue (BASELINE config 5).
+template <typename T, int LOG_RB, int WM, int WN, bool LITE, typename TL = T>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     constexpr int RB = 1 << LOG_RB, CPR = RB / 16, LOG_CPR = LOG_RB - 4;
     constexpr int NTHR = WM * WN * 64;
     constexpr int BM = WM * 64, BN = WN * 64;
-    constexpr int VE = 16 / (int)sizeof(T);
-    constexpr int CK = RB / (int)sizeof(T);
+    constexpr int VE = 16 / (int)sizeof(T);        // output elements per 16 bytes
+    constexpr int VEL = 16 / (int)sizeof(TL);      // operand elements per 16-byte LDS chunk
+    constexpr int CK = RB / (int)sizeof(TL);
+    constexpr bool F8 = sizeof(TL) != sizeof(T);
     constexpr int KSUB = RB / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -107,7 +123,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
-    const T* wbase = (const T*)a.w + ((size_t)e * a.CoutP + cout0) * TAPS * a.Cin;
+    const TL* wbase = (const TL*)a.w + ((size_t)e * a.CoutP + cout0) * TAPS * a.Cin;
     constexpr int WV = (BN * CPR + NTHR - 1) / NTHR;
     v4i wreg[WV];
     auto w_issue = [&](int c0, int tap) {
@@ -116,7 +132,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             const int v = tid + i * NTHR;
             if (v < BN * CPR) {
                 const int n = v >> LOG_CPR, j = v & (CPR - 1);
-                wreg[i] = ldg16(wbase + ((size_t)n * TAPS + tap) * a.Cin + c0 + j * VE);
+                wreg[i] = ldg16(wbase + ((size_t)n * TAPS + tap) * a.Cin + c0 + j * VEL);
             }
         }
     };
@@ -142,7 +158,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     const bool one_batch = NPIX * CPR <= MV1 * NTHR;    // every load of the patch in flight at once
     const bool big_batch = NPIX * CPR <= MV2 * NTHR;    // stride-2 halos (17x33 / 33x33 pixels)
     auto load_patch = [&](char* patch, int c0) {
-        if (LITE) {                                  // batches of 4 vectors: few registers, the other resident workgroup hides it
+        if constexpr (F8) {                          // convert on the way in (two loads per LDS chunk)
+            load_halo_patch<T, LOG_RB, NTHR, 0, TL>(patch, in, geo, c0, tid, a.in_scale);
+        } else if (LITE) {                           // batches of 4 vectors: few registers, the other resident workgroup hides it
             load_halo_patch<T, LOG_RB, NTHR, 0>(patch, in, geo, c0, tid);
         } else if (one_batch) {
             PatchStage<T, LOG_RB, NTHR, MV1> ps;
@@ -203,7 +221,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                            for (int mt = 0; mt < 2; ++mt) Mma<T>::run(paf[d][nt], pbf[d][mt], acc[nt][mt]);
+                            for (int mt = 0; mt < 2; ++mt) Mma<TL>::run(paf[d][nt], pbf[d][mt], acc[nt][mt]);
                     pend = false;
                 }
 #pragma unroll
@@ -225,7 +243,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                            for (int mt = 0; mt < 2; ++mt) Mma<T>::run(af[nt], bfr[mt], acc[nt][mt]);
+                            for (int mt = 0; mt < 2; ++mt) Mma<TL>::run(af[nt], bfr[mt], acc[nt][mt]);
                     }
                 }
                 LAP(1)                                   // fragment reads + MFMA issue of this tap
@@ -245,7 +263,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) Mma<T>::run(paf[d][nt], pbf[d][mt], acc[nt][mt]);
+                for (int mt = 0; mt < 2; ++mt) Mma<TL>::run(paf[d][nt], pbf[d][mt], acc[nt][mt]);
     }
     // ---- epilogue: D[cout][pixel] -> LDS f32 [BM / EP][BN] (16B units XOR-swizzled by pixel) ----
     constexpr int UPR = BN / 4;
@@ -260,6 +278,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     float bias[VE];
 #pragma unroll
     for (int i = 0; i < VE; ++i) bias[i] = (a.bias && cvalid) ? a.bias[(size_t)e * a.CoutP + cout + i] : 0.f;
+    float osc[F8 ? VE : 1];                          // fp8: weight scale / activation scale per output channel
+    if constexpr (F8) {
+#pragma unroll
+        for (int i = 0; i < VE; ++i) osc[i] = cvalid ? a.oscale[(size_t)e * a.CoutP + cout + i] : 0.f;
+    }
     float s1[VE], s2[VE];
 #pragma unroll
     for (int i = 0; i < VE; ++i) s1[i] = s2[i] = 0.f;
@@ -300,6 +323,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         }
         if (ok) {
             const size_t opix = ((size_t)n * a.OH + oy * a.out_step + a.out_offy) * a.OW + ox * a.out_step + a.out_offx;
+            if constexpr (F8) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] *= osc[i];
+            }
 #pragma unroll
             for (int i = 0; i < VE; ++i) v[i] += bias[i];
             if (a.res_mode) {
@@ -386,46 +413,40 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     }
 }
 
-template <typename T, int LOG_RB, int WM, int WN>
+template <typename T, int LOG_RB, int WM, int WN, typename TL = T>
 __global__ void __launch_bounds__(WM * WN * 64) conv_igemm_kernel(const ConvArgs a) {
-    conv_igemm_body<T, LOG_RB, WM, WN, false>(a);
+    conv_igemm_body<T, LOG_RB, WM, WN, false, TL>(a);
 }
 
-template <typename T, int LOG_RB>
+template <typename T, int LOG_RB, typename TL = T>
 __global__ void __launch_bounds__(512, 4) conv_igemm_lite_kernel(const ConvArgs a) {
-    conv_igemm_body<T, LOG_RB, 4, 2, true>(a);
+    conv_igemm_body<T, LOG_RB, 4, 2, true, TL>(a);
 }
 
-template <typename T, int LOG_RB>
+template <typename T, int LOG_RB, typename TL = T>
 static int launch_lite(const ConvArgs& a, int mblocks, size_t smem, hipStream_t st) {
-    auto k = conv_igemm_lite_kernel<T, LOG_RB>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    auto k = conv_igemm_lite_kernel<T, LOG_RB, TL>;
+    HIP_RET((ensure_dyn_lds<conv_igemm_lite_kernel<T, LOG_RB, TL>>(160 * 1024)));
     dim3 grid(mblocks * (a.CoutP / 128), 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL(k, grid, block, smem, st, a);
     return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int LOG_RB, int WM, int WN>
+template <typename T, int LOG_RB, int WM, int WN, typename TL = T>
 static int launch_cfg(const ConvArgs& a, int mblocks, size_t smem, hipStream_t st) {
-    auto k = conv_igemm_kernel<T, LOG_RB, WM, WN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    auto k = conv_igemm_kernel<T, LOG_RB, WM, WN, TL>;
+    HIP_RET((ensure_dyn_lds<conv_igemm_kernel<T, LOG_RB, WM, WN, TL>>(160 * 1024)));
     dim3 grid(mblocks, a.CoutP / (WN * 64), 1), block(WM * WN * 64, 1, 1);
     hipLaunchKernelGGL(k, grid, block, smem, st, a);
     return (int)hipGetLastError();
 }
 
-template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* out_mblocks, int* out_cfg = nullptr) {
-    const int esz = (int)sizeof(T);
-    if (a.Cin <= 0 || a.CoutP % 64 || a.Cout % (16 / esz) || a.Cin % (32 / esz)) return PMOE_ERR_ARG;
+template <typename T, typename TL = T> static int launch_dtype(ConvArgs a, hipStream_t st, int* out_mblocks, int* out_cfg = nullptr) {
+    const int esz = (int)sizeof(TL);                // operand element size in LDS
+    constexpr bool F8 = sizeof(TL) != sizeof(T);
+    if (a.Cin <= 0 || a.CoutP % 64 || a.Cout % (16 / (int)sizeof(T)) || a.Cin % (32 / esz)) return PMOE_ERR_ARG;
+    if (F8 && (!a.oscale || a.Cin % 64 || !(a.in_scale > 0.f))) return PMOE_ERR_ARG;
     if ((a.ks != 1 && a.ks != 3) || (a.stride != 1 && a.stride != 2) || (a.dilate && a.stride != 1)) return PMOE_ERR_ARG;
     if (a.N % a.ipe) return PMOE_ERR_ARG;
     const int E = a.N / a.ipe;
@@ -435,12 +456,13 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
     static int cfg42 = -1;      // PMOE_CONV_CFG42=0 switches back to the 4-wave tile (A/B measurements)
     if (cfg42 < 0) { const char* ev = getenv("PMOE_CONV_CFG42"); cfg42 = ev ? atoi(ev) : 1; }
     const bool big = wide && cfg42 && sizeof(T) == 2 && (long long)a.ipe * a.Ho * a.Wo >= 4096;   // not the MLP GEMMs
+    const int log_rb_min = F8 ? 6 : 5;              // fp8: 64 or 128 channels per chunk
     // (measured on the stage-1 U-Net at B = 10, where the 28x28 / 14x14 layers give < 256 workgroups: falling back to the
     // 128-pixel 4-wave tile to double the workgroup count is SLOWER, 41.9 vs 32.3 ms of conv time per step)
     const int BM = wide ? (big ? 256 : 128) : 256, BN = wide ? 128 : 64;
     auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     // candidate chunk widths (bytes per pixel row in LDS), widest first
-    for (int log_rb = 7; log_rb >= 5; --log_rb) {
+    for (int log_rb = 7; log_rb >= log_rb_min; --log_rb) {
         const int rb = 1 << log_rb, ck = rb / esz;
         if (a.Cin % ck) continue;
         int lTW = p2(a.Wo); if (lTW > 5) lTW = 5;
@@ -468,7 +490,7 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         static int pf_on = -1;      // PMOE_CONV_PREFETCH=0: A/B switch
         if (pf_on < 0) { const char* ev = getenv("PMOE_CONV_PREFETCH"); pf_on = ev ? atoi(ev) : 1; }
         // (also the expert MLP GEMMs: 1x1 "images", K = 512..1536 in 64-channel chunks -- a latency chain of 8..24 chunks)
-        a.prefetch = !lite && pf_on && (big || (a.H == 1 && a.W == 1 && a.ks == 1)) && a.Cin / ck >= 2 && (size_t)TN * PH * PW * (rb / 16) <= (size_t)6 * nthr &&
+        a.prefetch = !F8 && !lite && pf_on && (big || (a.H == 1 && a.W == 1 && a.ks == 1)) && a.Cin / ck >= 2 && (size_t)TN * PH * PW * (rb / 16) <= (size_t)6 * nthr &&
                      2 * pbytes + 2 * (size_t)BN * rb <= 150 * 1024;
         size_t smem = pbytes * (a.prefetch ? 2 : 1) + 2 * (size_t)BN * rb;
         const size_t stg = (size_t)BM * BN * 4 / (lite ? 2 : 1);
@@ -479,8 +501,15 @@ template <typename T> static int launch_dtype(ConvArgs a, hipStream_t st, int* o
         a.tiles_y = (a.Ho + TH - 1) / TH;
         a.tiles_x = (a.Wo + TW - 1) / TW;
         const int mblocks = E * a.n_groups * a.tiles_y * a.tiles_x;
-        if (out_cfg) *out_cfg = lite ? 2000 + log_rb : log_rb * 100 + (wide ? (big ? 42 : 22) : 41);   // see conv_igemm_plan
+        if (out_cfg) *out_cfg = (F8 ? 8000 : 0) + (lite ? 2000 + log_rb : log_rb * 100 + (wide ? (big ? 42 : 22) : 41));   // see conv_igemm_plan
         if (out_mblocks) { *out_mblocks = mblocks; return 0; }
+        if constexpr (F8) {
+            if (lite) return launch_lite<T, 7, TL>(a, mblocks, smem, st);
+            if (log_rb == 7 && big) return launch_cfg<T, 7, 4, 2, TL>(a, mblocks, smem, st);
+            if (log_rb == 6 && big) return launch_cfg<T, 6, 4, 2, TL>(a, mblocks, smem, st);
+            if (log_rb == 7) return wide ? launch_cfg<T, 7, 2, 2, TL>(a, mblocks, smem, st) : launch_cfg<T, 7, 4, 1, TL>(a, mblocks, smem, st);
+            return wide ? launch_cfg<T, 6, 2, 2, TL>(a, mblocks, smem, st) : launch_cfg<T, 6, 4, 1, TL>(a, mblocks, smem, st);
+        }
         if (lite) return launch_lite<T, 7>(a, mblocks, smem, st);
         if (log_rb == 7 && big) return launch_cfg<T, 7, 4, 2>(a, mblocks, smem, st);
         if (log_rb == 6 && big) return launch_cfg<T, 6, 4, 2>(a, mblocks, smem, st);
@@ -539,6 +568,10 @@ static int launch_stride2_1x1_inplace(const ConvArgs& a, int dtype, hipStream_t 
 }
 
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
+    if (a.w_fp8) {                                   // e4m3 weights: forward convs on the halo-patch kernels only
+        if (dtype != PMOE_DT_BF16 || a.dilate) return PMOE_ERR_ARG;
+        return launch_dtype<bf16, fp8>(a, st, nullptr);
+    }
     if (a.dilate && a.ks == 3 && a.pad == 1 && a.kh == 3) return launch_stride2_dgrad(a, dtype, st);
     if (a.dilate && a.ks == 1 && a.pad == 0 && a.res_mode == PMOE_RES_ADD && a.res == a.out && a.res_ld == a.out_ld &&
         a.res_coff == a.out_coff && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f)
@@ -557,6 +590,11 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
 int conv_igemm_plan(const ConvArgs& a, int dtype) {
     ConvArgs c = a;
     int extra = 0;
+    if (a.w_fp8) {                                   // 8000 + the bf16 code of the same tile
+        int mb = 0, cfg = 0;
+        const int rc = dtype == PMOE_DT_BF16 && !a.dilate ? launch_dtype<bf16, fp8>(c, nullptr, &mb, &cfg) : PMOE_ERR_ARG;
+        return rc ? rc : cfg;
+    }
     if (gemm_skinny_ok(a, dtype)) return 3000;           // gemm_skinny_kernel
     if (a.dilate && a.ks == 3 && a.pad == 1 && a.kh == 3) {
         c.dilate = 0; c.stride = 1; c.pad = 0; c.kh = c.kw = 2;
@@ -574,6 +612,11 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
 }
 
 int conv_igemm_mblocks(const ConvArgs& a, int dtype) {
+    if (a.w_fp8) {
+        int mb = 0;
+        const int rc = dtype == PMOE_DT_BF16 ? launch_dtype<bf16, fp8>(a, nullptr, &mb) : PMOE_ERR_ARG;
+        return rc ? rc : mb;
+    }
     ResPlan plan;
     if (conv_res_plan(a, dtype, &plan)) return (a.N / a.ipe) * plan.wgs_per_expert;
     int mb = 0;

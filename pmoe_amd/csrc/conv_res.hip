@@ -327,29 +327,16 @@ int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
     const int E = a.N / a.ipe;
     const int region = (int)((p.smem - (size_t)9 * 64 * (1 << p.log_rb)) / 2);
     dim3 grid(p.wgs_per_expert, E), block(512);
-    static bool attr7 = false, attr5 = false, attr7b = false;
     if (p.log_rb == 7 && a.bias) {
-        if (!attr7b) {
-            HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_res_kernel<7, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-            attr7b = true;
-        }
+        HIP_RET((ensure_dyn_lds<conv3x3_res_kernel<7, true>>(163840)));
         hipLaunchKernelGGL((conv3x3_res_kernel<7, true>), grid, block, p.smem + 256, st, a, p.tiles_per_expert,
                            p.wgs_per_expert, region);
     } else if (p.log_rb == 7) {
-        if (!attr7) {
-            HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_res_kernel<7>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-            attr7 = true;
-        }
-        hipLaunchKernelGGL(conv3x3_res_kernel<7>, grid, block, p.smem, st, a, p.tiles_per_expert, p.wgs_per_expert, region);
+        HIP_RET((ensure_dyn_lds<conv3x3_res_kernel<7, false>>(163840)));
+        hipLaunchKernelGGL((conv3x3_res_kernel<7, false>), grid, block, p.smem, st, a, p.tiles_per_expert, p.wgs_per_expert, region);
     } else {
-        if (!attr5) {
-            HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_res_kernel<5>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-            attr5 = true;
-        }
-        hipLaunchKernelGGL(conv3x3_res_kernel<5>, grid, block, p.smem, st, a, p.tiles_per_expert, p.wgs_per_expert, region);
+        HIP_RET((ensure_dyn_lds<conv3x3_res_kernel<5, false>>(163840)));
+        hipLaunchKernelGGL((conv3x3_res_kernel<5, false>), grid, block, p.smem, st, a, p.tiles_per_expert, p.wgs_per_expert, region);
     }
     return (int)hipGetLastError();
 }

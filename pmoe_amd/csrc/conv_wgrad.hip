@@ -9,8 +9,10 @@
 // scalar ds_read_b32 (the f32 MFMA takes one element per lane).  One dY fragment is reused for all
 // ks*ks taps, so each tap costs one transposed X read per MFMA.  Every wave keeps its
 // [32 cout][32 cin] x taps accumulators in registers across ALL the m-blocks the workgroup walks
-// (K-split over gridDim.x), and flushes once with f32 atomics whose lanes run along cin
-// (2 x 128-byte segments per wave-instruction: the full-rate shape).
+// (K-split over gridDim.x) and flushes ONCE, deterministically: the waves that split the pixels of one output tile
+// are summed through LDS in fixed order, the workgroup stores its tile with plain stores (lanes along cin: 2 x 128-byte
+// segments per wave-instruction) into its own slab of a partial workspace, and `wgrad_reduce_kernel` folds the K-split
+// slabs in fixed order.  No float atomics anywhere: weight gradients are bit-reproducible run to run.
 //
 // Pipeline (one workgroup per CU, one wave per SIMD, the whole 512-register file): the global loads
 // of m-block i+1 (dY tile + X halo patch, up to 28 x 16 B per lane) are issued into registers
@@ -181,38 +183,86 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
         }
     }
 
-    // flush: D[row = cout][col = cin]; lanes run along cin -> contiguous 128-byte atomic segments
+    // flush: D[row = cout][col = cin]; lanes run along cin -> contiguous 128-byte segments.  The WK waves that share
+    // an output tile meet in LDS (TPR taps per round: the operand tiles are dead by now), wave k_sub 0 adds the others'
+    // tiles in fixed order and stores.  Destination: the workgroup's own K-split slab (or dw itself when there is no split).
+    constexpr int TPR = TAPS == 9 ? 3 : 1;
+    constexpr int TILE_WAVES = WCO * WCI;
+    float* red = reinterpret_cast<float*>(smem);
+    const int tw = wave % TILE_WAVES;
     const int cin = ci0 + ci_sub * 32 + l31;
+    const size_t slab = a.per_image ? (size_t)e * a.ipe + blockIdx.x          // per image
+                                    : (size_t)blockIdx.x * gridDim.z + e;       // per (K-split, expert); split 0 = dw itself
+    float* dst = (a.per_image || gridDim.x == 1) ? a.dw : a.part;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-        const size_t slab = a.per_image ? (size_t)e * a.ipe + blockIdx.x : (size_t)e;      // per image / per expert
-        float* base = a.dw + ((slab * TAPS + tap) * a.CoutP) * a.CinP;
+    for (int t0 = 0; t0 < TAPS; t0 += TPR) {
+        __syncthreads();
+        if (k_sub > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cout = co0 + co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            atomicAdd(base + (size_t)cout * a.CinP + cin, acc[tap][r]);
+            for (int tp = 0; tp < TPR; ++tp)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[((((k_sub - 1) * TPR + tp) * TILE_WAVES + tw) * 16 + r) * 64 + lane] = acc[t0 + tp][r];
+        }
+        __syncthreads();
+        if (k_sub == 0) {
+#pragma unroll
+            for (int tp = 0; tp < TPR; ++tp) {
+                float* base = dst + ((slab * TAPS + t0 + tp) * a.CoutP) * a.CinP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[t0 + tp][r];
+#pragma unroll
+                    for (int k = 1; k < WK; ++k) v += red[((((k - 1) * TPR + tp) * TILE_WAVES + tw) * 16 + r) * 64 + lane];
+                    const int cout = co0 + co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    base[(size_t)cout * a.CinP + cin] = v;
+                }
+            }
         }
     }
 }
 
-template <typename T, int TAPS, int MAXV> static int launch_wg(const WgradArgs& a, int E, size_t smem, hipStream_t st) {
-    auto k = conv_wgrad_kernel<T, TAPS, MAXV>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+// dw[i] = sum over the K-split slabs, fixed order (slab s at part + s * total)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           const int nsplit, const long long total4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(part);
+    f32x4 s = p[i];
+    for (int k = 1; k < nsplit; ++k) {
+        const f32x4 v = p[(long long)k * total4 + i];
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
-    constexpr int CKW = 128 / (int)sizeof(T);
-    const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
-    dim3 grid((mbpe + a.mb_per_wg - 1) / a.mb_per_wg, ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW), E), block(WgradCfg<T>::NW * 64, 1, 1);
-    hipLaunchKernelGGL(k, grid, block, smem, st, a);
-    return (int)hipGetLastError();
+    reinterpret_cast<f32x4*>(dw)[i] = s;
 }
 
-template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st) {
+template <typename T, int TAPS, int MAXV> static int launch_wg(const WgradArgs& a, int E, size_t smem, hipStream_t st) {
+    HIP_RET((ensure_dyn_lds<conv_wgrad_kernel<T, TAPS, MAXV>>(160 * 1024)));
+    constexpr int CKW = 128 / (int)sizeof(T);
+    const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
+    const int nsplit = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
+    dim3 grid(nsplit, ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW), E), block(WgradCfg<T>::NW * 64, 1, 1);
+    // room for the in-workgroup fold of the pixel-split waves: (WK-1) x TPR taps x tile waves x 4 KiB
+    constexpr size_t fold = (size_t)(WgradCfg<T>::WK - 1) * (TAPS == 9 ? 3 : 1) * WgradCfg<T>::WCO * WgradCfg<T>::WCI * 4096;
+    if (smem < fold) smem = fold;
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, TAPS, MAXV>), grid, block, smem, st, a);
+    HIP_RET(hipGetLastError());
+    if (!a.per_image && nsplit > 1) {
+        const long long total4 = (long long)E * TAPS * a.CoutP * a.CinP / 4;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a.part, a.dw, nsplit,
+                           total4);
+        HIP_RET(hipGetLastError());
+    }
+    return 0;
+}
+
+// plan == true: nothing is launched, *ws_floats receives the size of the K-split workspace the launch needs (0: none)
+template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool plan, long long* ws_floats) {
     constexpr int CKW = 128 / (int)sizeof(T);
     constexpr int VEh = 16 / (int)sizeof(T);
-    if (a.Cin % VEh || a.Cout % VEh || a.CinP % CKW || a.CoutP % CKW || a.CinP < a.Cin || a.CoutP < a.Cout) return PMOE_ERR_ARG;
+    if (a.Cin % VEh || a.Cout % VEh || a.CinP < a.Cin || a.CoutP < a.Cout) return PMOE_ERR_ARG;
+    // the workgroup tiles must cover dw exactly (every element is WRITTEN, nothing is accumulated onto old contents)
+    if (a.CinP != (a.Cin + CKW - 1) / CKW * CKW || a.CoutP != (a.Cout + CKW - 1) / CKW * CKW) return PMOE_ERR_ARG;
     if ((a.ks != 1 && a.ks != 3) || (a.stride != 1 && a.stride != 2) || a.N % a.ipe) return PMOE_ERR_ARG;
     const int E = a.N / a.ipe;
     auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
@@ -251,6 +301,10 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st) {
             if (TN != 1) return PMOE_ERR_UNSUPPORTED;
             a.mb_per_wg = a.tiles_y * a.tiles_x;
         }
+        const int nsplit = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
+        const long long ws = (a.per_image || nsplit == 1) ? 0 : (long long)nsplit * E * a.ks * a.ks * a.CoutP * a.CinP;
+        if (plan) { *ws_floats = ws; return 0; }
+        if (ws > 0 && (!a.part || a.part_floats < ws)) return PMOE_ERR_ARG;
         if (need <= M1) return a.ks == 3 ? launch_wg<T, 9, M1>(a, E, smem, st) : launch_wg<T, 1, M1>(a, E, smem, st);
         return a.ks == 3 ? launch_wg<T, 9, M2>(a, E, smem, st) : launch_wg<T, 1, M2>(a, E, smem, st);
     }
@@ -258,7 +312,15 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st) {
 }
 
 int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
-    if (dtype == PMOE_DT_BF16) return wgrad_dtype<bf16>(a, st);
-    if (dtype == PMOE_DT_F32) return wgrad_dtype<float>(a, st);
+    long long ws = 0;
+    if (dtype == PMOE_DT_BF16) return wgrad_dtype<bf16>(a, st, false, &ws);
+    if (dtype == PMOE_DT_F32) return wgrad_dtype<float>(a, st, false, &ws);
     return PMOE_ERR_ARG;
+}
+
+long long conv_wgrad_ws_floats(const WgradArgs& a, int dtype) {
+    long long ws = 0;
+    const int rc = dtype == PMOE_DT_BF16 ? wgrad_dtype<bf16>(a, nullptr, true, &ws)
+                 : dtype == PMOE_DT_F32 ? wgrad_dtype<float>(a, nullptr, true, &ws) : PMOE_ERR_ARG;
+    return rc ? rc : ws;
 }

@@ -189,12 +189,8 @@ bool gemm_skinny_ok(const ConvArgs& a, int dtype) {
 }
 
 template <int NW> static int skinny_launch_nw(const ConvArgs& a, const dim3& grid, hipStream_t st) {
-    static bool attr_set = false;
     const int smem = NREG * BM * BN * (int)sizeof(float);
-    if (!attr_set) {
-        HIP_RET(hipFuncSetAttribute((const void*)gemm_skinny_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    HIP_RET((ensure_dyn_lds<gemm_skinny_kernel<NW>>(smem)));
     hipLaunchKernelGGL(gemm_skinny_kernel<NW>, grid, dim3(NW * 64), smem, st, a);
     return (int)hipGetLastError();
 }

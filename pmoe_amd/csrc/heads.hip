@@ -90,6 +90,82 @@ __global__ void __launch_bounds__(256) pack_w_scaled_kernel(const float* const* 
         bias[e * coutp + co] = co < cout ? shift[e * cout + co] - mean[e * cout + co] * scale[e * cout + co] : 0.f;
 }
 
+// ---- BASELINE config 5: e4m3 weights with one power-of-two scale per output channel --------------------------------
+// s[e][co] = 2^ceil(log2(amax_co / 448)) (1 if the row is all zero), q = e4m3(W / s) (round to nearest even, clamped to the
+// finite range): power-of-two scales make W / s and q * s exact, so the data-gradient operand (bf16) holds exactly the
+// dequantised weights the forward used.  wscale[e][co] = s; oscale[e][co] = s / in_scale (the conv epilogue's factor).
+__global__ void __launch_bounds__(256) fp8_row_scale_kernel(const float* const* __restrict__ src, float* __restrict__ wscale,
+                                                           float* __restrict__ oscale, float in_scale, int cout, int coutp,
+                                                           int row) {
+    const int co = blockIdx.x, e = blockIdx.y;
+    __shared__ float red[256];
+    float m = 0.f;
+    if (co < cout) {
+        const float* s = src[e] + (size_t)co * row;
+        for (int i = threadIdx.x; i < row; i += 256) m = fmaxf(m, fabsf(s[i]));
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float sc = 1.f;
+        if (red[0] > 0.f) {
+            int ex;
+            const float mant = frexpf(red[0] / PMOE_FP8_MAX, &ex);      // amax / 448 = mant * 2^ex, mant in [0.5, 1)
+            if (mant == 0.5f) ex -= 1;                                   // exact power of two: ceil(log2) = ex - 1
+            sc = ldexpf(1.f, ex);
+        }
+        wscale[e * coutp + co] = sc;
+        oscale[e * coutp + co] = sc / in_scale;
+    }
+}
+
+__device__ __forceinline__ unsigned char to_e4m3(float v) {
+    v = fminf(fmaxf(v, -PMOE_FP8_MAX), PMOE_FP8_MAX);
+    return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
+}
+
+// decode one OCP e4m3 byte (bias 7, no infinities; S.1111.111 = NaN does not occur: inputs are clamped)
+__device__ __forceinline__ float from_e4m3(unsigned char b) {
+    const int ex = (b >> 3) & 15, mt = b & 7;
+    const float mag = ex ? ldexpf((float)(8 + mt), ex - 10) : ldexpf((float)mt, -9);
+    return (b & 0x80) ? -mag : mag;
+}
+
+__global__ void __launch_bounds__(256) pack_w_fp8_kernel(const float* const* __restrict__ src, const float* __restrict__ wscale,
+                                                        unsigned char* __restrict__ fwd, bf16* __restrict__ dgrd, int cout, int cin,
+                                                        int taps, int coutp, int cinp, int cinp2, int coutp2) {
+    const int e = blockIdx.y;
+    const float* s = src[e];
+    const long long nf = fwd ? (long long)coutp * taps * cinp : 0;
+    const long long nd = dgrd ? (long long)cinp2 * taps * coutp2 : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nf + nd; i += (long long)gridDim.x * 256) {
+        if (i < nf) {
+            const int ci = (int)(i % cinp);
+            long long t = i / cinp;
+            const int tp = (int)(t % taps);
+            const int co = (int)(t / taps);
+            const float v = (co < cout && ci < cin) ? s[((size_t)co * cin + ci) * taps + tp] / wscale[e * coutp + co] : 0.f;
+            fwd[(size_t)e * nf + i] = to_e4m3(v);
+        } else {
+            const long long k = i - nf;
+            const int co = (int)(k % coutp2);
+            long long t = k / coutp2;
+            const int tp = (int)(t % taps);
+            const int ci = (int)(t / taps);
+            float v = 0.f;
+            if (co < cout && ci < cin) {
+                const float sc = wscale[e * coutp + co];
+                v = from_e4m3(to_e4m3(s[((size_t)co * cin + ci) * taps + (taps - 1 - tp)] / sc)) * sc;
+            }
+            dgrd[(size_t)e * nd + k] = (bf16)v;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ g, int cout,
                                                           int cin, int taps, int coutp, int cinp) {
     const int e = blockIdx.y;
@@ -145,7 +221,8 @@ __global__ void __launch_bounds__(256) gate_fwd_kernel(const T* __restrict__ hea
         hv[4] = to_f32(head[ix.alpha(b, e)]);
         sp = to_f32(spd[(shared ? (size_t)b : (size_t)e * B + b) * spd_ld]);
     }
-    float a = alpha_relu ? fmaxf(hv[4], 0.f) : hv[4];
+    const bool raw = alpha_relu & 2;        // lone expert (moe.py:74-101): alpha itself, no softmax over the group
+    float a = (alpha_relu & 1) ? fmaxf(hv[4], 0.f) : hv[4];
     if (!live) a = -INFINITY;
     float m = a;
     for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -154,7 +231,7 @@ __global__ void __launch_bounds__(256) gate_fwd_kernel(const T* __restrict__ hea
     for (int off = 1; off < G; off <<= 1) s += __shfl_xor(s, off);
     if (live) {
         const size_t o = (size_t)b * E + e;
-        probs[o] = ex / s;
+        probs[o] = raw ? a : ex / s;
         mean[o * 2 + 0] = hv[0];
         mean[o * 2 + 1] = hv[1];
         sd[o * 2 + 0] = (hv[2] > 0.f ? hv[2] : expm1f(hv[2])) + 1.f;
@@ -186,8 +263,8 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const T* __restrict__ hea
         const size_t o = (size_t)b * E + e;
         const float r2 = to_f32(head[ix.comp(b, e, 2)]), r3 = to_f32(head[ix.comp(b, e, 3)]);
         const float r4 = to_f32(head[ix.alpha(b, e)]);
-        float da = p * (dp - dot);
-        if (alpha_relu && !(r4 > 0.f)) da = 0.f;
+        float da = (alpha_relu & 2) ? dp : p * (dp - dot);
+        if ((alpha_relu & 1) && !(r4 > 0.f)) da = 0.f;
         dhead[ix.comp(b, e, 0)] = from_f32<T>(dmean ? dmean[o * 2 + 0] : 0.f);
         dhead[ix.comp(b, e, 1)] = from_f32<T>(dmean ? dmean[o * 2 + 1] : 0.f);
         dhead[ix.comp(b, e, 2)] = from_f32<T>(dstd ? dstd[o * 2 + 0] * (r2 > 0.f ? 1.f : expf(r2)) : 0.f);
@@ -344,6 +421,24 @@ __global__ void __launch_bounds__(256) eca_stem_fold_ds_kernel(const float* __re
 static inline int pow2ceil(int v) { int g = 1; while (g < v) g <<= 1; return g; }
 
 extern "C" {
+
+int pmoe_pack_conv_weights_fp8(const void* const* src_ptrs, void* fwd_e4m3, void* dgrd_bf16, float* wscale, float* oscale,
+                               float in_scale, int32_t E, int32_t cout, int32_t cin, int32_t ks, int32_t coutp, int32_t cinp,
+                               int32_t cinp2, int32_t coutp2, void* stream) {
+    if (!src_ptrs || !wscale || !oscale || !(in_scale > 0.f)) return PMOE_ERR_ARG;
+    if (coutp < cout || cinp < cin || (dgrd_bf16 && (cinp2 < cin || coutp2 < cout))) return PMOE_ERR_ARG;
+    const int taps = ks * ks;
+    hipLaunchKernelGGL(fp8_row_scale_kernel, dim3(coutp, E), dim3(256), 0, (hipStream_t)stream,
+                       (const float* const*)src_ptrs, wscale, oscale, in_scale, cout, coutp, cin * taps);
+    const long long n = (fwd_e4m3 ? (long long)coutp * taps * cinp : 0) + (dgrd_bf16 ? (long long)cinp2 * taps * coutp2 : 0);
+    long long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (n > 0)
+        hipLaunchKernelGGL(pack_w_fp8_kernel, dim3((int)g, E), dim3(256), 0, (hipStream_t)stream,
+                           (const float* const*)src_ptrs, wscale, (unsigned char*)fwd_e4m3, (bf16*)dgrd_bf16, cout, cin, taps,
+                           coutp, cinp, cinp2, coutp2);
+    return (int)hipGetLastError();
+}
 
 int pmoe_pack_conv_weights(const void* const* src_ptrs, void* fwd, void* dgrd, int32_t E, int32_t cout, int32_t cin,
                            int32_t ks, int32_t coutp, int32_t cinp, int32_t cinp2, int32_t coutp2, int32_t dtype,

@@ -11,6 +11,9 @@ struct ConvArgs {
     const void* res;       // residual / saved activation, geometry of `out` with its own ld/coff
     const float* bias;     // [E][CoutP] f32 or null
     float* stats;          // [mblocks][2][CoutP] f32 partial (sum, sum of squares) or null
+    const float* oscale;   // w_fp8: [E][CoutP] f32, accumulator scale = weight scale / in_scale
+    float in_scale;        // w_fp8: activations are stored in LDS as e4m3(x * in_scale)
+    int w_fp8;             // 1: `w` holds e4m3 bytes [E][CoutP][ks*ks][Cin]
     int N, H, W, Cin;
     int Ho, Wo, Cout, CoutP;
     int in_ld, in_coff, out_ld, out_coff, res_ld, res_coff;
@@ -34,7 +37,9 @@ struct ConvArgs {
 struct WgradArgs {
     const void* x;         // conv input  [Nin][H][W][x_ld] T
     const void* dy;        // output grad [N][Ho][Wo][dy_ld] T
-    float* dw;             // [E][taps][CoutP][CinP] f32, accumulated with atomics (must be zeroed)
+    float* dw;             // [E][taps][CoutP][CinP] f32, overwritten (every element is stored once; no atomics)
+    float* part;           // K-split partial slabs [nsplit][E][taps][CoutP][CinP] f32 (conv_wgrad_ws_floats; may be null if 0)
+    long long part_floats;
     int N, H, W, Cin, CinP;      // Cin: multiple of the channel chunk; CinP: row length of dw
     int Ho, Wo, Cout, CoutP;     // Cout: multiple of the channel chunk actually reduced
     int x_ld, x_coff, dy_ld, dy_coff;
@@ -53,3 +58,4 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st);
 int conv_igemm_mblocks(const ConvArgs& a, int dtype);
 int conv_igemm_plan(const ConvArgs& a, int dtype);
 int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);
+long long conv_wgrad_ws_floats(const WgradArgs& a, int dtype);

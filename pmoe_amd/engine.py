@@ -140,6 +140,7 @@ class ExpertGroupEngine:
         self.fold_bn_eval = True      # inference: eval-mode BatchNorm folded into the conv weights / epilogue
         self.pooled_stem_bwd = True   # stem-tail BatchNorm reductions from the pooled tensors (train mode)
         self.fold_eca_gate = True     # ECA gate folded into per-image conv weights (no gated activation in memory)
+        self.raw_alpha = False        # lone BaseExpert.forward: the gate kernel returns alpha itself instead of softmax(alpha)
         self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tests/experiments/probe_layers.py)
         self._collect()
 
@@ -407,8 +408,7 @@ class ExpertGroupEngine:
         ckw = 64 if self.dtype == torch.bfloat16 else 32
         cpw = (layer.cinp + ckw - 1) // ckw * ckw
         cow = (layer.cout_st + ckw - 1) // ckw * ckw
-        ws = self._wgrad_ws(E * layer.taps * cow * cpw)
-        ws.zero_()
+        ws = self._wgrad_ws(E * layer.taps * cow * cpw)      # overwritten by the launch (no atomics, nothing to zero)
         ops.set_meta(flop=flop, name=layer.name)
         ops.conv2d_wgrad(x.t, dy, ws, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B,
                          ks=layer.ks, stride=layer.stride, pad=layer.pad, x_shared=in_shared, x_coff=x.coff,
@@ -741,7 +741,6 @@ class ExpertGroupEngine:
                 cpw = (layer.cinp + ckw - 1) // ckw * ckw
                 cow = (layer.cout_st + ckw - 1) // ckw * ckw
                 G = self._wgrad_ws(N * layer.taps * cow * cpw, main=True)
-                G.zero_()
                 ops.set_meta(flop=flop, name=layer.name)
                 ops.conv2d_wgrad(x.t, dy, G, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=B_, ks=layer.ks,
                                  stride=layer.stride, pad=layer.pad, per_image=True)
@@ -962,11 +961,16 @@ class ExpertGroupEngine:
         speeds = torch.empty((Bsz, 1) if self.shared else (Bsz, K, 1), dtype=F32, device=self.dev)
         # BaseExpert applies ReLU to alpha (moe.py:97); BaseExpertAlt (moe.py:126) and the shared head (moe.py:226) do not
         ops.gate_mixture_fwd(head5.t.view(self.N, -1), sp.t.view(self.N, 16), probs, mean, std, speeds, Bsz, K,
-                             not self.alt and not self.shared, self.shared)
+                             self._alpha_mode(), self.shared)
         self._bump_batch_counters()
         state = dict(tape=self.tape, tail=(head5, sp, probs), B=self.B, N=self.N, dev=self.dev, dtype=self.dtype)
         self.tape = None
         return probs, mean, std, speeds, state
+
+    def _alpha_mode(self):
+        # bit 0: BaseExpert applies ReLU to alpha (moe.py:97); BaseExpertAlt (moe.py:126) and the shared head (moe.py:226)
+        # do not.  bit 1: lone expert, no softmax (pmoe_gate_mixture_fwd)
+        return int(not self.alt and not self.shared) | (2 if self.raw_alpha else 0)
 
     def _measurement_inputs(self, speed, command):
         Bsz = self.B
@@ -989,6 +993,11 @@ class ExpertGroupEngine:
         tensors = [m.num_batches_tracked for k, l in layers.items() for m in l.mods]
         steps = [count[k] for k, l in layers.items() for _ in l.mods]
         torch._foreach_add_(tensors, steps)
+        # bn_finalize updated the running statistics through raw pointers: bump their version counters so that every
+        # cache keyed on them (the eval-mode BatchNorm fold of _conv_bn) sees the change, as nn.BatchNorm2d's own
+        # in-place update would have made visible
+        torch.autograd.graph.increment_version([b for l in layers.values() for m in l.mods
+                                                for b in (m.running_mean, m.running_var)])
 
     def _image_input(self, images):
         """[B,T,C,H,W] f32 -> NHWC [B,H,W,r16(T*C)] in the compute dtype (frames concatenated along channels, moe.py:90-92)."""
@@ -1016,7 +1025,6 @@ class ExpertGroupEngine:
         cpw = (layer.cinp + ckw - 1) // ckw * ckw
         cow = (layer.cout_st + ckw - 1) // ckw * ckw
         G = self._wgrad_ws(self.N * layer.taps * cow * cpw, main=True)
-        G.zero_()
         ops.set_meta(flop=2.0 * self.N * dy.shape[1] * dy.shape[2] * layer.cout * layer.cin * layer.taps, name=layer.name)
         ops.conv2d_wgrad(x0.t, dy, G, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B, ks=layer.ks,
                          stride=1, pad=layer.pad, x_shared=True, per_image=True)
@@ -1057,7 +1065,7 @@ class ExpertGroupEngine:
             return t.contiguous().float() if t is not None else None
         ops.gate_mixture_bwd(head5.t.view(self.N, -1), probs, c(dprobs), c(dmean), c(dstd), c(dspeeds),
                              dhead.view(self.N, -1), dspd.view(self.N, 16), self.B, self.K,
-                             not self.alt and not self.shared, self.shared)
+                             self._alpha_mode(), self.shared)
         if dprobs is not None or dmean is not None or dstd is not None:
             head5.set_grad(dhead)
         if dspeeds is not None:

@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("ks", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dilate", C.c_int32),
         ("act", C.c_int32), ("res_mode", C.c_int32),
         ("drop_p", C.c_float), ("seed", C.c_uint64), ("dtype", C.c_int32),
+        ("w_fp8", C.c_int32), ("in_scale", C.c_float), ("out_scale", C.c_void_p),
     ]
 
 
@@ -50,6 +51,7 @@ class WgradDesc(C.Structure):
         ("ipe", C.c_int32), ("x_shared", C.c_int32),
         ("ks", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dtype", C.c_int32),
         ("per_image", C.c_int32),
+        ("part_ws", C.c_void_p), ("part_ws_floats", C.c_int64),
     ]
 
 
@@ -64,7 +66,9 @@ SIGNATURES = {
     "pmoe_conv2d_stat_rows": [C.POINTER(ConvDesc)],
     "pmoe_conv2d_plan": [C.POINTER(ConvDesc)],
     "pmoe_conv2d_wgrad": [C.POINTER(WgradDesc), _P],
+    "pmoe_conv2d_wgrad_ws_floats": [C.POINTER(WgradDesc)],
     "pmoe_pack_conv_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_pack_conv_weights_fp8": [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights_scaled": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights_gated": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_unpack_conv_wgrad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -120,7 +124,7 @@ SIGNATURES = {
     "pmoe_mt_adam": [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P, _P],
     "pmoe_mt_swa_update": [_P, _P, _P, _I, _L, _P],
 }
-_RESTYPES = {"pmoe_error_string": C.c_char_p}
+_RESTYPES = {"pmoe_error_string": C.c_char_p, "pmoe_conv2d_wgrad_ws_floats": C.c_int64}
 
 
 def lib_path():

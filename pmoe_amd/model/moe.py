@@ -137,12 +137,17 @@ class BaseExpert(_Grouped):
     def _alt(self):
         return False
 
+    def _make_engine(self):
+        eng = super()._make_engine()
+        eng.raw_alpha = True        # a lone expert has no group to normalise over: the gate kernel hands back alpha itself
+        return eng
+
     def forward(self, images, speed, command):
-        """-> alpha [B,1], mean [B,2], std [B,2], pred_speed [B,1] (moe.py:74-101).  ``alpha`` is returned as
-        log-probabilities' argument: for a single expert the softmax is trivially 1, so the raw
-        (post-ReLU) coefficient is recovered from the head output."""
-        raise RuntimeError("call the expert through MixtureOfExperts (grouped execution); a lone BaseExpert "
-                           "has no defined mixture output on the HIP path")
+        """-> alpha [B,1], mean [B,2], std [B,2], pred_speed [B,1] (moe.py:74-101; BaseExpertAlt: moe.py:112-128).
+        Runs as a group of ONE through the same engine the mixture uses (MixtureOfExperts builds its own grouped engine
+        over all its experts and never calls this)."""
+        alpha, mean, std, speeds = self._run(images, speed, command)
+        return alpha, mean[:, 0], std[:, 0], speeds[:, 0]
 
 
 class BaseExpertAlt(BaseExpert):

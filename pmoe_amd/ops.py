@@ -28,9 +28,10 @@ def _nhwc(t, name):
 
 def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=False, in_shared=False,
            in_coff=0, out_coff=0, res=None, res_coff=0, res_mode=hip.RES_NONE, bias=None, act=hip.ACT_NONE,
-           drop_p=0.0, seed=0, stats=None):
+           drop_p=0.0, seed=0, stats=None, plan_only=False):
     """out[..., out_coff:out_coff+cout] = epilogue(conv(x[..., in_coff:in_coff+cin], w)).
-    ``x`` [Nin,H,W,ldx], ``out`` [N,Ho,Wo,ldo] preallocated; also used for dgrad and grouped GEMM."""
+    ``x`` [Nin,H,W,ldx], ``out`` [N,Ho,Wo,ldo] preallocated; also used for dgrad and grouped GEMM.
+    ``plan_only``: launch nothing, return the kernel-instantiation code of ``pmoe_conv2d_plan`` (include/pmoe_hip.h)."""
     nin, h, w_, ldx = _nhwc(x, "x")
     n, ho, wo, ldo = _nhwc(out, "out")
     if x.dtype != out.dtype or w_packed.dtype != x.dtype:
@@ -55,6 +56,8 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
         raise ValueError("conv2d: input/output image counts differ")
     if w_packed.numel() < (n // ipe) * coutp * ks * ks * cin:
         raise ValueError("conv2d: packed weight tensor too small")
+    if plan_only:
+        return load().pmoe_conv2d_plan(C.byref(d))
     if _prof is not None:            # profiling: remember which kernel instantiation serves this launch
         _launch_info["kernel"] = load().pmoe_conv2d_plan(C.byref(d))
     check(load().pmoe_conv2d_igemm(C.byref(d), stream_ptr()), "pmoe_conv2d_igemm")
@@ -71,8 +74,23 @@ def conv2d_stat_rows(n, h, w_, ho, wo, cin, cout, coutp, ipe, ks, stride, pad, d
     return rows
 
 
+_wgrad_scratch = {}
+
+
+def _wgrad_part_ws(device, floats):
+    """K-split scratch of the weight-gradient launch: one growing f32 buffer per (device, stream) -- launches on one
+    stream are ordered, so consecutive layers may share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _wgrad_scratch.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = _wgrad_scratch[key] = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+    return buf
+
+
 def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, x_shared=False, x_coff=0, dy_coff=0,
-                 per_image=False):
+                 per_image=False, plan_only=False):
+    """dw_ws [E | N][ks*ks][coutp][cinp] f32 is OVERWRITTEN with the weight gradient (deterministic: fixed-order folds
+    of the pixel split, no atomics; csrc/conv_wgrad.hip)."""
     nin, h, w_, ldx = _nhwc(x, "x")
     n, ho, wo, ldy = _nhwc(dy, "dy")
     d = WgradDesc()
@@ -85,6 +103,14 @@ def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, 
     d.per_image = int(per_image)
     if dw_ws.numel() < (n if per_image else n // ipe) * ks * ks * coutp * cinp:
         raise ValueError("conv2d_wgrad: workspace too small")
+    need = load().pmoe_conv2d_wgrad_ws_floats(C.byref(d))
+    if need < 0:
+        check(int(need), "pmoe_conv2d_wgrad_ws_floats")
+    if plan_only:                    # number of K-split slices (workgroups along the pixel axis) the launch would use
+        return max(1, need // ((n // ipe) * ks * ks * coutp * cinp))
+    if need > 0:
+        part = _wgrad_part_ws(x.device, need)
+        d.part_ws, d.part_ws_floats = ptr(part, "part_ws"), part.numel()
     check(load().pmoe_conv2d_wgrad(C.byref(d), stream_ptr()), "pmoe_conv2d_wgrad")
     return dw_ws
 

@@ -42,14 +42,16 @@ def _f32_cuda(t, what):
 
 class _Table:
     """Device copy of a pmoe_opt_tensor array + its chunk lists.  Tables are cached on the tuple of raw pointers they
-    hold (parameter / state storage is stable, and torch's caching allocator hands the gradient arena back at the same
-    address step after step), so the steady state uploads nothing; a new table goes up through pinned memory without
-    blocking the host."""
+    hold PLUS their element counts and the device (parameter / state storage is stable, and torch's caching allocator
+    hands the gradient arena back at the same address step after step; the allocator also reuses addresses across
+    models, so pointers alone would not identify a table), so the steady state uploads nothing; a new table goes up
+    through pinned memory without blocking the host."""
 
     _cache = {}
 
     @classmethod
-    def get(cls, key, device, build_rows):
+    def get(cls, key, device, build_rows, numels=()):
+        key = (str(device), tuple(int(n) for n in numels)) + tuple(key)
         tab = cls._cache.get(key)
         if tab is None:
             if len(cls._cache) > 8:
@@ -91,7 +93,7 @@ def _grad_table(params):
         rows["grad"] = ptrs
         rows["numel"] = [p.numel() for p in ps]
         return rows
-    return _Table.get(("g",) + ptrs, ps[0].device, build), ps
+    return _Table.get(("g",) + ptrs, ps[0].device, build, [p.numel() for p in ps]), ps
 
 
 def clip_grad_norm_(parameters, max_norm, norm_type=2.0, scale=True):
@@ -172,7 +174,7 @@ class FusedAdam(torch.optim.Optimizer):
                 rows["bc2_sqrt"] = [(1.0 - b2 ** k) ** 0.5 for k in steps]
                 return rows
             key = ("a",) + tuple(v for c in cols.values() for v in c) + (() if uniform else tuple(steps))
-            tab = _Table.get(key, ps[0].device, build)
+            tab = _Table.get(key, ps[0].device, build, [p.numel() for p in ps])
             # all tensors at the same step (the normal case): bias corrections travel as kernel arguments and the cached
             # table is reused; otherwise the per-tensor values of a freshly built table are used (argument < 0)
             bc1 = 1.0 - b1 ** steps[0] if uniform else -1.0
@@ -206,8 +208,12 @@ class FusedAveragedModel(torch.optim.swa_utils.AveragedModel):
             rows["param"], rows["swa"] = pp, aa
             rows["numel"] = [p.numel() for p in theirs]
             return rows
-        tab = _Table.get(("s",) + pp + aa, mine[0].device, build)
-        n = int(self.n_averaged.item())
+        tab = _Table.get(("s",) + pp + aa, mine[0].device, build, [p.numel() for p in theirs])
+        # host-side mirror of n_averaged: no device->host sync per update when the buffer lives on the GPU
+        n = self.__dict__.get("_n_host")
+        if n is None or self.__dict__.get("_n_seen") != (id(self.n_averaged), self.n_averaged._version):
+            n = int(self.n_averaged.item())      # first call, or the buffer was replaced / loaded from a checkpoint
         check(load().pmoe_mt_swa_update(*tab.args(), n, stream_ptr()), "pmoe_mt_swa_update")
         torch.autograd.graph.increment_version(mine)
         self.n_averaged += 1
+        self.__dict__["_n_host"], self.__dict__["_n_seen"] = n + 1, (id(self.n_averaged), self.n_averaged._version)

@@ -28,6 +28,36 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 #   bf16: statistical agreement only (median cosine >= 0.85, total norm within 20%); the bf16 KERNELS are
 #         held to 1e-2 per op in tests/test_ops_gpu.py.
 TOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
+# bf16 forward bound, measured instead of flat: tests/golden/bf16_bounds.pt (oracle/make_bounds.py)
+# holds, per golden case and output, the float64 oracle's value and the error of the bf16-STORAGE-emulating oracle
+# (oracle/bf16_emulation.py: weights and every layer output rounded to bf16, f32 arithmetic) against it.  The HIP bf16
+# path must be within BF16_SLACK x that error of the float64 truth, output by output (metric max |d| / (1 + |ref|); the
+# larger of the two emulation variants, "every layer stored" / "BatchNorm passes fused", is the yardstick).
+BF16_SLACK = 1.25
+_BOUNDS = None
+
+
+def bf16_bounds(name):
+    global _BOUNDS
+    if _BOUNDS is None:
+        _BOUNDS = torch.load(GOLDEN / "bf16_bounds.pt", weights_only=False)
+    return _BOUNDS["forward"].get(name)
+
+
+def grad_bounds(name):
+    bf16_bounds(name)
+    return _BOUNDS["grad"].get(name)
+
+
+def bf16_fwd_report(name, outs):
+    """{output: (HIP error vs float64, emulating-oracle error vs float64)} for the outputs of golden case ``name``."""
+    b = bf16_bounds(name)
+    rep = {}
+    for k, got in outs.items():
+        ref = b["f64"][k]
+        err = ((got.detach().double().cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        rep[k] = (err, max(b["emul"][v][k][0] for v in b["emul"]))
+    return rep
 GRAD_TOL = {torch.float32: 2e-2, torch.bfloat16: None}
 GRAD_MEDIAN_TOL = 5e-3
 
@@ -80,14 +110,22 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
             dist, speeds = model(dev["images"], dev["speed"], dev["command"])
         loss = None
     probs, mean, std = dist.hip_params
-    report["probs"] = fwd_err(probs, g["probs"], dtype)
-    report["mean"] = fwd_err(mean, g["mean"], dtype)
-    report["std"] = fwd_err(std, g["std"], dtype)
-    report["speeds"] = fwd_err(speeds, g["speeds"], dtype)
+    if dtype == torch.bfloat16 and bf16_bounds(name) is not None:
+        # error vs the float64 oracle in units of BF16_SLACK x the bf16-emulating oracle's own error (<= 1 passes)
+        rep = bf16_fwd_report(name, dict(probs=probs, mean=mean, std=std, speeds=speeds))
+        for k, (err, emul) in rep.items():
+            report[k] = err / (BF16_SLACK * emul)
+            report[k + "_abs"] = (err, emul)
+    else:
+        report["probs"] = fwd_err(probs, g["probs"], dtype)
+        report["mean"] = fwd_err(mean, g["mean"], dtype)
+        report["std"] = fwd_err(std, g["std"], dtype)
+        report["speeds"] = fwd_err(speeds, g["speeds"], dtype)
     if loss is not None:
         report["loss"] = abs(loss.item() - g["loss"].item()) / max(1.0, abs(g["loss"].item())) / tol
     for k, v in report.items():
-        assert v <= fwd_tol_mult, f"{name} [{dtype}] {k}: {v:.3f} x tolerance {tol}"
+        if not k.endswith("_abs"):
+            assert v <= fwd_tol_mult, f"{name} [{dtype}] {k}: {v:.3f} x tolerance ({report.get(k + '_abs', tol)})"
     if loss is not None and check_grads:
         named = dict(model.named_parameters())
         od, os_ = oracle(inp["images"], inp["speed"], inp["command"])
@@ -120,9 +158,14 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
                 O.moe_loss(d64, s64, inp["control"].double(), inp["target_speed"].double(), ocfg.loss_coefs).backward()
                 g64 = {k: p.grad.float() for k, p in o64.named_parameters()}
             else:
-                # the largest cases skip the float64 evaluation (it is most of their run time): the f32 oracle stands in
-                # as the truth with its typical own drift (5e-3) assumed, i.e. a flat 2e-2 per-tensor bound
-                g64 = {k: p.grad for k, p in onamed.items()}
+                # the largest cases take the float64 evaluation from the fixture (oracle/make_bounds.py): per tensor the
+                # norm of the float64 gradient and the f32 oracle's own relative drift from it.  The full float64
+                # tensors are not stored (220 MB), so the distance to them is bounded by the triangle inequality:
+                # |hip - g64| <= |hip - o32| + |o32 - g64|, all relative to |g64| -- a SUFFICIENT condition, stricter
+                # than the live comparison the smaller cases get
+                gb = grad_bounds(name)
+                assert gb is not None, f"{name}: no float64 gradient fixture (oracle/make_bounds.py)"
+                g64 = None
             # Isolated ReLU-mask flips: any two f32 implementations disagree on the sign of a few pre-activations
             # that sit within ~1e-7 of zero (expected 0.2-2 per pass here).  At the 4x4 / 8x8 layers of these B=2
             # goldens one flip moves ONE channel's BatchNorm gradient by ~25 % and every upstream tensor of THAT
@@ -137,10 +180,16 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
                 return int(mt.group(1)) if mt else 0
             per_expert = {}
             for k, p in named.items():
-                if g64[k].norm().item() < 1e-6 * total_ref:
-                    continue
-                e_ref = rel_l2(onamed[k].grad, g64[k]) if f64_oracle else 5e-3
-                e_hip = rel_l2(p.grad, g64[k])
+                if g64 is None:
+                    n64, e_ref = gb[k]
+                    if n64 < 1e-6 * total_ref:
+                        continue
+                    e_hip = (p.grad.detach().float().cpu() - onamed[k].grad).norm().item() / n64 + e_ref
+                else:
+                    if g64[k].norm().item() < 1e-6 * total_ref:
+                        continue
+                    e_ref = rel_l2(onamed[k].grad, g64[k])
+                    e_hip = rel_l2(p.grad, g64[k])
                 ex = expert_of(k)
                 per_expert.setdefault(ex, []).append((e_hip, e_hip <= max(5e-3, 4 * e_ref), k))
             tight = [ex for ex, rows in per_expert.items() if all(ok for _, ok, _ in rows)]

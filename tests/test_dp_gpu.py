@@ -96,5 +96,6 @@ def test_engine_gradient_allreduce_two_ranks_one_gpu(kind):
         assert p.exitcode == 0
     for rank, err, differs in res:
         assert differs > 1e-3, "the two shards must produce different local gradients"
-        # two backward runs of one rank differ by the order of the weight-gradient atomics only
-        assert err <= 2e-4, (kind, rank, err)
+        # deterministic backward (no float atomics): the all-reduced gradient IS the mean of the local gradients, up to
+        # the f32 rounding of gloo's own sum
+        assert err <= 1e-6, (kind, rank, err)

@@ -51,13 +51,14 @@ def test_forward_is_deterministic_and_gradients_reproducible():
     for a, b in zip(o1, o2):
         assert torch.equal(a, b)               # fixed-order reductions everywhere on the forward path
     assert torch.equal(l1, l2)
-    for k in g1:                               # weight gradients accumulate with f32 atomics: order noise only
-        assert (g1[k] - g2[k]).norm() <= 1e-5 * g1[k].norm() + 1e-12, k
+    for k in g1:                               # no float atomics on the backward path either (fixed-order K-split folds)
+        assert torch.equal(g1[k], g2[k]), k
 
 
 def test_loss_scale_is_exact_in_the_gradients():
     """loss.py:132 is linear in loss_coefs; a factor of 2 is exact in binary floating point, so every kernel of the
-    backward pass must reproduce it up to the atomics' summation order."""
+    backward pass must reproduce it bit for bit (deterministic reductions; power-of-two scaling commutes with every
+    bf16 / f32 rounding on the path)."""
     m, batch = _model(), _batch()
     sd = copy.deepcopy(m.state_dict())
     _, l1, g1 = _step(m, batch, (0.7, 0.3))
@@ -65,7 +66,7 @@ def test_loss_scale_is_exact_in_the_gradients():
     _, l2, g2 = _step(m, batch, (1.4, 0.6))
     assert abs(l2.item() - 2 * l1.item()) <= 1e-6 * abs(l1.item())
     for k in g1:
-        assert (g2[k] - 2 * g1[k]).norm() <= 2e-5 * g1[k].norm() + 1e-12, k
+        assert torch.equal(g2[k], 2 * g1[k]), k
 
 
 def test_experts_are_independent_until_the_gate():

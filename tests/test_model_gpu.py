@@ -65,6 +65,68 @@ def test_fused_and_unfused_bn_stats_agree():
         assert rel_err(a, b) < 1e-5
 
 
+def test_bn_fold_cache_follows_the_running_statistics():
+    """the eval-mode BatchNorm fold is cached; train-mode forwards with FROZEN weights (PMoE training
+    with freeze(moe), the SWA BatchNorm re-estimation loop train_2.py:225-233) update the running statistics through raw
+    pointers, and the next eval forward must see them -- like nn.BatchNorm2d, which always reads the live buffers."""
+    g = torch.load(GOLDEN / "g5_moe_e3_b3_96.pt", weights_only=False)
+    _, oracle, model, inp = build_pair(g, torch.float32)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    dev = [inp[k].cuda() for k in ("images", "speed", "command")]
+    model.eval()
+    with torch.no_grad():
+        before = model.mixture_params(*dev)
+        model.train()
+        oracle.train()
+        for _ in range(3):
+            model(*dev)
+            oracle(inp["images"], inp["speed"], inp["command"])
+        model.eval()
+        oracle.eval()
+        folded = model.mixture_params(*dev)
+        model._engine().fold_bn_eval = False
+        unfolded = model.mixture_params(*dev)
+        od, _ = oracle(inp["images"], inp["speed"], inp["command"])
+    for a, b in zip(folded, unfolded):
+        assert rel_err(a, b) < 1e-5
+    assert rel_err(folded[1], od.component_distribution.base_dist.loc) < 1e-3        # the oracle after the same 3 updates
+    assert rel_err(folded[1], before[1]) > 1e-3                                       # and the statistics did move
+
+
+@pytest.mark.parametrize("alt", [False, True])
+def test_lone_expert_forward(alt):
+    """BaseExpert.forward / BaseExpertAlt.forward called on their own (moe.py:74-101, 112-128) -> (alpha, mean, std,
+    pred_speed): a group of one on the same engine, alpha WITHOUT the mixture's softmax (post-ReLU for BaseExpert)."""
+    import statistics
+    from oracle import pmoe_oracle as O, weights as W
+    from pmoe_amd.model.moe import BaseExpert, BaseExpertAlt
+    from pmoe_amd.utils import stage2_model_cfg
+    from tests.parity_util import rel_l2
+    kind = "moe_alt" if alt else "moe"
+    oracle = (O.BaseExpertAlt if alt else O.BaseExpert)(O.stage2_cfg(kind, 1))
+    W.fill_state_dict(oracle, seed=3)
+    oracle.train()
+    model = (BaseExpertAlt if alt else BaseExpert)(stage2_model_cfg(kind, 1, dropout=0.0))
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model = model.cuda()
+    model.compute_dtype = torch.float32
+    model.train()
+    inp = W.make_inputs(5, 64, 64, seed=5)
+    got = model(inp["images"].cuda(), inp["speed"].cuda(), inp["command"].cuda())
+    ref = oracle(inp["images"], inp["speed"], inp["command"])
+    assert [tuple(t.shape) for t in got] == [(5, 1), (5, 2), (5, 2), (5, 1)]
+    gen = torch.Generator().manual_seed(1)
+    wts = [torch.randn(t.shape, generator=gen) for t in ref]
+    for a, b, nm in zip(got, ref, ("alpha", "mean", "std", "pred_speed")):
+        assert rel_err(a, b) <= 1e-4, (nm, rel_err(a, b))
+    sum((a * w.cuda()).sum() for a, w in zip(got, wts)).backward()
+    sum((b * w).sum() for b, w in zip(ref, wts)).backward()
+    og = dict(oracle.named_parameters())
+    errs = [rel_l2(p.grad, og[k].grad) for k, p in model.named_parameters() if og[k].grad.norm() > 0]
+    assert statistics.median(errs) <= 5e-3 and max(errs) <= 0.15, (statistics.median(errs), max(errs))
+
+
 def test_module_contract():
     """deepcopy (AveragedModel), freeze-by-name, state_dict round trip, frozen parameters get no grads."""
     from pmoe_amd.loss import moe_loss

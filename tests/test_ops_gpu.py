@@ -83,9 +83,10 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(case, dtype):
+def _conv_case(case, dtype, plan=None):
+    """forward (+ fused BatchNorm partial sums), data gradient, weight gradient of one grouped conv against CPU fp32 autograd.
+    ``plan`` = (forward code, data-gradient code, weight-gradient K-split x channel-tile pairs): asserted BEFORE running, so
+    a routing change cannot silently move a shape off the kernel this case exists to cover."""
     E, ipe, cin, cout, H, W, ks, stride = case
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     pad = ks // 2
@@ -107,6 +108,9 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     out = torch.full((N, Ho, Wo, r16(cout)), 7.0, dtype=dtype, device=DEV)
     rows = ops.conv2d_stat_rows(N, H, W, Ho, Wo, cinp, cout, coutp, ipe, ks, stride, pad, dtype)
     stats = torch.zeros(rows, 2, coutp, device=DEV)
+    if plan is not None:
+        got = ops.conv2d(xd, wf, out, cin=cinp, cout=cout, coutp=coutp, ipe=ipe, ks=ks, stride=stride, pad=pad, plan_only=True)
+        assert got == plan[0], f"forward routed to kernel code {got}, this case is meant for {plan[0]}"
     ops.conv2d(xd, wf, out, cin=cinp, cout=cout, coutp=coutp, ipe=ipe, ks=ks, stride=stride, pad=pad, stats=stats)
     y = from_nhwc(out, cout)
     close(y, yr.detach(), dtype, "conv fwd")
@@ -119,6 +123,10 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     # data gradient: stride 1 = conv with flipped weights; stride 2 = dilated source
     dyd = nhwc(dy, r16(cout), dtype)
     dx = torch.empty(N, H, W, cinp, dtype=dtype, device=DEV)
+    if plan is not None:
+        got = ops.conv2d(dyd, wd, dx, cin=r16(cout), cout=cinp, coutp=r64(cin), ipe=ipe, ks=ks, stride=1,
+                         pad=ks - 1 - pad, dilate=(stride == 2), plan_only=True)
+        assert got == plan[1], f"data gradient routed to kernel code {got}, this case is meant for {plan[1]}"
     ops.conv2d(dyd, wd, dx, cin=r16(cout), cout=cinp, coutp=r64(cin), ipe=ipe, ks=ks, stride=1,
                pad=ks - 1 - pad, dilate=(stride == 2))
     close(from_nhwc(dx, cin), xr.grad, dtype, "conv dgrad")
@@ -133,12 +141,50 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     # weight gradient
     ckw = 64 if dtype == torch.bfloat16 else 32
     cpw, cow = (cinp + ckw - 1) // ckw * ckw, (r16(cout) + ckw - 1) // ckw * ckw
-    ws_buf = torch.zeros(E, ks * ks, cow, cpw, device=DEV)
+    ws_buf = torch.full((E, ks * ks, cow, cpw), 3.0, device=DEV)      # overwritten, not accumulated onto
+    if plan is not None:
+        nsplit = ops.conv2d_wgrad(xd, dyd, ws_buf, cin=cinp, cout=r16(cout), cinp=cpw, coutp=cow, ipe=ipe, ks=ks, stride=stride,
+                                  pad=pad, plan_only=True)
+        assert nsplit * E * (cow // ckw) * (cpw // ckw) == plan[2], (nsplit, plan[2])
     ops.conv2d_wgrad(xd, dyd, ws_buf, cin=cinp, cout=r16(cout), cinp=cpw, coutp=cow, ipe=ipe, ks=ks, stride=stride, pad=pad)
     grads = torch.empty(E, cout, cin, ks, ks, device=DEV)
     ops.unpack_conv_wgrad(ws_buf, grads, E, cout, cin, ks, cow, cpw)
     for e in range(E):
         close(grads[e], wr[e].grad, dtype, f"conv wgrad e{e}")
+
+
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    _conv_case(case, dtype)
+
+
+# The layer shapes of BASELINE config 2 (E=4, B=64, 256x256) at reduced image counts, each pinned to the kernel
+# instantiation that serves it in the benchmark (VERDICT r1 "weak" 3 / ADVICE r1: the dominant kernels had no isolated
+# parity test).  Codes: include/pmoe_hip.h pmoe_conv2d_plan; the third number = workgroups of the weight-gradient launch.
+BASELINE_CONV_CASES = [
+    # (E, ipe, cin, cout, H, W, ks, stride), (fwd, dgrad, wgrad workgroups)
+    ((1, 4, 128, 128, 64, 64, 3, 1), (2007, 2007, 256)),       # layer2: conv_igemm_lite_kernel<bf16,7>, 2 channel chunks
+    ((1, 8, 256, 256, 32, 32, 3, 1), (2007, 2007, 256)),       # layer3: 4 chunks, 8 images per 256-pixel tile column
+    ((2, 32, 512, 512, 16, 16, 3, 1), (2007, 2007, 256)),      # layer4: 8 chunks, one image per tile, 2 experts
+    ((1, 1, 64, 64, 256, 256, 3, 1), (1007, 1007, 256)),       # stem conv2: conv3x3_res_kernel<7>, 256 tiles of one image
+    ((2, 2, 64, 64, 128, 128, 3, 1), (1007, 1007, 256)),       # layer1: resident kernel, persistent workgroups per expert
+    ((1, 4, 64, 128, 128, 128, 3, 2), (642, 4741, 256)),       # layer2.0.conv1: stride-2 forward, parity-class data gradient
+    ((1, 4, 64, 128, 128, 128, 1, 2), (2007, 741, 128)),       # layer2.0.downsample (1x1: LITE tile over the used pixels)
+    ((1, 1, 12, 64, 256, 256, 3, 1), (1005, 1007, 256)),       # stem conv1 (12 -> 16 input channels): resident kernel, 32-byte rows
+]
+
+
+@pytest.mark.parametrize("case,plan", BASELINE_CONV_CASES)
+def test_conv_baseline_layer_shapes_bf16(case, plan):
+    _conv_case(case, torch.bfloat16, plan)
+
+
+@pytest.mark.parametrize("case", [c for c, _ in BASELINE_CONV_CASES[:4]])
+def test_conv_baseline_layer_shapes_f32(case):
+    _conv_case(case, torch.float32)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
