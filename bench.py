@@ -39,10 +39,14 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--experts", type=int, default=4)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8 = BASELINE config 5: e4m3 weights + activations on the fp8 matrix cores for the ResNet layer1-4 "
+                         "forward convolutions, bf16 elsewhere (quote it with --batch 128)")
     ap.add_argument("--dropout", type=float, default=0.3, help="stage_2*.yaml value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage1", action="store_true", help="skip the stage-1 PU-Net training step (section 8f N4)")
+    ap.add_argument("--no-sub-configs", action="store_true",
+                    help="skip the short sub-records of BASELINE configs C3 (per-GPU shard, E=8), C4 (punet) and C5 (fp8, B=128)")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--measure-overlap", action="store_true",
                     help="also time the step with weight gradients on a side stream (co-running kernels: keep it out of "
@@ -61,9 +65,21 @@ def make_batch(B, size, seed, device):
     return [t.to(device) for t in (images, speed, command, control, target)]
 
 
+def _cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
     """The CPU oracle (oracle/pmoe_oracle.py, a port of the reference path checked against goldens of the
-    imported reference) timed on this box's host cores on a bounded sample of the same workload."""
+    imported reference) timed on this box's host cores on bounded samples of the workloads SURVEY.md section 8d names:
+    the headline shape at batch 4 (the `value`), BASELINE config 1 exactly (E=4, B=2, 128x128, the full H1 step:
+    fwd + moe_loss + zero_grad + bwd + clip_grad_norm_(1.0) + Adam(amsgrad), train_2.py:149-165) and B=8 at 256x256."""
     from oracle import pmoe_oracle as O
     from oracle import weights as W
     # the box grants one GPU a 16-CPU share; os.cpu_count() reports the whole host and oversubscribes
@@ -73,28 +89,113 @@ def cpu_baseline(args):
         n = os.cpu_count() or 1
     n = max(1, min(n, 16))
     torch.set_num_threads(n)
-    Bc = 4
     model = O.get_model(O.stage2_cfg("moe", args.experts, dropout=0.0))
     model.train()
-    inp = W.make_inputs(Bc, args.size, args.size, seed=7)
 
-    def step():
-        model.zero_grad(set_to_none=True)
-        d, s = model(inp["images"], inp["speed"], inp["command"])
-        O.moe_loss(d, s, inp["control"], inp["target_speed"], [0.7, 0.3]).backward()
+    def timed(Bc, size, budget_s, max_iters, h1=False):
+        inp = W.make_inputs(Bc, size, size, seed=7)
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True) if h1 else None
+
+        def step():
+            d, s = model(inp["images"], inp["speed"], inp["command"])
+            loss = O.moe_loss(d, s, inp["control"], inp["target_speed"].clone(), [0.7, 0.3])
+            model.zero_grad(set_to_none=True)
+            loss.backward()
+            if h1:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+                opt.step()
+        step()                                                 # thread-pool / allocator warm-up at this shape
+        t0 = time.perf_counter()
+        iters = 0
+        while iters < 2 or (time.perf_counter() - t0 < budget_s and iters < max_iters):
+            step()
+            iters += 1
+        dt = time.perf_counter() - t0
+        return round(Bc * iters / dt, 4), iters
 
     small = W.make_inputs(1, 64, 64, seed=7)
-    d, s = model(small["images"], small["speed"], small["command"])       # thread-pool / allocator warm-up
+    d, s = model(small["images"], small["speed"], small["command"])
     O.moe_loss(d, s, small["control"], small["target_speed"], [0.7, 0.3]).backward()
-    t0 = time.perf_counter()
-    iters = 0
-    while iters < 2 or (time.perf_counter() - t0 < 12 and iters < 6):
+    v4, it4 = timed(4, args.size, 8, 5)
+    v8, it8 = timed(8, args.size, 8, 3)
+    vc1, itc1 = timed(2, 128, 4, 12, h1=True)
+    return {"value": v4, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": _cpu_model_string(), "host_cpus": os.cpu_count(),
+            "sample": f"{it4} x (fwd+moe_loss+bwd) at batch 4, {args.size}x{args.size}, E={args.experts}, fp32, "
+                      f"torch {torch.__version__} CPU",
+            "batch8": {"value": v8, "unit": "samples/s",
+                       "sample": f"{it8} x (fwd+moe_loss+bwd) at batch 8, {args.size}x{args.size}, E={args.experts}, fp32"},
+            "config1": {"value": vc1, "unit": "samples/s",
+                        "sample": f"{itc1} x full H1 step (fwd+moe_loss+zero_grad+bwd+clip_grad_norm_(1.0)+Adam amsgrad) at "
+                                  f"batch 2, 128x128, E={args.experts}, fp32 -- BASELINE config 1"}}
+
+
+def sub_configs(dev, args):
+    """Short driver-timed records of the other single-GPU BASELINE configs (they used to live in DESIGN.md prose only):
+    C3's per-GPU shard (E=8, B=64), C4 (PUNetExpert T=4 F=6, B=64) and C5 (fp8 policy, B=128), all 256x256, fwd+loss+bwd."""
+    import gc
+    import tempfile
+    from pmoe_amd.loss import moe_loss, punet_loss
+    from pmoe_amd.model.moe import get_model
+    from pmoe_amd.utils import stage2_model_cfg
+    out = {}
+
+    def timed(step, n=4):
         step()
-        iters += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(Bc * iters / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{iters} x (fwd+moe_loss+bwd) at batch {Bc}, {args.size}x{args.size}, "
-            f"E={args.experts}, fp32, torch {torch.__version__} CPU"}
+        step()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            step()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+        return ev[0].elapsed_time(ev[n]) / n, per[n // 2]
+
+    def moe_case(experts, batch, fp8):
+        model = get_model(stage2_model_cfg("moe", experts, dropout=args.dropout)).to(dev)
+        model.compute_dtype = torch.bfloat16
+        model.fp8_weights = fp8
+        model.train()
+        images, speed, command, control, target = make_batch(batch, args.size, 99, dev)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            d, s = model(images, speed, command)
+            moe_loss(d, s, control, target, [0.7, 0.3]).backward()
+        ms, med = timed(step)
+        flop = 6 * MAC_FWD_PER_EXPERT_SAMPLE_256 * experts * (args.size / 256.0) ** 2 * batch
+        return {"ms_per_step": round(ms, 2), "ms_per_step_median": round(med, 2), "samples_per_s": round(batch / ms * 1e3, 1),
+                "tflops_algorithmic": round(flop / ms / 1e9, 1)}
+
+    out["C3_shard_e8_b64"] = dict(moe_case(8, 64, False), what="8-expert MoE, batch 64 (one GPU's shard of the B=512 DP config), bf16")
+    gc.collect(); torch.cuda.empty_cache()
+    out["C5_fp8_b128"] = dict(moe_case(args.experts, 128, True), what="4-expert MoE, batch 128, e4m3 weights + activations on "
+                              "the fp8 matrix cores for the layer1-4 forward convolutions (bf16 stem / backward)")
+    gc.collect(); torch.cuda.empty_cache()
+    out["C2_bf16_b128"] = dict(moe_case(args.experts, 128, False), what="same shape as C5 in plain bf16 (the A/B partner)")
+    gc.collect(); torch.cuda.empty_cache()
+    # C4: PUNetExpert (the constructor reads checkpoint files in the reference's layouts: write random-init ones)
+    from tests.punet_util import build_product
+    tmp = Path(tempfile.mkdtemp())
+    model = build_product(tmp, dict(type="punet", n_experts=2, future_frames=6), dropout=args.dropout).to(dev)
+    model.compute_dtype = torch.bfloat16
+    model.train()
+    images, speed, command, control, target = make_batch(64, args.size, 98, dev)
+
+    def pstep():
+        model.zero_grad(set_to_none=True)
+        act, sp = model(images, speed, command)
+        punet_loss(act, sp, control, target, [0.7, 0.3]).backward()
+    ms, med = timed(pstep, 3)
+    out["C4_punet_b64"] = {"ms_per_step": round(ms, 2), "ms_per_step_median": round(med, 2),
+                           "samples_per_s": round(64 / ms * 1e3, 1),
+                           "tflops_algorithmic": round((2 * 477.27e9 + 6 * 16.4836e9) * 64 / ms / 1e9, 1),
+                           "what": "PUNetExpert T=4 F=6, batch 64, 256x256, bf16, fwd+punet_loss+bwd (PU-Net frozen, forward only)"}
+    del model
+    gc.collect(); torch.cuda.empty_cache()
+    return out
 
 
 def stage1_step(dev, batch=10, size=224, frames=6, steps=3):
@@ -145,7 +246,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # under torch.distributed.run the process group is created even for ONE rank: the RCCL communicator, ReduceOp.AVG and
+    # the bucket waits of pmoe_amd.parallel then run exactly as in the N-GPU job (tests/test_dp_gpu.py runs this on one GPU)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         if share:
             dist.init_process_group("gloo")
         else:
@@ -157,16 +261,17 @@ def main():
     from pmoe_amd.utils import stage2_model_cfg
     hip.load()
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     torch.manual_seed(0)
     model = get_model(stage2_model_cfg("moe", args.experts, dropout=args.dropout)).to(dev)
     model.compute_dtype = dtype
+    model.fp8_weights = args.dtype == "fp8"
     model.train()
-    if world > 1:
+    if use_dist:
         # identical replicas: broadcast rank 0's random init
         for p in model.parameters():
             dist.broadcast(p.data, 0)
-        model.enable_data_parallel()
+        model.enable_data_parallel(always=True)
     images, speed, command, control, target = make_batch(args.batch, args.size, 1234 + rank, dev)
     coefs = [0.7, 0.3]
 
@@ -178,7 +283,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -194,29 +299,40 @@ def main():
             log("first step done")
     fence()
     log("timing")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step durations for the median
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms = elapsed / args.steps * 1e3
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2]
     total_samples = args.batch * world * args.steps
     value = total_samples / elapsed
 
     out = {
         "metric": "samples/sec fwd+bwd, 256x256 RGB 4-expert PMoE", "value": round(value, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "ms_per_step_median": round(ms_median, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.experts}-expert MoE (PMoE experts), {args.size}x{args.size}x3 x4 frames, "
-                               f"batch {args.batch}/GPU, fwd+moe_loss+bwd, dropout {args.dropout}",
+                               f"batch {args.batch}/GPU, fwd+moe_loss+bwd, dropout {args.dropout}"
+                               + (", fp8 policy (e4m3 weights + activations, layer1-4 forward convolutions)" if args.dtype == "fp8" else ""),
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         "loss": round(float(loss.item()), 5),
     }
 
+    if use_dist and rank == 0:
+        from pmoe_amd import parallel as _par
+        out["dp"] = {"backend": dist.get_backend(), "world": world,
+                     "buckets_issued_per_backward": _par.BucketedAllReduce.last_issued}
     if rank == 0:
         # ---- whole-step rooflines from the algorithmic work model
         scale = (args.size / 256.0) ** 2 * args.experts / 4.0
@@ -259,22 +375,26 @@ def main():
         out["kernel_ms_total"] = round(tot, 3)
         # ---- roofline of the dominant kernel: conv launches attributed to the kernel instantiation that served them
         # (pmoe_conv2d_plan), so that the numbers line up with the rows of a rocprofv3 kernel trace
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-        tname = "DF16b" if args.dtype == "bf16" else "f"
+        peak = 157.3 if args.dtype == "f32" else PEAK_BF16_TFLOPS    # (the non-scaled fp8 MFMA runs at the bf16 rate)
+        tname = "f" if args.dtype == "f32" else "DF16b"
+        kdt = "f32" if args.dtype == "f32" else "bf16"
 
         def symbol(code):
+            if code >= 8000:                      # e4m3 operands (BASELINE config 5): same tiles, TL = fp8
+                r, m, n = symbol(code - 8000)
+                return r.replace("<bf16,", "<bf16+e4m3,"), m.replace(f"E{tname}Ev8ConvArgs", "E3fp8Ev8ConvArgs"), n
             four = code >= 4000
             code %= 4000
             if code == 3000:
                 return "gemm_skinny_kernel", "gemm_skinny_kernel", 1
             if code >= 2000:
-                return (f"conv_igemm_lite_kernel<{args.dtype},{code - 2000}>" + (" (4 parity-class launches per stride-2 dgrad)" if four else ""),
-                        f"_Z22conv_igemm_lite_kernelI{tname}Li{code - 2000}EEv8ConvArgs", 4 if four else 1)
+                return (f"conv_igemm_lite_kernel<{kdt},{code - 2000}>" + (" (4 parity-class launches per stride-2 dgrad)" if four else ""),
+                        f"_Z22conv_igemm_lite_kernelI{tname}Li{code - 2000}E{tname}Ev8ConvArgs", 4 if four else 1)
             if code >= 1000:
                 return f"conv3x3_res_kernel<{code - 1000}>", f"void conv3x3_res_kernel<{code - 1000}", 1
             rb, wm, wn = code // 100, code // 10 % 10, code % 10
-            return (f"conv_igemm_kernel<{args.dtype},{rb},{wm},{wn}>" + (" (4 parity-class launches per stride-2 dgrad)" if four else ""),
-                    f"_Z17conv_igemm_kernelI{tname}Li{rb}ELi{wm}ELi{wn}EEv8ConvArgs", 4 if four else 1)
+            return (f"conv_igemm_kernel<{kdt},{rb},{wm},{wn}>" + (" (4 parity-class launches per stride-2 dgrad)" if four else ""),
+                    f"_Z17conv_igemm_kernelI{tname}Li{rb}ELi{wm}ELi{wn}E{tname}Ev8ConvArgs", 4 if four else 1)
         groups = {}
         for name, meta, ms_k in recs:
             if name != "conv2d" or "kernel" not in meta:
@@ -322,7 +442,8 @@ def main():
             for _ in range(n_h1):
                 step_fn()
             fence()
-            return {"ms_per_step": round((time.perf_counter() - t0) / n_h1 * 1e3, 3), "what": label}
+            ms_h1 = (time.perf_counter() - t0) / n_h1 * 1e3
+            return {"ms_per_step": round(ms_h1, 3), "samples_per_s": round(args.batch * world / ms_h1 * 1e3, 1), "what": label}
 
         fopt = fused_optim.FusedAdam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
 
@@ -350,6 +471,31 @@ def main():
         out["h1_step_torch_optim"] = time_h1(h1_torch, "same step with torch.nn.utils.clip_grad_norm_ + torch.optim.Adam")
         del opt
 
+    # ---- the gradient all-reduce against the backward pass that has to hide it: measured backward
+    # time of this rank vs a model of the bucketed ring all-reduce over xGMI (7 links x ~153 GB/s per GPU, point to point)
+    if rank == 0:
+        d, sp = model(images, speed, command)
+        lossb = moe_loss(d, sp, control, target, coefs)
+        model.zero_grad(set_to_none=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lossb.backward()
+        e1.record()
+        torch.cuda.synchronize()
+        nbytes = 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
+        link = 153e9
+        ring = lambda n: 2 * (n - 1) / n * nbytes / link * 1e3           # one ring: per-link bound
+        out["allreduce_model"] = {
+            "gradient_bytes": nbytes, "buckets": model._engine().dp_buckets, "backward_ms_measured": round(e0.elapsed_time(e1), 2),
+            "xgmi_link_GBs": 153, "ring_ms": {str(n): round(ring(n), 2) for n in (2, 4, 8)},
+            "note": "RCCL ring all-reduce of the f32 gradient arena, per-link bound (2(N-1)/N x bytes / 153 GB/s); the "
+                    "buckets start as soon as the tape has moved past them (heads -> layer4 -> ... -> stem), and the last "
+                    "bucket (stem + layer1, ~45 % of backward time) is the only one not covered by remaining backward work"}
+    elif use_dist:
+        d, sp = model(images, speed, command)                             # keep the ranks' collectives aligned
+        model.zero_grad(set_to_none=True)
+        moe_loss(d, sp, control, target, coefs).backward()
+
     # ---- optional mode: weight gradients on a side stream (engine.overlap_wgrad), reported beside the standard path
     if world == 1 and args.measure_overlap:
         eng = model._engine()
@@ -369,13 +515,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_stage1:
         log("stage-1 PU-Net training step")
         out["stage1_step"] = stage1_step(dev)
+    if rank == 0 and world == 1 and not use_dist and not args.no_sub_configs and args.dtype == "bf16" and args.batch == 64:
+        log("sub-records of BASELINE configs C3 / C4 / C5")
+        del model
+        out["configs"] = sub_configs(dev, args)
 
     log("H1 done; CPU baseline")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

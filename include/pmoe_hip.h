@@ -85,6 +85,8 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
  *   3000                     gemm_skinny_kernel<4|8>               (expert MLP layers / <= 2048 output pixels per expert, bf16)
  *   1000 + LOG_RB            conv3x3_res_kernel<LOG_RB>            (resident-filter kernel, conv_res.hip)
  *   2000 + LOG_RB            conv_igemm_lite_kernel<T, LOG_RB>     (8-wave 256 x 128 tile, two workgroups per CU)
+ *   5007                     conv3x3_dma_kernel                    (LDS-DMA staged 3x3 stride-1 kernel, >= 128 channels, conv_dma.hip)
+ *   8000 + one of the above  the same tile with e4m3 operands (w_fp8)
  *   LOG_RB*100 + WM*10 + WN  conv_igemm_kernel<T, LOG_RB, WM, WN>  (halo-patch implicit GEMM, conv_igemm.hip)
  *   4000 + the latter        the four parity-class launches of a stride-2 3x3 data gradient */
 int pmoe_conv2d_plan(const pmoe_conv_desc* d);

@@ -40,6 +40,7 @@ __device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const 
     constexpr int PSTEP = NTHR / CPR;
     constexpr int VE = 16 / (int)sizeof(TL);
     constexpr bool CVT = sizeof(TL) != sizeof(T);
+    constexpr int UB = CVT ? 2 : 4;                   // chunks in flight per batch (a converting chunk is two loads)
     static_assert(!CVT || (sizeof(T) == 2 && sizeof(TL) == 1), "conversion on load: bf16 -> fp8 only");
     const int pj = tid & (CPR - 1);
     int pp = tid >> LOG_CPR;
@@ -47,10 +48,10 @@ __device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const 
     const int row = pp / g.PW;
     int iy = row % g.PH, pn = row / g.PH;
     while (pp < g.NPIX) {
-        v4i v[4], v2[CVT ? 4 : 1];
-        int dst[4];
+        v4i v[UB], v2[CVT ? UB : 1];
+        int dst[UB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UB; ++u) {
             dst[u] = -1;
             if (pp < g.NPIX) {
                 const int n = g.n0 + pn;
@@ -81,7 +82,7 @@ __device__ __forceinline__ void load_halo_patch(char* patch, const T* in, const 
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < UB; ++u)
             if (dst[u] >= 0) {
                 if (CVT) *reinterpret_cast<v4i*>(patch + dst[u]) = cvt16_bf16_to_fp8(v[u], v2[u], in_scale);
                 else *reinterpret_cast<v4i*>(patch + dst[u]) = v[u];

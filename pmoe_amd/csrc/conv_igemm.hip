@@ -446,7 +446,7 @@ template <typename T, typename TL = T> static int launch_dtype(ConvArgs a, hipSt
     const int esz = (int)sizeof(TL);                // operand element size in LDS
     constexpr bool F8 = sizeof(TL) != sizeof(T);
     if (a.Cin <= 0 || a.CoutP % 64 || a.Cout % (16 / (int)sizeof(T)) || a.Cin % (32 / esz)) return PMOE_ERR_ARG;
-    if (F8 && (!a.oscale || a.Cin % 64 || !(a.in_scale > 0.f))) return PMOE_ERR_ARG;
+    if (F8 && (a.Cin % 64 || (!out_mblocks && (!a.oscale || !(a.in_scale > 0.f))))) return PMOE_ERR_ARG;
     if ((a.ks != 1 && a.ks != 3) || (a.stride != 1 && a.stride != 2) || (a.dilate && a.stride != 1)) return PMOE_ERR_ARG;
     if (a.N % a.ipe) return PMOE_ERR_ARG;
     const int E = a.N / a.ipe;
@@ -579,6 +579,12 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
     if (gemm_skinny_ok(a, dtype)) return gemm_skinny_launch(a, st);
     ResPlan plan;
     if (conv_res_plan(a, dtype, &plan)) return conv_res_launch(a, plan, st);
+    {
+        ConvArgs c = a;
+        int mb, pb;
+        size_t sm;
+        if (conv_dma_plan(c, dtype, &mb, &sm, &pb)) return conv_dma_launch(a, st);
+    }
     if (dtype == PMOE_DT_BF16) return launch_dtype<bf16>(a, st, nullptr);
     if (dtype == PMOE_DT_F32) return launch_dtype<float>(a, st, nullptr);
     return PMOE_ERR_ARG;
@@ -604,6 +610,10 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
     } else {
         ResPlan plan;
         if (conv_res_plan(a, dtype, &plan)) return 1000 + plan.log_rb;
+        ConvArgs d = a;
+        int mbd, pb;
+        size_t sm;
+        if (conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return 5007;          // conv3x3_dma_kernel
     }
     int mb = 0, cfg = 0;
     const int rc = dtype == PMOE_DT_BF16 ? launch_dtype<bf16>(c, nullptr, &mb, &cfg)
@@ -619,6 +629,12 @@ int conv_igemm_mblocks(const ConvArgs& a, int dtype) {
     }
     ResPlan plan;
     if (conv_res_plan(a, dtype, &plan)) return (a.N / a.ipe) * plan.wgs_per_expert;
+    {
+        ConvArgs d = a;
+        int mbd, pb;
+        size_t sm;
+        if (!gemm_skinny_ok(a, dtype) && conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return mbd;
+    }
     int mb = 0;
     int rc = (dtype == PMOE_DT_BF16) ? launch_dtype<bf16>(a, nullptr, &mb) : launch_dtype<float>(a, nullptr, &mb);
     return rc ? rc : mb;

@@ -69,9 +69,22 @@ class GroupedConv:
         self.taps = ks * ks
         self.w_fwd = self.w_dg = self.bias_packed = None
         self.need_dgrad = True
+        self.fp8_ok = False          # set for the ResNet layer1-4 convolutions (the fp8 policy's selection)
+        self.w_f8 = self.wscale = self.oscale = None
+
+    @property
+    def fp8(self):
+        """this layer's forward runs on e4m3 operands (BASELINE config 5: engine.fp8 + bf16 activations)"""
+        return self.fp8_ok and self.eng.fp8 and self.cin % 64 == 0 and self.cin >= self.eng.fp8_min_cin
 
     def alloc(self, dtype, dev):
         E = self.eng.E
+        if self.fp8 and dtype == torch.bfloat16:
+            self.w_f8 = torch.empty(E, self.coutp, self.taps, self.cinp, dtype=torch.uint8, device=dev)
+            self.wscale = torch.empty(E, self.coutp, dtype=F32, device=dev)
+            self.oscale = torch.empty(E, self.coutp, dtype=F32, device=dev)
+        else:
+            self.w_f8 = self.wscale = self.oscale = None
         self.w_fwd = torch.empty(E, self.coutp, self.taps, self.cinp, dtype=dtype, device=dev)
         self.w_dg = torch.empty(E, self.dg_rows, self.taps, self.dg_red, dtype=dtype, device=dev) if self.need_dgrad else None
         if self.biases is not None:
@@ -79,6 +92,11 @@ class GroupedConv:
 
     def pack(self, wtab, btab):
         E = self.eng.E
+        if self.w_f8 is not None:
+            # e4m3 forward operand + per-channel scales; the data-gradient operand holds the exactly dequantised weights
+            ops.pack_conv_weights_fp8(wtab, self.w_f8, self.w_dg, self.wscale, self.oscale, self.eng.fp8_in_scale, E,
+                                      self.cout, self.cin, self.ks, self.coutp, self.cinp, self.dg_rows, self.dg_red)
+            return
         ops.pack_conv_weights(wtab, self.w_fwd, self.w_dg, E, self.cout, self.cin, self.ks, self.coutp, self.cinp,
                               self.dg_rows, self.dg_red, self.w_fwd.dtype)
         if self.biases is not None:
@@ -128,6 +146,7 @@ class ExpertGroupEngine:
         self.dp_group = None          # torch.distributed process group for gradient all-reduce (None = WORLD)
         self.dp_enabled = False       # set by pmoe_amd.parallel-aware callers (bench.py, enable_data_parallel)
         self.dp_buckets = 6
+        self.dp_always = False        # issue the collectives even in a one-rank group (RCCL path on a single GPU)
         self._built_for = None
         self._seed_counter = itertools.count(1)
         self.fuse_conv_stats = True
@@ -140,6 +159,11 @@ class ExpertGroupEngine:
         self.fold_bn_eval = True      # inference: eval-mode BatchNorm folded into the conv weights / epilogue
         self.pooled_stem_bwd = True   # stem-tail BatchNorm reductions from the pooled tensors (train mode)
         self.fold_eca_gate = True     # ECA gate folded into per-image conv weights (no gated activation in memory)
+        # BASELINE config 5: e4m3 weights + e4m3 activations on the fp8 matrix cores for the layer1-4 forward convolutions
+        # (policy: include/pmoe_hip.h, pmoe_pack_conv_weights_fp8).  fp8_min_cin: smallest input-channel count that takes it
+        self.fp8 = False
+        self.fp8_in_scale = 16.0
+        self.fp8_min_cin = int(os.environ.get("PMOE_FP8_MIN_CIN", "64"))
         self.raw_alpha = False        # lone BaseExpert.forward: the gate kernel returns alpha itself instead of softmax(alpha)
         self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tests/experiments/probe_layers.py)
         self._collect()
@@ -236,6 +260,8 @@ class ExpertGroupEngine:
                 if blks[0].downsample is not None:
                     d["down"] = (conv(f"layer{li}.{bi}.down", [k.downsample[0] for k in blks]),
                                  bn(f"layer{li}.{bi}.downbn", [k.downsample[1] for k in blks]))
+                    d["down"][0].fp8_ok = True
+                d["conv1"].fp8_ok = d["conv2"].fp8_ok = True
                 self.blocks.append(d)
 
     def _collect_heads(self, ex):
@@ -267,11 +293,12 @@ class ExpertGroupEngine:
 
     # ------------------------------------------------------------------ buffers
     def _ensure_built(self, dev, dtype):
-        key = (str(dev), dtype)
+        key = (str(dev), dtype, self.fp8, self.fp8_min_cin)
         if self._built_for == key:
             return
         for layer in self.all_convs + ([self.head] if getattr(self.head, "parts", None) else []):
-            if layer.w_fwd is None or layer.w_fwd.dtype != dtype or layer.w_fwd.device != dev:
+            if (layer.w_fwd is None or layer.w_fwd.dtype != dtype or layer.w_fwd.device != dev
+                    or (layer.w_f8 is not None) != (layer.fp8 and dtype == torch.bfloat16)):
                 layer.alloc(dtype, dev)
         self._ptr_key = None
         self._packed_version = None
@@ -358,17 +385,18 @@ class ExpertGroupEngine:
         else:
             o = out.window(out_coff, layer.cout_st)
         stats = None
+        f8 = layer.w_f8 is not None and bias is False and act == hip.ACT_NONE
         if want_stats:
             rows = ops.conv2d_stat_rows(self.N, H, W, Ho, Wo, layer.cinp, layer.cout_st, layer.coutp, self.B, layer.ks,
-                                        layer.stride, layer.pad, self.dtype)
+                                        layer.stride, layer.pad, self.dtype, w_fp8=f8)
             stats = torch.empty(rows, 2, layer.coutp, dtype=F32, device=self.dev)
         seed = (next(self._seed_counter) * 0x9E3779B1 + self.base_seed) & 0xFFFFFFFFFFFF if drop_p > 0 else 0
         flop = 2.0 * self.N * Ho * Wo * layer.cout * layer.cin * layer.taps
         ops.set_meta(flop=flop, name=layer.name)
-        ops.conv2d(x.t, layer.w_fwd, o.t, cin=layer.cinp, cout=layer.cout_st, coutp=layer.coutp, ipe=self.B,
-                   ks=layer.ks, stride=layer.stride, pad=layer.pad, in_shared=in_shared, in_coff=x.coff,
+        ops.conv2d(x.t, layer.w_f8 if f8 else layer.w_fwd, o.t, cin=layer.cinp, cout=layer.cout_st, coutp=layer.coutp,
+                   ipe=self.B, ks=layer.ks, stride=layer.stride, pad=layer.pad, in_shared=in_shared, in_coff=x.coff,
                    out_coff=o.coff, bias=layer.bias_packed if bias else None, act=act, drop_p=drop_p, seed=seed,
-                   stats=stats)
+                   stats=stats, out_scale=layer.oscale if f8 else None, in_scale=self.fp8_in_scale)
         o.act, o.drop_p = act, drop_p
         o.needs_grad = x.needs_grad or layer.trainable
         if out is not None and o.needs_grad:
@@ -917,7 +945,7 @@ class ExpertGroupEngine:
         """[relu](bn(conv(x)) [+ res]).  Training / taped: conv (+ fused statistics) then the BatchNorm passes.
         Inference (eval mode, nothing taped): the BatchNorm is FOLDED into the conv -- weights scaled per output channel,
         beta - mean*scale as the bias, residual add and ReLU in the conv epilogue: no pass over the activation at all."""
-        if self.training or self.taping or not self.fold_bn_eval:
+        if self.training or self.taping or not self.fold_bn_eval or conv.w_f8 is not None:      # (the fp8 policy is not folded)
             z, st = self._conv_stats(x, conv)
             return self._bn(z, bn, relu=relu, res=res, stats=st, out=out)
         E = self.E
@@ -1080,7 +1108,7 @@ class ExpertGroupEngine:
         self._filled, self._cursor = set(), 0
         reducer = None
         if self.dp_group is not None or (dist.is_initialized() and self.dp_enabled):
-            reducer = BucketedAllReduce(self.dp_group, self.dp_buckets)
+            reducer = BucketedAllReduce(self.dp_group, self.dp_buckets, self.dp_always)
             reducer.begin(self._arena)
         self._tail_bwd(tape_state["tail"], *douts)
         main = torch.cuda.current_stream()

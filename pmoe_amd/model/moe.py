@@ -70,6 +70,8 @@ class _Grouped(nn.Module):
     """Shared forward plumbing of modules that own a list of experts."""
 
     compute_dtype = None      # None -> module-level default (bf16)
+    fp8_weights = False       # True (with bf16 compute): BASELINE config 5 -- the ResNet layer1-4 forward convolutions run on
+                              # e4m3 weights / e4m3 activations and the fp8 matrix cores (pmoe_conv_desc.w_fp8)
 
     def _engine(self):
         eng = self.__dict__.get("_eng")
@@ -102,16 +104,18 @@ class _Grouped(nn.Module):
     def _run(self, images, speed, command):
         eng = self._engine()
         dtype = self.compute_dtype or _DEFAULT_DTYPE
+        eng.fp8 = bool(self.fp8_weights) and dtype == torch.bfloat16
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if self.training else 0
         # grad mode is off inside Function.forward, so decide here whether a backward tape is needed
         taping = torch.is_grad_enabled() and any(p.requires_grad for p in eng.flat_params)
         return _GroupFn.apply(eng, images, speed, command, self.training, dtype, seed, taping, *eng.flat_params)
 
-    def enable_data_parallel(self, group=None, n_buckets=6):
+    def enable_data_parallel(self, group=None, n_buckets=6, always=False):
         """Average parameter gradients over ``group`` (default WORLD) inside backward, bucketed and
-        overlapped (pmoe_amd.parallel.BucketedAllReduce)."""
+        overlapped (pmoe_amd.parallel.BucketedAllReduce).  ``always``: issue the collectives even in a one-rank group
+        (exercises the RCCL path on a single GPU)."""
         eng = self._engine()
-        eng.dp_group, eng.dp_enabled, eng.dp_buckets = group, True, n_buckets
+        eng.dp_group, eng.dp_enabled, eng.dp_buckets, eng.dp_always = group, True, n_buckets, always
         return self
 
 

@@ -28,14 +28,17 @@ def _nhwc(t, name):
 
 def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=False, in_shared=False,
            in_coff=0, out_coff=0, res=None, res_coff=0, res_mode=hip.RES_NONE, bias=None, act=hip.ACT_NONE,
-           drop_p=0.0, seed=0, stats=None, plan_only=False):
+           drop_p=0.0, seed=0, stats=None, plan_only=False, out_scale=None, in_scale=1.0):
     """out[..., out_coff:out_coff+cout] = epilogue(conv(x[..., in_coff:in_coff+cin], w)).
     ``x`` [Nin,H,W,ldx], ``out`` [N,Ho,Wo,ldo] preallocated; also used for dgrad and grouped GEMM.
     ``plan_only``: launch nothing, return the kernel-instantiation code of ``pmoe_conv2d_plan`` (include/pmoe_hip.h)."""
     nin, h, w_, ldx = _nhwc(x, "x")
     n, ho, wo, ldo = _nhwc(out, "out")
-    if x.dtype != out.dtype or w_packed.dtype != x.dtype:
+    w_fp8 = w_packed.dtype == torch.uint8          # e4m3 bytes (pack_conv_weights_fp8): BASELINE config 5
+    if x.dtype != out.dtype or (w_packed.dtype != x.dtype and not w_fp8):
         raise ValueError("conv2d: x, w and out must share one dtype")
+    if w_fp8 and (out_scale is None or x.dtype != torch.bfloat16):
+        raise ValueError("conv2d: e4m3 weights need bf16 activations and the per-channel out_scale of the pack")
     d = ConvDesc()
     d.in_, d.w, d.out = ptr(x, "x"), ptr(w_packed, "w"), ptr(out, "out")
     d.res = ptr(res, "res", x.dtype) if res is not None else None
@@ -50,6 +53,8 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
     d.ks, d.stride, d.pad, d.dilate = ks, stride, pad, int(dilate)
     d.act, d.res_mode = act, res_mode if res is not None else hip.RES_NONE
     d.drop_p, d.seed, d.dtype = float(drop_p), int(seed), dt(x)
+    if w_fp8:
+        d.w_fp8, d.in_scale, d.out_scale = 1, float(in_scale), ptr(out_scale, "out_scale", torch.float32)
     if in_shared and nin != ipe:
         raise ValueError("conv2d: shared input must hold exactly ipe images")
     if not in_shared and nin != n:
@@ -64,8 +69,9 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
     return out
 
 
-def conv2d_stat_rows(n, h, w_, ho, wo, cin, cout, coutp, ipe, ks, stride, pad, dtype):
+def conv2d_stat_rows(n, h, w_, ho, wo, cin, cout, coutp, ipe, ks, stride, pad, dtype, w_fp8=False):
     d = ConvDesc()
+    d.w_fp8, d.in_scale = int(w_fp8), 1.0
     d.n, d.h, d.w_, d.cin, d.ho, d.wo, d.cout, d.coutp = n, h, w_, cin, ho, wo, cout, coutp
     d.ipe, d.ks, d.stride, d.pad, d.dtype = ipe, ks, stride, pad, hip._TORCH_DT[dtype]
     rows = load().pmoe_conv2d_stat_rows(C.byref(d))
@@ -119,6 +125,15 @@ def pack_conv_weights(ptr_tab, fwd, dgrd, E, cout, cin, ks, coutp, cinp, cinp2, 
     check(load().pmoe_pack_conv_weights(ptr(ptr_tab, "ptr table", torch.int64), ptr(fwd), ptr(dgrd), E, cout, cin, ks,
                                         coutp, cinp, cinp2, coutp2, hip._TORCH_DT[dtype], stream_ptr()),
           "pmoe_pack_conv_weights")
+
+
+def pack_conv_weights_fp8(ptr_tab, fwd, dgrd, wscale, oscale, in_scale, E, cout, cin, ks, coutp, cinp, cinp2, coutp2):
+    """e4m3 weight pack with one power-of-two scale per output channel (include/pmoe_hip.h)."""
+    check(load().pmoe_pack_conv_weights_fp8(ptr(ptr_tab, "ptr table", torch.int64), ptr(fwd, "fwd", torch.uint8),
+                                            ptr(dgrd, "dgrd", torch.bfloat16) if dgrd is not None else None,
+                                            ptr(wscale, "wscale", torch.float32), ptr(oscale, "oscale", torch.float32),
+                                            float(in_scale), E, cout, cin, ks, coutp, cinp, cinp2, coutp2, stream_ptr()),
+          "pmoe_pack_conv_weights_fp8")
 
 
 def pack_conv_weights_scaled(ptr_tab, scale, shift, mean, fwd, bias, E, cout, cin, ks, coutp, cinp, dtype):

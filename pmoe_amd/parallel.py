@@ -18,10 +18,13 @@ import torch.distributed as dist
 
 
 class BucketedAllReduce:
-    def __init__(self, group=None, n_buckets=6):
+    last_issued = 0          # collectives launched by the most recent backward of this process (bench.py / tests report it)
+
+    def __init__(self, group=None, n_buckets=6, always=False):
         self.group = group
         self.n_buckets = max(1, int(n_buckets))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.single = self.world == 1 and not (always and dist.is_initialized())    # nothing to exchange
         self._avg_native = dist.is_initialized() and dist.get_backend(group) == "nccl"
 
     def begin(self, arena):
@@ -32,8 +35,11 @@ class BucketedAllReduce:
         self.works = []
 
     def ready(self, upto, final=False):
-        """Elements [0, upto) of the arena are final (their kernels are enqueued on the current stream)."""
-        if self.world == 1:
+        """Elements [0, upto) of the arena are final: every kernel that writes them is enqueued on the CURRENT stream or on
+        a stream the current one already waits for.  (The collective orders itself after the current stream at the moment
+        of the call; with weight gradients on a side stream the engine calls this from that side stream after making it
+        wait for the main one -- engine.backward -- so both producers are covered.)"""
+        if self.single:
             return
         n = self.arena.numel()
         limit = n if final else (min(upto, n) // self.bucket) * self.bucket
@@ -49,13 +55,14 @@ class BucketedAllReduce:
 
     def finish(self):
         """Flush the tail and make the current stream wait for every bucket."""
-        if self.world == 1:
+        if self.single:
             return
         self.ready(self.arena.numel(), final=True)
         for w, chunk in self.works:
             w.wait()
             if not self._avg_native:
                 chunk.mul_(1.0 / self.world)
+        BucketedAllReduce.last_issued = len(self.works)
         self.works = []
 
 

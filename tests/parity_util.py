@@ -31,9 +31,12 @@ TOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
 # bf16 forward bound, measured instead of flat: tests/golden/bf16_bounds.pt (oracle/make_bounds.py)
 # holds, per golden case and output, the float64 oracle's value and the error of the bf16-STORAGE-emulating oracle
 # (oracle/bf16_emulation.py: weights and every layer output rounded to bf16, f32 arithmetic) against it.  The HIP bf16
-# path must be within BF16_SLACK x that error of the float64 truth, output by output (metric max |d| / (1 + |ref|); the
-# larger of the two emulation variants, "every layer stored" / "BatchNorm passes fused", is the yardstick).
+# path must be within north_star's 1e-2 of the float64 truth, or -- where the storage format itself makes that impossible
+# -- within BF16_SLACK x the emulation's own error, output by output (metric max |d| / (1 + |ref|)).  That error is a
+# maximum over a few dozen values, i.e. a random quantity: the yardstick is the largest of 14 draws of it (two emulation
+# variants, "every layer stored" / "BatchNorm passes fused", on the golden inputs and on 6 copies with images jittered by 1 %).
 BF16_SLACK = 1.25
+BF16_FLOOR = 1e-2
 _BOUNDS = None
 
 
@@ -56,8 +59,13 @@ def bf16_fwd_report(name, outs):
     for k, got in outs.items():
         ref = b["f64"][k]
         err = ((got.detach().double().cpu() - ref).abs() / (1 + ref.abs())).max().item()
-        rep[k] = (err, max(b["emul"][v][k][0] for v in b["emul"]))
+        rep[k] = (err, max(BF16_FLOOR / BF16_SLACK, emul_worst(b["emul"], k)))
     return rep
+
+
+def emul_worst(draws, k):
+    """largest max-metric error of output ``k`` over all variants and draws of an emulation record."""
+    return max(d[k][0] for v in draws for d in draws[v])
 GRAD_TOL = {torch.float32: 2e-2, torch.bfloat16: None}
 GRAD_MEDIAN_TOL = 5e-3
 

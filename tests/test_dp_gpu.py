@@ -99,3 +99,26 @@ def test_engine_gradient_allreduce_two_ranks_one_gpu(kind):
         # deterministic backward (no float atomics): the all-reduced gradient IS the mean of the local gradients, up to
         # the f32 rounding of gloo's own sum
         assert err <= 1e-6, (kind, rank, err)
+
+
+def test_rccl_branch_runs_on_one_gpu():
+    """the `nccl` (= RCCL) branch of bench.py / pmoe_amd.parallel had never executed anywhere.  bench.py
+    under torch.distributed.run with ONE rank: RCCL communicator init (before the first GPU call of the rank), the weight
+    broadcast, ReduceOp.AVG on every arena bucket launched from the engine's backward, the bucket waits, barrier and
+    max-over-ranks timing -- everything the N-GPU job does except moving bytes between devices."""
+    import json
+    import subprocess
+    import sys
+    repo = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(repo / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--batch", "8", "--size", "128", "--no-cpu-baseline", "--no-stage1", "--no-sub-configs"]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["parallelism"] == "dp1"
+    assert out["allreduce_model"]["gradient_bytes"] == 4 * 55373360          # E=4 MixtureOfExperts (SURVEY.md section 6)
+    # the collectives really ran: bench logs the backend and the bucket count it issued
+    assert out.get("dp", {}).get("backend") == "nccl" and out["dp"]["buckets_issued_per_backward"] == 6, out.get("dp")

@@ -1,0 +1,208 @@
+"""BASELINE config 5 (-m gpu): e4m3 weights + e4m3 activations on the fp8 matrix cores for the ResNet layer1-4 forward
+convolutions (replacing the weight operand of nn.Conv2d at model/blocks/backbone.py:57-70 as built by torchvision's
+BasicBlock).  The reference has no fp8 path, so the yardstick is the CPU statement of the policy, oracle/fp8_policy.py:
+
+  * the quantisers are BYTE work and are held bit-exact (weight bytes, power-of-two scales, dequantised data-gradient
+    operand, activation conversion);
+  * a convolution on those operands against F.conv2d on the CPU-quantised operands: only the f32 summation order and the
+    bf16 rounding of the output differ;
+  * the whole network: error against the float64 oracle <= 1.25 x the error of the oracle with bf16 storage + the same
+    fp8 policy emulated (largest of 14 draws; tests/golden/bf16_bounds.pt, oracle/make_bounds.py).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fp8_policy as P  # noqa: E402
+from pmoe_amd import hip, ops  # noqa: E402
+from tests.test_ops_gpu import DEV, from_nhwc, nhwc, r16, r64, rnd  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def _pack8(ws, ks, in_scale=P.IN_SCALE):
+    E = len(ws)
+    cout, cin = ws[0].shape[:2]
+    dev_ws = [w.to(DEV).contiguous() for w in ws]
+    tab = hip.ptr_table(dev_ws, DEV)
+    coutp, cinp, cinp2, coutp2 = r64(cout), r16(cin), r64(cin), r16(cout)
+    f8 = torch.empty(E, coutp, ks * ks, cinp, dtype=torch.uint8, device=DEV)
+    dg = torch.empty(E, cinp2, ks * ks, coutp2, dtype=BF, device=DEV)
+    wscale = torch.empty(E, coutp, device=DEV)
+    oscale = torch.empty(E, coutp, device=DEV)
+    ops.pack_conv_weights_fp8(tab, f8, dg, wscale, oscale, in_scale, E, cout, cin, ks, coutp, cinp, cinp2, coutp2)
+    torch.cuda.synchronize()
+    return f8, dg, wscale, oscale, dev_ws
+
+
+def test_weight_quantiser_is_bit_exact():
+    """bytes, scales and the dequantised data-gradient operand equal the CPU policy exactly -- including an all-zero row,
+    rows whose maximum is exactly 448 * 2^k (the ceil(log2) edge), e4m3 subnormals and values that round up to the next
+    binade."""
+    g = torch.Generator().manual_seed(8)
+    E, cout, cin, ks = 2, 70, 64, 3
+    ws = []
+    for e in range(E):
+        w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        w[3] = 0.0                                          # all-zero row: scale 1
+        w[4] *= 1e-4
+        w[5] = w[5] / w[5].abs().max() * 448.0 * 2.0 ** -5   # amax exactly on the power-of-two edge
+        w[6] = w[6] / w[6].abs().max() * 448.0 * 2.0 ** 3
+        w[7, 0, 0, 0] = w[7].abs().max() * 300                # one dominant element: the rest falls into the subnormals
+        w[8] = torch.linspace(-1, 1, cin * 9).view(cin, 3, 3) * 2.0 ** -3
+        ws.append(w)
+    f8, dg, wscale, oscale, _ = _pack8(ws, ks)
+    for e in range(E):
+        s = P.row_scale(ws[e])
+        assert torch.equal(wscale[e, :cout].cpu(), s)
+        assert torch.equal(oscale[e, :cout].cpu(), s / P.IN_SCALE)
+        want = P.e4m3_bytes(ws[e] / s.view(-1, 1, 1, 1))                        # [cout][cin][ky][kx]
+        got = f8[e, :cout].cpu().view(cout, 3, 3, r16(cin))[..., :cin].permute(0, 3, 1, 2)
+        # -0 and +0 are the same number: compare bytes modulo the sign of zero
+        a, b = got.clone(), want.clone()
+        a[a == 0x80] = 0
+        b[b == 0x80] = 0
+        assert torch.equal(a, b)
+        assert f8[e, cout:].abs().max().item() == 0                               # padded output rows
+        deq = P.qdq_weight(ws[e])
+        gd = dg[e, :cin, :, :cout].float().cpu()                                  # [cin][tap flipped][cout]
+        wd = deq.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9, cout)
+        assert torch.equal(gd, wd)                                                # q * s is exact in bf16
+
+
+def test_activation_conversion_is_bit_exact():
+    """a 1x1 convolution with identity e4m3 weights returns the converted input itself: e4m3(bf16(x) * 16) / 16, round to
+    nearest even, saturating at 448 / 16 -- subnormals, ties and overflow included."""
+    C = 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, C, 16, 24, generator=g)
+    x[0, :, 0] *= 1e-3                                        # e4m3 subnormals after the x16 scale
+    x[0, :, 1] *= 40.0                                        # beyond 28: saturates
+    x[1, :, 2, :] = (torch.arange(24).float() / 16 / 16).view(1, 24)      # exact ties at every step of the subnormal grid
+    x[1, :, 3, :] = (17.0 + torch.arange(24).float()) / 16 / 8 + 1.0 / 256   # ties in the normal range
+    xb = x.to(BF).float()
+    w = [torch.eye(C).view(C, C, 1, 1)]
+    f8, _, _, oscale, _ = _pack8(w, 1)
+    xd = nhwc(xb, C, BF)
+    out = torch.empty(2, 16, 24, C, dtype=BF, device=DEV)
+    ops.conv2d(xd, f8, out, cin=C, cout=C, coutp=C, ipe=2, ks=1, stride=1, pad=0, out_scale=oscale, in_scale=P.IN_SCALE)
+    assert torch.equal(from_nhwc(out, C), P.qdq_act(xb))
+
+
+FP8_CONV_CASES = [
+    # (E, ipe, cin, cout, H, W, ks, stride), kernel code (8000 + the bf16 code of the same tile, include/pmoe_hip.h)
+    ((1, 4, 128, 128, 64, 64, 3, 1), 10007),        # layer2: LITE tile, 128-channel chunks
+    ((1, 8, 256, 256, 32, 32, 3, 1), 10007),        # layer3
+    ((2, 32, 512, 512, 16, 16, 3, 1), 10007),       # layer4
+    ((2, 2, 64, 64, 128, 128, 3, 1), 8641),         # layer1: 64-channel chunks
+    ((1, 4, 64, 128, 128, 128, 3, 2), 8642),        # layer2.0.conv1 (stride 2)
+    ((1, 4, 64, 128, 128, 128, 1, 2), 8642),        # layer2.0.downsample
+    ((2, 3, 128, 256, 14, 14, 3, 2), None),         # small maps / ragged tiles
+    ((3, 1, 512, 512, 7, 7, 3, 1), None),
+]
+
+
+@pytest.mark.parametrize("case,plan", FP8_CONV_CASES)
+def test_conv_fp8_forward(case, plan):
+    E, ipe, cin, cout, H, W, ks, stride = case
+    g = torch.Generator().manual_seed(sum(case))
+    pad = ks // 2
+    N = E * ipe
+    x = torch.relu(rnd((N, cin, H, W), g, BF)) * 1.5                       # post-ReLU activations, like the real inputs
+    x = x.to(BF).float()
+    ws = [rnd((cout, cin, ks, ks), g, torch.float32, (2.0 / (cin * ks * ks)) ** 0.5) for _ in range(E)]
+    Ho, Wo = ops.conv_out_size(H, ks, stride, pad), ops.conv_out_size(W, ks, stride, pad)
+    ref = torch.cat([F.conv2d(P.qdq_act(x[e * ipe:(e + 1) * ipe]), P.qdq_weight(ws[e]), stride=stride, padding=pad)
+                     for e in range(E)])
+    f8, _, _, oscale, _ = _pack8(ws, ks)
+    xd = nhwc(x, cin, BF)
+    out = torch.full((N, Ho, Wo, r16(cout)), 7.0, dtype=BF, device=DEV)
+    kw = dict(cin=cin, cout=cout, coutp=r64(cout), ipe=ipe, ks=ks, stride=stride, pad=pad, out_scale=oscale,
+              in_scale=P.IN_SCALE)
+    if plan is not None:
+        got = ops.conv2d(xd, f8, out, plan_only=True, **kw)
+        assert got == plan, f"routed to kernel code {got}, this case is meant for {plan}"
+    rows = ops.conv2d_stat_rows(N, H, W, Ho, Wo, cin, cout, r64(cout), ipe, ks, stride, pad, BF, w_fp8=True)
+    stats = torch.zeros(rows, 2, r64(cout), device=DEV)
+    ops.conv2d(xd, f8, out, stats=stats, **kw)
+    y = from_nhwc(out, cout)
+    # the products are exact in f32 (two e4m3 factors), so only the summation order and the bf16 output rounding differ
+    err = (y - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3 * ref.abs().max()).all(), (err.max().item(), ref.abs().max().item())
+    st = stats.view(E, rows // E, 2, r64(cout)).sum(1).cpu()
+    yo = out.float().cpu()[..., :cout].reshape(E, -1, cout)
+    assert ((st[:, 0, :cout] - yo.sum(1)).abs().max() / yo.sum(1).abs().max()).item() <= 1e-3
+
+
+def _run_model(name, fp8):
+    from tests.parity_util import GOLDEN, build_pair
+    g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
+    ocfg, oracle, model, inp = build_pair(g, BF)
+    model.fp8_weights = fp8
+    dev = {k: v.cuda() for k, v in inp.items()}
+    return g, ocfg, oracle, model, inp, dev
+
+
+@pytest.mark.parametrize("name", ["g1_moe_e4_b2_128", "g5_moe_e3_b3_96", "g10_moe_e4_b32_64", "g2_moe_e4_b1_224_eval"])
+def test_model_fp8_forward_within_the_emulated_policy(name):
+    """E2E forward of the 4-expert mixture with the fp8 policy: per output, the distance to the float64 oracle is at most
+    1.25 x that of the CPU oracle with bf16 storage + the same fp8 policy emulated."""
+    from tests.parity_util import BF16_SLACK, bf16_bounds, emul_worst
+    g, ocfg, oracle, model, inp, dev = _run_model(name, True)
+    with torch.no_grad():
+        dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+    probs, mean, std = dist.hip_params
+    b = bf16_bounds(name)
+    rep = {}
+    for k, got in dict(probs=probs, mean=mean, std=std, speeds=speeds).items():
+        ref = b["f64"][k]
+        err = ((got.double().cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        emul = emul_worst(b["emul_fp8"], k)
+        rep[k] = (err, emul)
+    print(name, "fp8", {k: "%.2e vs emul %.2e" % v for k, v in rep.items()})
+    for k, (err, emul) in rep.items():
+        assert err <= BF16_SLACK * emul, (name, k, err, emul)
+    # and it is really the fp8 path: the result differs from the bf16 run of the same model
+    model.fp8_weights = False
+    with torch.no_grad():
+        d2, _ = model(dev["images"], dev["speed"], dev["command"])
+    assert not torch.equal(d2.hip_params[1], mean)
+
+
+def test_model_fp8_train_step():
+    """fwd + moe_loss + bwd with the fp8 forward: finite gradients for every parameter, aligned with the f32 oracle's
+    (straight-through data gradient on exactly dequantised weights), BatchNorm buffers updated, deterministic."""
+    from pmoe_amd.loss import moe_loss
+    from oracle import pmoe_oracle as O
+    g, ocfg, oracle, model, inp, dev = _run_model("g10_moe_e4_b32_64", True)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+        loss = moe_loss(dist, speeds, dev["control"], dev["target_speed"], ocfg.loss_coefs)
+        loss.backward()
+        return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters()}
+    import copy
+    sd = copy.deepcopy(model.state_dict())
+    l1, g1 = step()
+    model.load_state_dict(sd)
+    l2, g2 = step()
+    assert l1 == l2 and all(torch.equal(g1[k], g2[k]) for k in g1)
+    od, os_ = oracle(inp["images"], inp["speed"], inp["command"])
+    O.moe_loss(od, os_, inp["control"], inp["target_speed"], ocfg.loss_coefs).backward()
+    ref = {k: p.grad for k, p in oracle.named_parameters()}
+    assert abs(l1 - g["loss"].item()) <= 5e-2 * max(1.0, abs(g["loss"].item()))
+    cos = sorted(F.cosine_similarity(g1[k].flatten().cpu().float(), ref[k].flatten(), dim=0).item()
+                 for k in g1 if g1[k].numel() >= 1024)
+    tot = sum(v.float().norm().item() ** 2 for v in g1.values()) ** 0.5
+    tot_ref = sum(v.norm().item() ** 2 for v in ref.values()) ** 0.5
+    from tests.parity_util import bf16_bounds
+    emul_cos = bf16_bounds("g10_moe_e4_b32_64")["emul_fp8_grad_median_cos"]
+    print("fp8 train step: median grad cosine %.3f (the emulated policy on the CPU: %.3f), total norm ratio %.3f"
+          % (cos[len(cos) // 2], emul_cos, tot / tot_ref))
+    assert all(torch.isfinite(v).all() for v in g1.values())
+    # as well aligned with the f32 oracle's gradients as the CPU emulation of the same policy is (fp8 noise in the forward
+    # decorrelates the gradients of this random-weight network far more than bf16 does: DESIGN.md "numerics")
+    assert cos[len(cos) // 2] >= emul_cos - 0.1 and abs(tot - tot_ref) <= 0.25 * tot_ref

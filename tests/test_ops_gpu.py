@@ -166,9 +166,11 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
 # parity test).  Codes: include/pmoe_hip.h pmoe_conv2d_plan; the third number = workgroups of the weight-gradient launch.
 BASELINE_CONV_CASES = [
     # (E, ipe, cin, cout, H, W, ks, stride), (fwd, dgrad, wgrad workgroups)
-    ((1, 4, 128, 128, 64, 64, 3, 1), (2007, 2007, 256)),       # layer2: conv_igemm_lite_kernel<bf16,7>, 2 channel chunks
-    ((1, 8, 256, 256, 32, 32, 3, 1), (2007, 2007, 256)),       # layer3: 4 chunks, 8 images per 256-pixel tile column
-    ((2, 32, 512, 512, 16, 16, 3, 1), (2007, 2007, 256)),      # layer4: 8 chunks, one image per tile, 2 experts
+    ((1, 4, 128, 128, 64, 64, 3, 1), (5007, 5007, 256)),       # layer2: conv3x3_dma_kernel (LDS-DMA), 2 channel chunks
+    ((1, 8, 256, 256, 32, 32, 3, 1), (5007, 5007, 256)),       # layer3: 4 chunks, 32 x 8 pixel tiles
+    ((2, 32, 512, 512, 16, 16, 3, 1), (5007, 5007, 256)),      # layer4: 8 chunks, one 16 x 16 image per tile (two patch rows per
+                                                               # 32-lane fragment: the column-keyed swizzle), 2 experts
+    ((1, 5, 128, 256, 40, 24, 3, 1), (5007, 5007, 200)),       # ragged: 24-wide rows in 32-wide tiles, 40 rows in strips of 8, 5 images
     ((1, 1, 64, 64, 256, 256, 3, 1), (1007, 1007, 256)),       # stem conv2: conv3x3_res_kernel<7>, 256 tiles of one image
     ((2, 2, 64, 64, 128, 128, 3, 1), (1007, 1007, 256)),       # layer1: resident kernel, persistent workgroups per expert
     ((1, 4, 64, 128, 128, 128, 3, 2), (642, 4741, 256)),       # layer2.0.conv1: stride-2 forward, parity-class data gradient
