@@ -5,8 +5,9 @@
 // halo patch of a 64-channel chunk staged ONCE in LDS and read by all 9 taps at shifted addresses), but every byte reaches
 // LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no VALU, and the requests stay in flight across the
 // per-tap barriers behind COUNTED `s_waitcnt vmcnt(N)`:
-//   * weights  : ring of 4 tap tiles [128 couts][128 B]; the tile of tap t+2 is requested at tap t into the slot last read
-//                at tap t-2 (two barriers earlier);
+//   * weights  : ring of 4 tap tiles [128 couts][128 B]; the tile of tap t+3 is requested at tap t into the slot last read
+//                at tap t-1, and the tile of tap t+1 is already visible during tap t, so the fragments of the next tap's
+//                first k-step are read under the last MFMAs of the current one (no LDS round trip after a barrier);
 //   * patches  : 2 buffers; the NEXT chunk's halo patch is requested piece by piece (1 KiB per wave-instruction) at taps
 //                1..6 of the current chunk; pixels outside the image / beyond the expert's last image are zero-filled by the
 //                buffer's range check (their offset is parked beyond num_records) -- the halo costs no instructions;
@@ -33,8 +34,20 @@ __device__ __forceinline__ int cswz(int x) { return (x >> 1) & 7; }
 
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// -DPMOE_STAMP (tools/stamp_conv.py only, never the product build): s_memtime laps of the four phases of a workgroup's life
+// + its wall time (s_memrealtime, 100 MHz) land in a.stats instead of the BatchNorm partial sums.
+#ifdef PMOE_STAMP
+#define STAMP_INIT unsigned long long st_prev = __builtin_amdgcn_s_memtime(); const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime(); unsigned st_acc[4] = {0, 0, 0, 0};
+#define LAP(i) { const unsigned long long st_t = __builtin_amdgcn_s_memtime(); st_acc[i] += (unsigned)(st_t - st_prev); st_prev = st_t; }
+#else
+#define STAMP_INIT
+#define LAP(i)
+#endif
+
+template <int VARIANT>
 __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, const int pbuf_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    STAMP_INIT
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -132,12 +145,31 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
     const int nchunks = a.Cin / CK;
     const int T = nchunks * 9;
 
-    // ---- prologue: patch of chunk 0, weight tiles of taps 0 and 1
+    // ---- prologue: patch of chunk 0, weight tiles of taps 0..2; the fragments of (tap 0, k-step 0) once they are visible
 #pragma unroll
     for (int i = 0; i < 6; ++i)
         if (i < my_pieces) dma_patch(i, 0, 0);
     dma_w(0, 0, 0);
     dma_w(1, 1, 0);
+    dma_w(2, 2, 0);
+    VMCNT(4);                                            // all but W(1), W(2): the patch and W(0) are in LDS
+    __builtin_amdgcn_s_barrier();
+    LAP(0)                                               // prologue: descriptors, offsets, first patch + weight tile landed
+
+    // fragment double buffer: k-step ks of a tap lives in set ks & 1; the set of (tap t+1, k-step 0) is read under the last
+    // MFMAs of tap t -- its weight tile W(t+1) is already visible by then (the wait at the top of tap t covers it), so a wave
+    // never starts a tap with an LDS round trip in front of its first MFMA
+    v4i af[2][2], bfr[2][2];
+    auto read_frags = [&](int set, const char* wt, const char* patch, int tap, int ks) {
+        const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RB;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) af[set][nt] = *reinterpret_cast<const v4i*>(wt + aoff[nt][ks]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            bfr[set][mt] = *reinterpret_cast<const v4i*>(patch + pbase[mt] + tapoff +
+                                                         (((ks * 2 + h) ^ cswz(pcol[mt] + (tap % 3))) << 4));
+    };
+    read_frags(0, wring, smem, 0, 0);
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
@@ -146,47 +178,62 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int tt = ch * 9 + tap;
-            // W(tt) has landed for this wave once at most {W(tt+1), the patch piece issued in the previous iteration}
-            // are outstanding (vmcnt counts in issue order)
+            // W(tt+1) has landed for this wave once at most {W(tt+2), the patch piece issued in the previous iteration} are
+            // outstanding (vmcnt counts in issue order); the patch of the next chunk is older than its first weight tile
             const bool prev_piece = tap >= 2 && tap <= 7 && more && (tap - 2) < my_pieces;
-            if (tt + 1 >= T) VMCNT(0);
+            if (tt + 2 >= T) VMCNT(0);
             else if (prev_piece) VMCNT(3);
             else VMCNT(2);
-            __builtin_amdgcn_s_barrier();                // every wave's share of tap tt (and of this chunk's patch) is in LDS
-            if (tap >= 1 && tap <= 6 && more && (tap - 1) < my_pieces) dma_patch(tap - 1, (ch + 1) & 1, c0 + CK);
-            if (tt + 2 < T) {
-                int ntap = tap + 2, nc0 = c0;
-                if (ntap >= 9) { ntap -= 9; nc0 += CK; }
-                dma_w((tt + 2) & (RING - 1), ntap, nc0);
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot about to be refilled are back
+            if (VARIANT != 4)                            // (4: timing experiment only, wrong results: no per-tap barrier)
+            __builtin_amdgcn_s_barrier();                // publishes W(tt+1) (+ the next chunk's patch); slot (tt-1) & 3 is free
+            // this tap's DMA requests go out BETWEEN the MFMA groups, and at different points for the two waves of a SIMD
+            // (waves w and w + 4): issued right behind the barrier by all 8 waves at once they left the matrix pipes idle
+            // for ~300 cycles per tap; now one wave's request issue runs under its partner's MFMAs
+            auto issue_dma = [&]() {
+                if (VARIANT == 3) return;                // timing experiment only (wrong results): no main-loop DMA
+                if (tap >= 1 && tap <= 6 && more && (tap - 1) < my_pieces) dma_patch(tap - 1, (ch + 1) & 1, c0 + CK);
+                if (tt + 3 < T) {
+                    int ntap = tap + 3, nc0 = c0;
+                    if (ntap >= 9) { ntap -= 9; nc0 += CK; }
+                    dma_w((tt + 3) & (RING - 1), ntap, nc0);
+                }
+            };
+            if (VARIANT == 0) issue_dma();
+            if (VARIANT == 2 && wave < 4) issue_dma();   // older half right behind the barrier, younger half mid-tap
             const char* wt = wring + (tt & (RING - 1)) * WSLOT;
-            const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RB;
-            int bsw[2];
-            const char* bp[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                bp[mt] = patch + pbase[mt] + tapoff;
-                bsw[mt] = cswz(pcol[mt] + (tap % 3));
-            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                v4i af[2], bfr[2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) af[nt] = *reinterpret_cast<const v4i*>(wt + aoff[nt][ks]);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    bfr[mt] = *reinterpret_cast<const v4i*>(bp[mt] + (((ks * 2 + h) ^ bsw[mt]) << 4));
+                if (VARIANT == 2 && ks == 2 && wave >= 4) {
+                    issue_dma();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks < 3) {
+                    read_frags((ks + 1) & 1, wt, patch, tap, ks + 1);
+                } else if (tt + 1 < T) {                 // first k-step of the next tap (next chunk's patch after tap 8)
+                    read_frags(0, wring + ((tt + 1) & (RING - 1)) * WSLOT,
+                               tap == 8 ? smem + ((ch + 1) & 1) * pbuf_bytes : patch, tap == 8 ? 0 : tap + 1, 0);
+                }
+                // pin the software pipeline: hipcc otherwise sinks every read to just in front of its MFMA (one fragment set,
+                // an LDS round trip per k-step and the next tap's first reads back behind the barrier)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[nt]),
-                                                                              __builtin_bit_cast(bf16x8, bfr[mt]),
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks & 1][nt]),
+                                                                              __builtin_bit_cast(bf16x8, bfr[ks & 1][mt]),
                                                                               acc[nt][mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (VARIANT == 1 && ((ks == 0 && wave < 4) || (ks == 2 && wave >= 4))) {
+                    issue_dma();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
 
+    LAP(1)                                               // main loop
     // ---- epilogue: D[cout][pixel] -> LDS f32 [128 pixel rows][BN] per half (16-byte units XOR-swizzled by pixel) -> whole
     // 16-byte channel vectors per pixel, with bias / residual / activation / dropout / BatchNorm partial sums fused
     constexpr int UPR = BN / 4, BMH = BM / 2;
@@ -271,16 +318,27 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
                     for (int i = 0; i < VE; ++i) v[i] = hash_uniform(a.seed, base + i) >= a.drop_p ? v[i] * keep_scale : 0.f;
                 }
                 const v4i pk = pack16<bf16>(v);
+#ifndef PMOE_STAMP
                 if (a.stats) {
                     float rr[VE];
                     unpack16<bf16>(pk, rr);
 #pragma unroll
                     for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
                 }
+#endif
                 stg16(out + opix * a.out_ld + a.out_coff + cout, pk);
             }
         }
     }
+#ifdef PMOE_STAMP
+    LAP(2)                                               // epilogue (staging + fused read-out + stores)
+    if (a.stats && lane == 0) {
+        float* o = a.stats + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 3; ++i) o[i] = (float)st_acc[i];
+        o[3] = (float)(unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+    }
+    return;
+#endif
     if (a.stats) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);     // [8 waves][2][BN]
@@ -350,7 +408,24 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
     if (!conv_dma_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
-    HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel>(160 * 1024)));
-    hipLaunchKernelGGL(conv3x3_dma_kernel, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
+    const char* ev = getenv("PMOE_DMA_VARIANT");         // A/B switch (tools/ab_conv.py); 0 = measured best
+    const int variant = ev ? atoi(ev) : 0;
+    const dim3 grid(mblocks * (a.CoutP / BN)), block(NTHR);
+    if (variant == 1) {
+        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<1>>(160 * 1024)));
+        hipLaunchKernelGGL(conv3x3_dma_kernel<1>, grid, block, smem, st, a, pbuf);
+    } else if (variant == 2) {
+        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<2>>(160 * 1024)));
+        hipLaunchKernelGGL(conv3x3_dma_kernel<2>, grid, block, smem, st, a, pbuf);
+    } else if (variant == 3) {
+        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<3>>(160 * 1024)));
+        hipLaunchKernelGGL(conv3x3_dma_kernel<3>, grid, block, smem, st, a, pbuf);
+    } else if (variant == 4) {
+        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<4>>(160 * 1024)));
+        hipLaunchKernelGGL(conv3x3_dma_kernel<4>, grid, block, smem, st, a, pbuf);
+    } else {
+        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<0>>(160 * 1024)));
+        hipLaunchKernelGGL(conv3x3_dma_kernel<0>, grid, block, smem, st, a, pbuf);
+    }
     return (int)hipGetLastError();
 }

@@ -9,7 +9,7 @@
 // scalar ds_read_b32 (the f32 MFMA takes one element per lane).  One dY fragment is reused for all
 // ks*ks taps, so each tap costs one transposed X read per MFMA.  Every wave keeps its
 // [32 cout][32 cin] x taps accumulators in registers across ALL the m-blocks the workgroup walks
-// (K-split over gridDim.x) and flushes ONCE, deterministically: the waves that split the pixels of one output tile
+// (K-split over the flat grid) and flushes ONCE, deterministically: the waves that split the pixels of one output tile
 // are summed through LDS in fixed order, the workgroup stores its tile with plain stores (lanes along cin: 2 x 128-byte
 // segments per wave-instruction) into its own slab of a partial workspace, and `wgrad_reduce_kernel` folds the K-split
 // slabs in fixed order.  No float atomics anywhere: weight gradients are bit-reproducible run to run.
@@ -54,7 +54,14 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
 
     const int e = blockIdx.z;
     const int n_ci_blk = (a.Cin + CKW - 1) / CKW;
-    const int cob = blockIdx.y / n_ci_blk, cib = blockIdx.y % n_ci_blk;
+    // flat grid, channel-tile pair FASTEST: the workgroups that walk the SAME pixels (every (cout, cin) tile pair of one K
+    // slice reads the same dY tiles / X patches) are dispatch neighbours and, through the XCD remap, share one XCD's L2 --
+    // with the slice index fastest they were a whole grid row apart and each operand byte came from HBM once per pair
+    // (1.10 GB fetched per launch against 0.54 GB compulsory, profiles/traffic.json of round 1)
+    const int npairs = n_ci_blk * ((a.Cout + CKW - 1) / CKW);
+    const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
+    const int pair = (int)(flat % npairs), split = (int)(flat / npairs), nsplit = (int)(gridDim.x / npairs);
+    const int cob = pair / n_ci_blk, cib = pair % n_ci_blk;
     const int co0 = cob * CKW, ci0 = cib * CKW;
 
     const int lTW = a.lTW, lTH = a.lTH;
@@ -77,7 +84,7 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
 
     const T* x = (const T*)a.x;
     const T* dy = (const T*)a.dy;
-    const int mb_begin = blockIdx.x * a.mb_per_wg;
+    const int mb_begin = split * a.mb_per_wg;
     int mb_end = mb_begin + a.mb_per_wg;
     if (mb_end > mbpe) mb_end = mbpe;
 
@@ -191,9 +198,9 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
     float* red = reinterpret_cast<float*>(smem);
     const int tw = wave % TILE_WAVES;
     const int cin = ci0 + ci_sub * 32 + l31;
-    const size_t slab = a.per_image ? (size_t)e * a.ipe + blockIdx.x          // per image
-                                    : (size_t)blockIdx.x * gridDim.z + e;       // per (K-split, expert); split 0 = dw itself
-    float* dst = (a.per_image || gridDim.x == 1) ? a.dw : a.part;
+    const size_t slab = a.per_image ? (size_t)e * a.ipe + split               // per image
+                                    : (size_t)split * gridDim.z + e;            // per (K-split, expert); split 0 = dw itself
+    float* dst = (a.per_image || nsplit == 1) ? a.dw : a.part;
 #pragma unroll
     for (int t0 = 0; t0 < TAPS; t0 += TPR) {
         __syncthreads();
@@ -241,7 +248,7 @@ template <typename T, int TAPS, int MAXV> static int launch_wg(const WgradArgs& 
     constexpr int CKW = 128 / (int)sizeof(T);
     const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
     const int nsplit = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
-    dim3 grid(nsplit, ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW), E), block(WgradCfg<T>::NW * 64, 1, 1);
+    dim3 grid(nsplit * ((a.Cout + CKW - 1) / CKW) * ((a.Cin + CKW - 1) / CKW), 1, E), block(WgradCfg<T>::NW * 64, 1, 1);
     // room for the in-workgroup fold of the pixel-split waves: (WK-1) x TPR taps x tile waves x 4 KiB
     constexpr size_t fold = (size_t)(WgradCfg<T>::WK - 1) * (TAPS == 9 ? 3 : 1) * WgradCfg<T>::WCO * WgradCfg<T>::WCI * 4096;
     if (smem < fold) smem = fold;

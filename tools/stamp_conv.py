@@ -20,11 +20,15 @@ PHASES = ["halo patch staging (+ its barrier)", "fragment reads + MFMA issue", "
 def build():
     csrc, bld = ROOT / "pmoe_amd" / "csrc", ROOT / "build"
     subprocess.check_call([str(ROOT / "build.sh")])
-    obj = bld / "conv_igemm_stamp.o"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-                           "-Wno-unused-result", "-DPMOE_STAMP", "-c", str(csrc / "conv_igemm.hip"), "-o", str(obj)])
-    others = [str(o) for o in sorted(bld.glob("*.o")) if o.name not in ("conv_igemm.o", "conv_igemm_stamp.o")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), str(obj)] + others)
+    objs = []
+    for src in ("conv_igemm", "conv_dma"):
+        obj = bld / f"{src}_stamp.o"
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                               "-Wno-unused-result", "-DPMOE_STAMP", "-c", str(csrc / f"{src}.hip"), "-o", str(obj)])
+        objs.append(str(obj))
+    skip = ("conv_igemm.o", "conv_igemm_stamp.o", "conv_dma.o", "conv_dma_stamp.o")
+    others = [str(o) for o in sorted(bld.glob("*.o")) if o.name not in skip]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + objs + others)
     print("built", LIB)
 
 
@@ -60,6 +64,14 @@ def main():
             torch.cuda.synchronize()
             v = stats.flatten().cpu()
             nwg = rows * (cout // 128)
+            if os.environ.get("PMOE_CONV_DMA", "1") != "0":       # conv3x3_dma_kernel: 3 laps + wall time per wave
+                rec = v[:nwg * 8 * 8].view(nwg * 8, 8)[:, :4]
+                assert (rec >= 0).all(), "stamped library not loaded or a different kernel ran"
+                cyc, wall = rec[:, :3], rec[:, 3] / 100.0
+                print(f"{name} {what} [conv3x3_dma_kernel]: {nwg} workgroups; per wave: prologue {cyc[:, 0].mean():.0f}, main loop "
+                      f"{cyc[:, 1].mean():.0f}, epilogue {cyc[:, 2].mean():.0f} cycles; workgroup wall time {wall.mean():.2f} us "
+                      f"(=> {cyc.sum(1).mean() / wall.mean() / 1e3:.2f} GHz)")
+                continue
             rec = v[:nwg * 8 * 8].view(nwg * 8, 8)[:, :5]
             assert (rec >= 0).all(), "stamped library not loaded or a different kernel ran"
             tot = rec.sum(1)
