@@ -26,7 +26,7 @@ from oracle import weights as W  # noqa: E402
 GOLDEN = ROOT / "tests" / "golden"
 MOE_CASES = ["g1_moe_e4_b2_128", "g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g6_moeshared_k4_b6_96", "g10_moe_e4_b32_64",
              "g2_moe_e4_b1_224_eval", "g7_moeshared_k6_b1_224_eval"]
-PUNET_CASES = ["p1_punet_b2_64_f2", "p2_punet_b1_64_f6_eval", "p3_punetinter_b2_64_f2"]
+PUNET_CASES = ["p1_punet_b2_64_f2", "p2_punet_b1_64_f6_eval", "p3_punetinter_b2_64_f2", "p5_pmoe_e2_b2_64_f2"]
 GRAD_CASES = ["g3_moe_e8_b2_128", "g10_moe_e4_b32_64"]
 VARIANTS = ("all", "fused")
 JITTERS = 6        # extra draws of the emulation error: the same case with its images jittered by 1 % (seeds 1..JITTERS)
@@ -37,6 +37,8 @@ def build(meta):
     kw = dict(dropout=0.0)
     if "future_frames" in meta:
         kw["future_frames"] = meta["future_frames"]
+    if meta["type"].startswith("pmoe"):
+        kw["exclude_freeze"] = ["lat_weights", "long_weights"]
     cfg = O.stage2_cfg(meta["type"], meta["n_experts"], **kw)
     model = O.get_model(cfg)
     W.fill_state_dict(model, seed=meta["weight_seed"])
@@ -48,8 +50,15 @@ def build(meta):
 def outputs(model, inp, dtype, clone=True):
     m = copy.deepcopy(model).to(dtype) if clone else model     # (instance-patched forwards do not survive a deepcopy)
     with torch.no_grad():
+        if hasattr(m, "blend"):                                 # PMoE: its deterministic parts (tests/punet_parity.run_pmoe_case)
+            args = (inp["images"].to(dtype), inp["speed"].to(dtype), inp["command"].to(dtype))
+            pa, _ = m.punet(*args)
+            d, _ = m.moe(*args)
+            return {"punet_actions": pa.double(), "probs": d.mixture_distribution.probs.double(),
+                    "mean": d.component_distribution.base_dist.loc.double(),
+                    "std": d.component_distribution.base_dist.scale.double()}
         r = m(inp["images"].to(dtype), inp["speed"].to(dtype), inp["command"].to(dtype))
-    if isinstance(r[0], torch.Tensor):                          # PUNetExpert: (actions, speed)
+    if isinstance(r[0], torch.Tensor):                        # PUNetExpert: (actions, speed)
         return {"actions": r[0].double(), "speed": r[1].double()}
     d, s = r
     return {"probs": d.mixture_distribution.probs.double(), "mean": d.component_distribution.base_dist.loc.double(),
@@ -144,6 +153,12 @@ def main():
     torch.manual_seed(0)
     path = GOLDEN / "bf16_bounds.pt"
     keep_grads = "--keep-grads" in sys.argv and path.exists()   # reuse the (slow) float64 gradient records
+    if "--only" in sys.argv:                                    # add / refresh the forward record of one case
+        name = sys.argv[sys.argv.index("--only") + 1]
+        out = torch.load(path, weights_only=False)
+        out["forward"][name] = forward_bounds(name)
+        torch.save(out, path)
+        return
     out = {"forward": {}, "grad": torch.load(path, weights_only=False)["grad"] if keep_grads else {}}
     for name in MOE_CASES + PUNET_CASES:
         out["forward"][name] = forward_bounds(name)

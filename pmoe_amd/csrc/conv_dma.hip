@@ -5,9 +5,10 @@
 // halo patch of a 64-channel chunk staged ONCE in LDS and read by all 9 taps at shifted addresses), but every byte reaches
 // LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no VALU, and the requests stay in flight across the
 // per-tap barriers behind COUNTED `s_waitcnt vmcnt(N)`:
-//   * weights  : ring of 4 tap tiles [128 couts][128 B]; the tile of tap t+3 is requested at tap t into the slot last read
-//                at tap t-1, and the tile of tap t+1 is already visible during tap t, so the fragments of the next tap's
-//                first k-step are read under the last MFMAs of the current one (no LDS round trip after a barrier);
+//   * weights  : ring of 4 tap tiles [128 couts][128 B]; the tile of tap t+2 is requested at tap t into the slot last read
+//                at tap t-2 (two barriers earlier).  (A hand-pipelined variant -- ring lookahead 3, the next tap's first
+//                fragments read under the current tap's last MFMAs, order pinned with sched_barrier -- measured 2-4 %
+//                SLOWER in an interleaved A/B, tools/ab_conv.py: hipcc's own just-in-time read placement wins here);
 //   * patches  : 2 buffers; the NEXT chunk's halo patch is requested piece by piece (1 KiB per wave-instruction) at taps
 //                1..6 of the current chunk; pixels outside the image / beyond the expert's last image are zero-filled by the
 //                buffer's range check (their offset is parked beyond num_records) -- the halo costs no instructions;
@@ -18,7 +19,14 @@
 //                (the linear key cost 15 % bank-conflict cycles there, profiles/r01_conv_lds_pmc.json).
 // One barrier per tap, 16 MFMAs per wave between barriers, all 9 taps unrolled (static tap offsets), one workgroup per CU
 // (150 KiB of LDS, 2 waves per SIMD).  Epilogue = that of conv_igemm.hip (bias / residual modes / activation / dropout /
-// fused BatchNorm partial sums), staged through LDS in two halves.
+// fused BatchNorm partial sums): staged through LDS as bf16 rows in ONE phase when nothing is added to the accumulator
+// before it is rounded (forward + statistics, plain and ReLU'-masked data gradients: 8.0 k -> 5.9 k cycles per tile), as
+// f32 in two halves otherwise.
+// Measured and NOT adopted (interleaved A/B in one process, tools/ab_conv.py): persistent workgroups with the DMA stream
+// running across tile boundaries (the next tile's operands land under the epilogue) -- 4-8 % slower: the epilogue's
+// stores share the in-order vmcnt counter with the prefetch, the cold next-tile patch stalls the counted waits of the
+// last chunk, and the kernel needs all 256 VGPRs; DMA requests issued between the MFMA groups, staggered between the two
+// waves of a SIMD -- within 1 %.
 #include "conv_common.h"
 #include <stdlib.h>
 #include "kernels.h"
@@ -44,7 +52,6 @@ __device__ __forceinline__ int cswz(int x) { return (x >> 1) & 7; }
 #define LAP(i)
 #endif
 
-template <int VARIANT>
 __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, const int pbuf_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     STAMP_INIT
@@ -145,31 +152,12 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
     const int nchunks = a.Cin / CK;
     const int T = nchunks * 9;
 
-    // ---- prologue: patch of chunk 0, weight tiles of taps 0..2; the fragments of (tap 0, k-step 0) once they are visible
+    // ---- prologue: patch of chunk 0, weight tiles of taps 0 and 1
 #pragma unroll
     for (int i = 0; i < 6; ++i)
         if (i < my_pieces) dma_patch(i, 0, 0);
     dma_w(0, 0, 0);
     dma_w(1, 1, 0);
-    dma_w(2, 2, 0);
-    VMCNT(4);                                            // all but W(1), W(2): the patch and W(0) are in LDS
-    __builtin_amdgcn_s_barrier();
-    LAP(0)                                               // prologue: descriptors, offsets, first patch + weight tile landed
-
-    // fragment double buffer: k-step ks of a tap lives in set ks & 1; the set of (tap t+1, k-step 0) is read under the last
-    // MFMAs of tap t -- its weight tile W(t+1) is already visible by then (the wait at the top of tap t covers it), so a wave
-    // never starts a tap with an LDS round trip in front of its first MFMA
-    v4i af[2][2], bfr[2][2];
-    auto read_frags = [&](int set, const char* wt, const char* patch, int tap, int ks) {
-        const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RB;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) af[set][nt] = *reinterpret_cast<const v4i*>(wt + aoff[nt][ks]);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-            bfr[set][mt] = *reinterpret_cast<const v4i*>(patch + pbase[mt] + tapoff +
-                                                         (((ks * 2 + h) ^ cswz(pcol[mt] + (tap % 3))) << 4));
-    };
-    read_frags(0, wring, smem, 0, 0);
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
@@ -178,57 +166,46 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int tt = ch * 9 + tap;
-            // W(tt+1) has landed for this wave once at most {W(tt+2), the patch piece issued in the previous iteration} are
-            // outstanding (vmcnt counts in issue order); the patch of the next chunk is older than its first weight tile
+            // W(tt) has landed for this wave once at most {W(tt+1), the patch piece issued in the previous iteration}
+            // are outstanding (vmcnt counts in issue order)
             const bool prev_piece = tap >= 2 && tap <= 7 && more && (tap - 2) < my_pieces;
-            if (tt + 2 >= T) VMCNT(0);
+            if (tt + 1 >= T) VMCNT(0);
             else if (prev_piece) VMCNT(3);
             else VMCNT(2);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot about to be refilled are back
-            if (VARIANT != 4)                            // (4: timing experiment only, wrong results: no per-tap barrier)
-            __builtin_amdgcn_s_barrier();                // publishes W(tt+1) (+ the next chunk's patch); slot (tt-1) & 3 is free
-            // this tap's DMA requests go out BETWEEN the MFMA groups, and at different points for the two waves of a SIMD
-            // (waves w and w + 4): issued right behind the barrier by all 8 waves at once they left the matrix pipes idle
-            // for ~300 cycles per tap; now one wave's request issue runs under its partner's MFMAs
-            auto issue_dma = [&]() {
-                if (VARIANT == 3) return;                // timing experiment only (wrong results): no main-loop DMA
-                if (tap >= 1 && tap <= 6 && more && (tap - 1) < my_pieces) dma_patch(tap - 1, (ch + 1) & 1, c0 + CK);
-                if (tt + 3 < T) {
-                    int ntap = tap + 3, nc0 = c0;
-                    if (ntap >= 9) { ntap -= 9; nc0 += CK; }
-                    dma_w((tt + 3) & (RING - 1), ntap, nc0);
-                }
-            };
-            if (VARIANT == 0) issue_dma();
-            if (VARIANT == 2 && wave < 4) issue_dma();   // older half right behind the barrier, younger half mid-tap
+            __builtin_amdgcn_s_barrier();                // every wave's share of tap tt (and of this chunk's patch) is in LDS
+#ifdef PMOE_STAMP
+            if (tt == 0) LAP(0)                          // prologue: descriptors, offsets, first patch + two weight tiles landed
+#endif
+            if (tap >= 1 && tap <= 6 && more && (tap - 1) < my_pieces) dma_patch(tap - 1, (ch + 1) & 1, c0 + CK);
+            if (tt + 2 < T) {
+                int ntap = tap + 2, nc0 = c0;
+                if (ntap >= 9) { ntap -= 9; nc0 += CK; }
+                dma_w((tt + 2) & (RING - 1), ntap, nc0);
+            }
             const char* wt = wring + (tt & (RING - 1)) * WSLOT;
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RB;
+            int bsw[2];
+            const char* bp[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                bp[mt] = patch + pbase[mt] + tapoff;
+                bsw[mt] = cswz(pcol[mt] + (tap % 3));
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if (VARIANT == 2 && ks == 2 && wave >= 4) {
-                    issue_dma();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (ks < 3) {
-                    read_frags((ks + 1) & 1, wt, patch, tap, ks + 1);
-                } else if (tt + 1 < T) {                 // first k-step of the next tap (next chunk's patch after tap 8)
-                    read_frags(0, wring + ((tt + 1) & (RING - 1)) * WSLOT,
-                               tap == 8 ? smem + ((ch + 1) & 1) * pbuf_bytes : patch, tap == 8 ? 0 : tap + 1, 0);
-                }
-                // pin the software pipeline: hipcc otherwise sinks every read to just in front of its MFMA (one fragment set,
-                // an LDS round trip per k-step and the next tap's first reads back behind the barrier)
-                __builtin_amdgcn_sched_barrier(0);
+                v4i af[2], bfr[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) af[nt] = *reinterpret_cast<const v4i*>(wt + aoff[nt][ks]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    bfr[mt] = *reinterpret_cast<const v4i*>(bp[mt] + (((ks * 2 + h) ^ bsw[mt]) << 4));
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks & 1][nt]),
-                                                                              __builtin_bit_cast(bf16x8, bfr[ks & 1][mt]),
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[nt]),
+                                                                              __builtin_bit_cast(bf16x8, bfr[mt]),
                                                                               acc[nt][mt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (VARIANT == 1 && ((ks == 0 && wave < 4) || (ks == 2 && wave >= 4))) {
-                    issue_dma();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
             }
         }
     }
@@ -251,6 +228,86 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
     const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     bf16* out = (bf16*)a.out;
     const bf16* res = (const bf16*)a.res;
+    // fused tail of one 8-channel vector v of output pixel p of the tile
+    auto finish = [&](int p, float* v) {
+        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+        const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
+        if (!(cvalid && n < n_end && oy < a.Ho && ox < a.Wo)) return;
+            const size_t opix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+            for (int i = 0; i < VE; ++i) v[i] += bias[i];
+            if (a.res_mode) {
+                float rv[VE];
+                unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cout), rv);
+                if (a.res_mode == PMOE_RES_ADD) {
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) v[i] += rv[i];
+                } else if (a.res_mode == PMOE_RES_DRELU) {
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) v[i] = rv[i] > 0.f ? v[i] * keep_scale : 0.f;
+                } else if (a.res_mode == PMOE_RES_DELU) {
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) {
+                        const float y = rv[i] * (1.f / keep_scale);
+                        const float d = y > 0.f ? 1.f : y + 1.f;
+                        v[i] = (a.drop_p > 0.f && rv[i] == 0.f) ? 0.f : v[i] * d * keep_scale;
+                    }
+                }
+            }
+            if (a.act == PMOE_ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] = fmaxf(v[i], 0.f);
+            } else if (a.act == PMOE_ACT_ELU) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] = v[i] > 0.f ? v[i] : expm1f(v[i]);
+            }
+            if (a.drop_p > 0.f && a.res_mode < PMOE_RES_DRELU) {
+                const unsigned long long base = (unsigned long long)opix * (unsigned)a.Cout + cout;
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] = hash_uniform(a.seed, base + i) >= a.drop_p ? v[i] * keep_scale : 0.f;
+            }
+            const v4i pk = pack16<bf16>(v);
+#ifndef PMOE_STAMP
+            if (a.stats) {
+                float rr[VE];
+                unpack16<bf16>(pk, rr);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
+            }
+#endif
+            stg16(out + opix * a.out_ld + a.out_coff + cout, pk);
+    };
+    // bf16 staging is exact when nothing is added to the accumulator before it is rounded (forward + statistics, plain and
+    // ReLU'-masked data gradients): ONE phase, all 8 waves write their 64 x 64 sub-tiles as bf16 rows [256 px][256 B]
+    // (16-byte chunks XOR-swizzled by pixel), one barrier, 8 vectors per thread -- half the LDS bytes and half the
+    // barriers of the f32 path below
+    const bool fast_epi = !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f &&
+                          (a.res_mode == PMOE_RES_NONE || a.res_mode == PMOE_RES_DRELU);
+    if (fast_epi) {
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int p = wm * 64 + mt * 32 + l31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (bf16)acc[nt][mt][4 * g + i];
+                    const int c16 = wn * 8 + nt * 4 + g;
+                    *reinterpret_cast<bf16x4*>(smem + p * 256 + ((c16 ^ (p & 15)) << 4) + 8 * h) = v;
+                }
+            }
+        __syncthreads();
+#pragma unroll 2
+        for (int u = 0; u < BM / PROWS; ++u) {
+            const int ph = pr + u * PROWS;
+            float v[VE];
+            unpack16<bf16>(*reinterpret_cast<const v4i*>(smem + ph * 256 + ((cc ^ (ph & 15)) << 4)), v);
+            finish(ph, v);
+        }
+    } else
     for (int half = 0; half < 2; ++half) {
         __syncthreads();                                 // main loop reads / the previous half's read-out are done
         if (wm / 2 == half) {
@@ -272,9 +329,6 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
         __syncthreads();
         for (int ph = pr; ph < BMH; ph += PROWS) {
             const int p = ph + half * BMH;
-            const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
-            const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
-            const bool ok = cvalid && n < n_end && oy < a.Ho && ox < a.Wo;
             float v[VE];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -283,51 +337,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[4 * k + i] = tt[i];
             }
-            if (ok) {
-                const size_t opix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
-#pragma unroll
-                for (int i = 0; i < VE; ++i) v[i] += bias[i];
-                if (a.res_mode) {
-                    float rv[VE];
-                    unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cout), rv);
-                    if (a.res_mode == PMOE_RES_ADD) {
-#pragma unroll
-                        for (int i = 0; i < VE; ++i) v[i] += rv[i];
-                    } else if (a.res_mode == PMOE_RES_DRELU) {
-#pragma unroll
-                        for (int i = 0; i < VE; ++i) v[i] = rv[i] > 0.f ? v[i] * keep_scale : 0.f;
-                    } else if (a.res_mode == PMOE_RES_DELU) {
-#pragma unroll
-                        for (int i = 0; i < VE; ++i) {
-                            const float y = rv[i] * (1.f / keep_scale);
-                            const float d = y > 0.f ? 1.f : y + 1.f;
-                            v[i] = (a.drop_p > 0.f && rv[i] == 0.f) ? 0.f : v[i] * d * keep_scale;
-                        }
-                    }
-                }
-                if (a.act == PMOE_ACT_RELU) {
-#pragma unroll
-                    for (int i = 0; i < VE; ++i) v[i] = fmaxf(v[i], 0.f);
-                } else if (a.act == PMOE_ACT_ELU) {
-#pragma unroll
-                    for (int i = 0; i < VE; ++i) v[i] = v[i] > 0.f ? v[i] : expm1f(v[i]);
-                }
-                if (a.drop_p > 0.f && a.res_mode < PMOE_RES_DRELU) {
-                    const unsigned long long base = (unsigned long long)opix * (unsigned)a.Cout + cout;
-#pragma unroll
-                    for (int i = 0; i < VE; ++i) v[i] = hash_uniform(a.seed, base + i) >= a.drop_p ? v[i] * keep_scale : 0.f;
-                }
-                const v4i pk = pack16<bf16>(v);
-#ifndef PMOE_STAMP
-                if (a.stats) {
-                    float rr[VE];
-                    unpack16<bf16>(pk, rr);
-#pragma unroll
-                    for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
-                }
-#endif
-                stg16(out + opix * a.out_ld + a.out_coff + cout, pk);
-            }
+            finish(p, v);
         }
     }
 #ifdef PMOE_STAMP
@@ -408,24 +418,7 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
     if (!conv_dma_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
-    const char* ev = getenv("PMOE_DMA_VARIANT");         // A/B switch (tools/ab_conv.py); 0 = measured best
-    const int variant = ev ? atoi(ev) : 0;
-    const dim3 grid(mblocks * (a.CoutP / BN)), block(NTHR);
-    if (variant == 1) {
-        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<1>>(160 * 1024)));
-        hipLaunchKernelGGL(conv3x3_dma_kernel<1>, grid, block, smem, st, a, pbuf);
-    } else if (variant == 2) {
-        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<2>>(160 * 1024)));
-        hipLaunchKernelGGL(conv3x3_dma_kernel<2>, grid, block, smem, st, a, pbuf);
-    } else if (variant == 3) {
-        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<3>>(160 * 1024)));
-        hipLaunchKernelGGL(conv3x3_dma_kernel<3>, grid, block, smem, st, a, pbuf);
-    } else if (variant == 4) {
-        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<4>>(160 * 1024)));
-        hipLaunchKernelGGL(conv3x3_dma_kernel<4>, grid, block, smem, st, a, pbuf);
-    } else {
-        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<0>>(160 * 1024)));
-        hipLaunchKernelGGL(conv3x3_dma_kernel<0>, grid, block, smem, st, a, pbuf);
-    }
+    HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel>(160 * 1024)));
+    hipLaunchKernelGGL(conv3x3_dma_kernel, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
     return (int)hipGetLastError();
 }

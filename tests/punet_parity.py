@@ -8,7 +8,7 @@ import torch
 from oracle import pmoe_oracle as O
 from oracle import weights as W
 from pmoe_amd.loss import pmoe_loss, punet_loss
-from tests.parity_util import rel_err, rel_l2
+from tests.parity_util import BF16_FLOOR, BF16_SLACK, bf16_bounds, emul_worst, rel_err, rel_l2
 from tests.punet_util import build_product
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
@@ -79,12 +79,26 @@ def run_punet_case(tmp, name, dtype=torch.float32, verbose=True, fwd_tol_mult=1.
             actions, speeds = model(dev["images"], dev["speed"], dev["command"])
         loss = None
     assert actions.shape == g["actions"].shape and speeds.shape == g["speeds"].shape
-    report["actions"] = fwd_err(actions, g["actions"], dtype)
-    report["speeds"] = fwd_err(speeds, g["speeds"], dtype)
+    bounds = bf16_bounds(name) if dtype == torch.bfloat16 else None
+    if bounds is not None:
+        # bf16: distance to the float64 oracle in units of max(1e-2, 1.25 x the bf16-storage-emulating oracle's own
+        # distance, largest of 14 draws) -- tests/parity_util.py; the chained train-mode U-Nets make that figure large
+        # on the tiny-batch cases (0.3 on p1's actions), and it is the measured figure, not a multiplier, that says so
+        for k, got in (("actions", actions), ("speed", speeds)):
+            ref = bounds["f64"][k]
+            err = ((got.detach().double().cpu() - ref).abs() / (1 + ref.abs())).max().item()
+            lim = max(BF16_FLOOR, BF16_SLACK * emul_worst(bounds["emul"], k))
+            report[k] = err / lim
+            report[k + "_abs"] = (err, lim)
+    else:
+        report["actions"] = fwd_err(actions, g["actions"], dtype)
+        report["speeds"] = fwd_err(speeds, g["speeds"], dtype)
     allowance = max(fwd_tol_mult, 5 * drift / FWD_TOL[dtype])
     for k, v in report.items():
-        if k != "f32_oracle_drift":
-            assert v <= allowance, f"{name} [{dtype}] {k}: {v:.3f} x tolerance {FWD_TOL[dtype]} (allowance {allowance:.2f})"
+        if k == "loss" and bounds is not None:
+            continue                                     # (the loss follows the actions: covered by their measured bound)
+        if k != "f32_oracle_drift" and not k.endswith("_abs"):
+            assert v <= allowance, f"{name} [{dtype}] {k}: {v:.3f} x tolerance {report.get(k + '_abs', FWD_TOL[dtype])} (allowance {allowance:.2f})"
     if loss is not None:
         named = dict(model.named_parameters())
         oa, os_ = oracle(inp["images"], inp["speed"], inp["command"])
@@ -154,20 +168,35 @@ def run_pmoe_case(tmp, name, dtype=torch.float32, verbose=True, fwd_tol_mult=1.0
     pa, _ = model.punet(dev["images"], dev["speed"], dev["command"])
     dists, _ = model.moe(dev["images"], dev["speed"], dev["command"])
     probs, mean, std = dists.hip_params
-    report["punet_actions"] = fwd_err(pa, g["punet_actions"], dtype)
-    report["probs"] = fwd_err(probs, g["probs"], dtype)
-    report["mean"] = fwd_err(mean, g["mean"], dtype)
-    report["std"] = fwd_err(std, g["std"], dtype)
+    bounds = bf16_bounds(name) if dtype == torch.bfloat16 else None
+    if bounds is not None:
+        lims = {}
+        for k, got in (("punet_actions", pa), ("probs", probs), ("mean", mean), ("std", std)):
+            ref = bounds["f64"][k]
+            err = ((got.detach().double().cpu() - ref).abs() / (1 + ref.abs())).max().item()
+            lims[k] = max(BF16_FLOOR, BF16_SLACK * emul_worst(bounds["emul"], k))
+            report[k] = err / lims[k]
+    else:
+        report["punet_actions"] = fwd_err(pa, g["punet_actions"], dtype)
+        report["probs"] = fwd_err(probs, g["probs"], dtype)
+        report["mean"] = fwd_err(mean, g["mean"], dtype)
+        report["std"] = fwd_err(std, g["std"], dtype)
     out = model.blend(g["moe_actions"].cuda(), pa)              # the reference's own draw (moe.py:352) under seed 77
     report["actions"] = fwd_err(out, g["actions"], dtype)
     loss = pmoe_loss(out, -1, dev["control"], dev["target_speed"], ocfg.loss_coefs)
     report["loss"] = abs(loss.item() - g["loss"].item()) / FWD_TOL[dtype]
     loss.backward()
+    if bounds is not None:
+        # the blend and the loss inherit the PU-Net expert's error: (1, 2) -> 1 Linear + tanh is 1-Lipschitz per weight
+        w = max(model.lat_weights.weight.abs().sum().item(), model.long_weights.weight.abs().sum().item(), 1.0)
+        inherit = w * lims["punet_actions"] / FWD_TOL[dtype]
     for k, v in report.items():
         lim = allowance if k in ("punet_actions", "actions", "loss") else 1.0     # the mixture itself is well conditioned
+        if bounds is not None:
+            lim = inherit if k in ("actions", "loss") else 1.0
         assert k == "f32_oracle_drift" or v <= lim * fwd_tol_mult, f"{name} [{dtype}] {k}: {v:.3f} x tolerance (limit {lim:.1f})"
     named = dict(model.named_parameters())
-    gtol = (max(2e-3, 20 * drift) if dtype == torch.float32 else 8e-2) * fwd_tol_mult
+    gtol = (max(2e-3, 20 * drift) if dtype == torch.float32 else max(8e-2, 2 * lims["punet_actions"])) * fwd_tol_mult
     for k, ref in g["grads_small"].items():
         e = (named[k].grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
         report["grad " + k] = e

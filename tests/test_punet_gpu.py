@@ -39,18 +39,19 @@ def test_punet_train_parity_f32(tmp_path, name):
 
 def test_punet_train_bf16(tmp_path):
     """bf16 storage through 6-7 chained train-mode U-Nets decorrelates these tiny-batch cases (the f32 oracle already
-    drifts 4e-4 from f64), so bf16 train mode is held to: the well-conditioned punet_inter case within 4x the bf16
-    forward tolerance with aligned gradients, and finite, bounded results on the backbone case."""
-    r = run_punet_case(tmp_path, "p3_punetinter_b2_64_f2", torch.bfloat16, fwd_tol_mult=4.0)
+    drifts 4e-4 from f64): both are held to 1.25 x the measured error of the bf16-storage-emulating oracle against the
+    float64 oracle (tests/golden/bf16_bounds.pt: 0.09 on p3's actions, 0.3 on p1's), the well-conditioned punet_inter
+    case also to aligned gradients."""
+    r = run_punet_case(tmp_path, "p3_punetinter_b2_64_f2", torch.bfloat16)
     assert r["grad_median_cos"] >= 0.9 and r["grad_total_rel"] <= 0.2, r
-    r = run_punet_case(tmp_path, "p1_punet_b2_64_f2", torch.bfloat16, fwd_tol_mult=12.0)
+    r = run_punet_case(tmp_path, "p1_punet_b2_64_f2", torch.bfloat16)
     assert r["grad_total_rel"] <= 0.3, r
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pmoe_parity(tmp_path, dtype):
     """PMoE (moe.py:326-363): frozen mixture + PU-Net expert + lat/long blend on the reference's own draw."""
-    run_pmoe_case(tmp_path, "p5_pmoe_e2_b2_64_f2", dtype, fwd_tol_mult=1.0 if dtype == torch.float32 else 6.0)
+    run_pmoe_case(tmp_path, "p5_pmoe_e2_b2_64_f2", dtype)      # bf16: measured emulation bounds (tests/punet_parity.py)
 
 
 def test_punet_stem_fold_matches_explicit_path(tmp_path):
