@@ -80,13 +80,14 @@ def test_conv_plan_reports_the_kernel_instantiation():
         return load().pmoe_conv2d_plan(C.byref(d))
     assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1007                 # conv3x3_res_kernel<7>
     assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1005                 # 12(16)-channel stem on the resident kernel
-    assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 2007                # conv_igemm_lite_kernel<bf16,7>: 2 workgroups / CU
+    assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 5007                # conv3x3_dma_kernel (LDS-DMA staged, conv_dma.hip)
+    assert plan(128, 256, 64, 1, 2, torch.bfloat16) == 2007                # 1x1 stride 2: conv_igemm_lite_kernel<bf16,7>, 2 workgroups / CU
     assert plan(256, 256, 32, 3, 1, torch.float32) == 722                  # f32: 4-wave 128x128 tile, 32-channel chunks
     assert plan(1536, 512, 1, 1, 1, torch.bfloat16) == 3000                # expert MLP GEMM: gemm_skinny_kernel
     assert plan(1536, 512, 1, 1, 1, torch.float32) == 722                  # ... in f32: generic 4-wave tile
     assert plan(512, 512, 14, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # B=1 inference layer4: tap-looping skinny kernel
     assert plan(128, 128, 56, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # ... layer2 (3136 pixels per expert <= 3200)
-    assert plan(128, 128, 64, 3, 1, torch.bfloat16, B=1, E=3) == 2007      # 4096 pixels per expert: LITE tile
+    assert plan(128, 128, 64, 3, 1, torch.bfloat16, B=1, E=3) == 5007      # 4096 pixels per expert: the LDS-DMA tile
     assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 4741   # stride-2 dgrad: 4 class launches <7,4,1>
 
 
@@ -95,7 +96,8 @@ def test_cycle_stamped_tools_build_compiles(tmp_path):
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    src = REPO / "pmoe_amd" / "csrc" / "conv_igemm.hip"
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DPMOE_STAMP",
-                           "-c", str(src), "-o", str(tmp_path / "conv_igemm_stamp.o")], stderr=subprocess.DEVNULL)
+    for name in ("conv_igemm", "conv_dma"):
+        src = REPO / "pmoe_amd" / "csrc" / f"{name}.hip"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DPMOE_STAMP",
+                               "-c", str(src), "-o", str(tmp_path / f"{name}_stamp.o")], stderr=subprocess.DEVNULL)
     assert (tmp_path / "conv_igemm_stamp.o").stat().st_size > 0
