@@ -383,6 +383,8 @@ def main():
             if code >= 8000:                      # e4m3 operands (BASELINE config 5): same tiles, TL = fp8
                 r, m, n = symbol(code - 8000)
                 return r.replace("<bf16,", "<bf16+e4m3,"), m.replace(f"E{tname}Ev8ConvArgs", "E3fp8Ev8ConvArgs"), n
+            if code == 5007:                      # LDS-DMA staged 3x3 kernel (conv_dma.hip)
+                return "conv3x3_dma_kernel", "void (anonymous namespace)::conv3x3_dma_kernel", 1
             four = code >= 4000
             code %= 4000
             if code == 3000:

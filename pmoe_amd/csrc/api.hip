@@ -83,6 +83,7 @@ static int to_wgrad_args(const pmoe_wgrad_desc* d, WgradArgs& a) {
     a.ipe = d->ipe; a.x_shared = d->x_shared;
     a.ks = d->ks; a.stride = d->stride; a.pad = d->pad; a.per_image = d->per_image;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = a.mb_per_wg = 0;
+    a.slice_fastest = 0;
     return 0;
 }
 

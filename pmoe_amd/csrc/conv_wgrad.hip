@@ -60,7 +60,10 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
     // (1.10 GB fetched per launch against 0.54 GB compulsory, profiles/traffic.json of round 1)
     const int npairs = n_ci_blk * ((a.Cout + CKW - 1) / CKW);
     const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
-    const int pair = (int)(flat % npairs), split = (int)(flat / npairs), nsplit = (int)(gridDim.x / npairs);
+    const int nsplit = (int)(gridDim.x / npairs);
+    // (a.slice_fastest: the round-1 order, K slice fastest -- A/B switch PMOE_WGRAD_SLICE_FASTEST=1)
+    const int pair = a.slice_fastest ? (int)(blockIdx.x / nsplit) : (int)(flat % npairs);
+    const int split = a.slice_fastest ? (int)(blockIdx.x % nsplit) : (int)(flat / npairs);
     const int cob = pair / n_ci_blk, cib = pair % n_ci_blk;
     const int co0 = cob * CKW, ci0 = cib * CKW;
 
@@ -308,6 +311,7 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
             if (TN != 1) return PMOE_ERR_UNSUPPORTED;
             a.mb_per_wg = a.tiles_y * a.tiles_x;
         }
+        { const char* ev = getenv("PMOE_WGRAD_SLICE_FASTEST"); a.slice_fastest = ev ? atoi(ev) : 0; }
         const int nsplit = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
         const long long ws = (a.per_image || nsplit == 1) ? 0 : (long long)nsplit * E * a.ks * a.ks * a.CoutP * a.CinP;
         if (plan) { *ws_floats = ws; return 0; }

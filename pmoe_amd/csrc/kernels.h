@@ -47,6 +47,7 @@ struct WgradArgs {
     int ks, stride, pad;
     int per_image;         // 1: dw is [N][taps][CoutP][CinP] -- one slab per IMAGE (no sum over the expert's images)
     int lTW, lTH, TN, n_groups, tiles_y, tiles_x, mb_per_wg;
+    int slice_fastest;     // launcher: grid order of round 1 (A/B switch)
 };
 
 // grouped skinny GEMM for the expert MLP layers (gemm_skinny.hip)
