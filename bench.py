@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-sub-configs", action="store_true",
                     help="skip the short sub-records of BASELINE configs C3 (per-GPU shard, E=8), C4 (punet) and C5 (fp8, B=128)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--only-steps", action="store_true",
+                    help="run warm-up + timed steps and print the basic line only (PMC traffic collection: tools/collect_traffic.py)")
     ap.add_argument("--measure-overlap", action="store_true",
                     help="also time the step with weight gradients on a side stream (co-running kernels: keep it out of "
                          "runs that are profiled per kernel)")
@@ -340,8 +342,15 @@ def main():
         out["step_mfma_frac"] = round(flop_per_sample * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)
         out["step_hbm_frac_model"] = round(HBM_BYTES_PER_SAMPLE_E4_256_BF16 * scale * value / world / 1e9 / PEAK_HBM_GBS, 4)
 
-    # ---- per-kernel timing with HIP events on the launch stream (one instrumented step, untimed region)
     log(f"timed: {ms:.2f} ms/step")
+    if args.only_steps:
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    # ---- per-kernel timing with HIP events on the launch stream (one instrumented step, untimed region)
     if not args.no_kernel_profile:
         # every rank runs this step (its backward holds collectives); only rank 0 records the per-launch events
         if rank == 0:

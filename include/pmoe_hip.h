@@ -32,11 +32,15 @@ extern "C" {
 #define PMOE_ACT_NONE 0
 #define PMOE_ACT_RELU 1
 #define PMOE_ACT_ELU 2
+#define PMOE_ACT_TANH 3    /* make_mlp `act` choices of model/blocks/basics.py:23-28 */
+#define PMOE_ACT_SIGMOID 4
 
 #define PMOE_RES_NONE 0
 #define PMOE_RES_ADD 1     /* out = acc + res                                   (residual / grad sum) */
 #define PMOE_RES_DRELU 2   /* out = acc * relu'(res), res = saved layer output  (MLP backward)        */
 #define PMOE_RES_DELU 3    /* out = acc * elu'(res),  res = saved layer output                        */
+#define PMOE_RES_DTANH 4   /* out = acc * (1 - res^2)                                                  */
+#define PMOE_RES_DSIGMOID 5 /* out = acc * res (1 - res)                                               */
 
 int pmoe_version(void);
 const char* pmoe_error_string(int code);
@@ -152,6 +156,12 @@ int pmoe_unpack_conv_wgrad(const float* dw_ws, float* grads, int32_t E, int32_t 
                            int32_t coutp, int32_t cinp, void* stream);
 /* bias pack: E pointers to f32 [cout] -> f32 [E][coutp] */
 int pmoe_pack_bias(const void* const* src_ptrs, float* dst, int32_t E, int32_t cout, int32_t coutp, void* stream);
+
+/* Stand-alone activation + inverted dropout over n contiguous elements (n % (16 / sizeof(element)) == 0):
+ * make_mlp with bn=True puts BatchNorm1d between the Linear and its activation (model/blocks/basics.py:30-39), so the
+ * activation cannot ride in the GEMM epilogue there.  act = PMOE_ACT_*; backward from the saved output y. */
+int pmoe_act_fwd(const void* x, void* y, int64_t n, int32_t act, float drop_p, uint64_t seed, int32_t dtype, void* stream);
+int pmoe_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int32_t act, float drop_p, int32_t dtype, void* stream);
 
 /* ---- BatchNorm2d, training mode (nn.BatchNorm2d at basics.py:101,121; torchvision bn1/bn2/downsample.1)
  * rows = N*H*W activations of C channels; expert e owns rows [e*rows_per_expert, ...).            */

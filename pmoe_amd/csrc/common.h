@@ -75,6 +75,21 @@ template <> __device__ __forceinline__ v4i pack16<float>(const float* f) {
 __device__ __forceinline__ v4i ldg16(const void* p) { return *reinterpret_cast<const v4i*>(p); }
 __device__ __forceinline__ void stg16(void* p, v4i v) { *reinterpret_cast<v4i*>(p) = v; }
 
+// Activations of make_mlp (model/blocks/basics.py:23-28) and their derivatives expressed through the SAVED OUTPUT y = act(z)
+// (the backward pass never keeps z): relu' = [y > 0], elu' = y > 0 ? 1 : y + 1, tanh' = 1 - y^2, sigmoid' = y (1 - y).
+__device__ __forceinline__ float act_apply(int act, float v) {
+    if (act == PMOE_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == PMOE_ACT_ELU) return v > 0.f ? v : expm1f(v);
+    if (act == PMOE_ACT_TANH) return tanhf(v);
+    if (act == PMOE_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+__device__ __forceinline__ float act_deriv_from_output(int res_mode, float y) {
+    if (res_mode == PMOE_RES_DELU) return y > 0.f ? 1.f : y + 1.f;
+    if (res_mode == PMOE_RES_DTANH) return 1.f - y * y;
+    return y * (1.f - y);                                // PMOE_RES_DSIGMOID
+}
+
 // 32-bit mix for the dropout mask (counter based: seed + element index -> uniform [0,1))
 __device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx) {
     unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;

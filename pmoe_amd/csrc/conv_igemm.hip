@@ -338,11 +338,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
                 } else if (a.res_mode == PMOE_RES_DRELU) {          // saved output y: relu'(y) (with dropout scale)
 #pragma unroll
                     for (int i = 0; i < VE; ++i) v[i] = rv[i] > 0.f ? v[i] * keep_scale : 0.f;
-                } else if (a.res_mode == PMOE_RES_DELU) {           // saved output y = elu(z) * mask * keep_scale
+                } else if (a.res_mode >= PMOE_RES_DELU) {               // saved output y = act(z) * mask * keep_scale
 #pragma unroll
                     for (int i = 0; i < VE; ++i) {
                         const float y = rv[i] * (1.f / keep_scale);
-                        const float d = y > 0.f ? 1.f : y + 1.f;
+                        const float d = act_deriv_from_output(a.res_mode, y);
                         v[i] = (a.drop_p > 0.f && rv[i] == 0.f) ? 0.f : v[i] * d * keep_scale;
                     }
                 }
@@ -350,9 +350,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
             if (a.act == PMOE_ACT_RELU) {
 #pragma unroll
                 for (int i = 0; i < VE; ++i) v[i] = fmaxf(v[i], 0.f);
-            } else if (a.act == PMOE_ACT_ELU) {
+            } else if (a.act != PMOE_ACT_NONE) {                     // elu / tanh / sigmoid
 #pragma unroll
-                for (int i = 0; i < VE; ++i) v[i] = v[i] > 0.f ? v[i] : expm1f(v[i]);
+                for (int i = 0; i < VE; ++i) v[i] = act_apply(a.act, v[i]);
             }
             if (a.drop_p > 0.f && a.res_mode < PMOE_RES_DRELU) {
                 const unsigned long long base = (unsigned long long)opix * (unsigned)a.Cout + cout;

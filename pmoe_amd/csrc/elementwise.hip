@@ -595,6 +595,46 @@ __global__ void __launch_bounds__(256) pad_rows_kernel(const float* __restrict__
 }
 
 // ================================================================================================
+// ------------------------------------------------------------------------------------------------
+// Stand-alone activation (+ inverted dropout) of make_mlp's BatchNorm1d layout (basics.py:30-39: Linear -> BN1d -> act ->
+// Dropout); without BatchNorm the activation lives in the GEMM epilogue.  Backward from the SAVED output.
+template <typename T>
+__global__ void __launch_bounds__(256) act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long nvec, int act,
+                                                     float drop_p, unsigned long long seed) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        float v[VE];
+        unpack16<T>(ldg16(x + i * VE), v);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) {
+            v[k] = act_apply(act, v[k]);
+            if (drop_p > 0.f) v[k] = hash_uniform(seed, (unsigned long long)i * VE + k) >= drop_p ? v[k] * keep_scale : 0.f;
+        }
+        stg16(y + i * VE, pack16<T>(v));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                     long long nvec, int act, float drop_p) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const int mode = act == PMOE_ACT_ELU ? PMOE_RES_DELU : act == PMOE_ACT_TANH ? PMOE_RES_DTANH : PMOE_RES_DSIGMOID;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        float g[VE], yv[VE];
+        unpack16<T>(ldg16(dy + i * VE), g);
+        unpack16<T>(ldg16(y + i * VE), yv);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) {
+            if (act == PMOE_ACT_NONE) g[k] = (drop_p > 0.f && yv[k] == 0.f) ? 0.f : g[k] * keep_scale;
+            else if (act == PMOE_ACT_RELU) g[k] = yv[k] > 0.f ? g[k] * keep_scale : 0.f;
+            else g[k] = (drop_p > 0.f && yv[k] == 0.f) ? 0.f : g[k] * act_deriv_from_output(mode, yv[k] * (1.f / keep_scale)) * keep_scale;
+        }
+        stg16(dx + i * VE, pack16<T>(g));
+    }
+}
+
 static inline int grid_for(long long nvec, int cap = 4096) {
     long long g = (nvec + 255) / 256;
     if (g > cap) g = cap;
@@ -677,6 +717,28 @@ int pmoe_bn_bwd_apply(const void* dy, const void* y, const void* x, const float*
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(nvec, cap), E), dim3(256), 0, (hipStream_t)stream,
                            (const T*)dy, (const T*)y, (const T*)x, mean, invstd, scale, shift, c1, c2, (T*)dx, (T*)gmask_out,
                            (long long)rows_per_expert, C, relu);
+        return (int)hipGetLastError();
+    });
+}
+
+int pmoe_act_fwd(const void* x, void* y, int64_t n, int32_t act, float drop_p, uint64_t seed, int32_t dtype, void* stream) {
+    if (!x || !y || n <= 0 || act < PMOE_ACT_NONE || act > PMOE_ACT_SIGMOID || drop_p < 0.f || drop_p >= 1.f) return PMOE_ERR_ARG;
+    DISPATCH_DT(dtype, {
+        constexpr int VE = 16 / (int)sizeof(T);
+        if (n % VE) return PMOE_ERR_ARG;
+        hipLaunchKernelGGL((act_fwd_kernel<T>), dim3(grid_for(n / VE)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y,
+                           (long long)(n / VE), act, drop_p, (unsigned long long)seed);
+        return (int)hipGetLastError();
+    });
+}
+
+int pmoe_act_bwd(const void* dy, const void* y, void* dx, int64_t n, int32_t act, float drop_p, int32_t dtype, void* stream) {
+    if (!dy || !y || !dx || n <= 0 || act < PMOE_ACT_NONE || act > PMOE_ACT_SIGMOID || drop_p < 0.f || drop_p >= 1.f) return PMOE_ERR_ARG;
+    DISPATCH_DT(dtype, {
+        constexpr int VE = 16 / (int)sizeof(T);
+        if (n % VE) return PMOE_ERR_ARG;
+        hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(grid_for(n / VE)), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+                           (const T*)y, (T*)dx, (long long)(n / VE), act, drop_p);
         return (int)hipGetLastError();
     });
 }

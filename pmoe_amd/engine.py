@@ -204,15 +204,14 @@ class ExpertGroupEngine:
             for s in seqs:
                 if s.spec != spec:
                     raise ValueError("experts of one mixture must share MLP configuration")
-            if spec["bn"]:
-                raise NotImplementedError(
-                    "make_mlp(bn=True) (BatchNorm1d heads, docs/experiments.md / stage_3.yaml) is not on the HIP "
-                    "path yet; every stage-2 config uses bn: False")
-            if spec["act"] not in ("relu", "elu"):
-                raise NotImplementedError(f"MLP activation {spec['act']!r} is not on the HIP path (stage-2 uses relu/elu)")
             lins = [[m for m in s if isinstance(m, B.Linear)] for s in seqs]
-            layers = [conv(f"{name}.{i}", [l[i] for l in lins]) for i in range(len(lins[0]))]
-            return dict(layers=layers, act=hip.ACT_RELU if spec["act"] == "relu" else hip.ACT_ELU,
+            bns = [[m for m in s if isinstance(m, B.BatchNorm1d)] for s in seqs]
+            layers, bn_layers = [], []
+            for i in range(len(lins[0])):             # forward order: Linear i, then its BatchNorm1d (basics.py:30-34)
+                layers.append(conv(f"{name}.{i}", [l[i] for l in lins]))
+                if spec["bn"] and i < len(lins[0]) - 1:
+                    bn_layers.append(bn(f"{name}.bn{i}", [b_[i] for b_ in bns]))
+            return dict(layers=layers, bns=bn_layers if spec["bn"] else None, act=hip.ACT_BY_NAME[spec["act"]],
                         l_act=spec["l_act"], dropout=spec["dropout"])
 
         self._mk = dict(conv=conv, bn=bn, eca=eca, mlp=mlp)
@@ -483,7 +482,7 @@ class ExpertGroupEngine:
             if x.act != hip.ACT_NONE:
                 if prev is not None:
                     raise RuntimeError("activation output consumed twice: unsupported gradient accumulation")
-                res, res_mode = x.t, (hip.RES_DRELU if x.act == hip.ACT_RELU else hip.RES_DELU)
+                res, res_mode = x.t, hip.RES_OF_ACT[x.act]
             elif prev is not None:
                 res, res_mode = prev, hip.RES_ADD       # second consumer: accumulate in the epilogue
             g = prev if prev is not None else torch.empty_like(x.t)
@@ -491,7 +490,7 @@ class ExpertGroupEngine:
             ops.conv2d(dy, layer.w_dg, g, cin=layer.dg_red, cout=layer.cinp, coutp=layer.dg_rows, ipe=self.B,
                        ks=layer.ks, stride=1, pad=layer.ks - 1 - layer.pad, dilate=(layer.stride == 2),
                        in_coff=o.coff, out_coff=x.coff, res=res, res_coff=x.coff, res_mode=res_mode,
-                       drop_p=x.drop_p if res_mode in (hip.RES_DRELU, hip.RES_DELU) else 0.0)
+                       drop_p=x.drop_p if res_mode >= hip.RES_DRELU else 0.0)
             x.set_grad(g)
 
     @staticmethod
@@ -812,10 +811,37 @@ class ExpertGroupEngine:
                 x.set_grad(dx)
             self.tape.append(bwd)
 
+    def _act(self, x, act, drop_p):
+        """y = dropout(act(x)) as its own pass (behind a BatchNorm1d, basics.py:34-39); backward from the saved output."""
+        y = Var(torch.empty_like(x.t))
+        seed = (next(self._seed_counter) * 0x9E3779B1 + self.base_seed) & 0xFFFFFFFFFFFF if drop_p > 0 else 0
+        ops.act_fwd(x.t, y.t, act, drop_p, seed)
+        y.needs_grad = x.needs_grad
+        if self.taping and y.needs_grad:
+            def bwd():
+                if y.grad is None:
+                    return
+                dx = torch.empty_like(x.t)
+                ops.act_bwd(y.grad, y.t, dx, act, drop_p)
+                x.set_grad(dx)
+            self.tape.append(bwd)
+        return y
+
     def _mlp(self, x, spec, out=None, out_coff=0, in_shared=False):
         layers = spec["layers"]
         drop = spec["dropout"] if self.training else 0.0
         v = x
+        if spec.get("bns") is not None:
+            # make_mlp(bn=True): Linear (no bias) -> BatchNorm1d over the expert's batch rows -> act -> Dropout per hidden
+            # layer, bare Linear last (basics.py:30-42; docs/experiments.md, conf/stage_3.yaml)
+            for i, layer in enumerate(layers):
+                last = i == len(layers) - 1
+                if last:
+                    act = spec["act"] if spec["l_act"] else hip.ACT_NONE
+                    return self._conv(v, layer, act=act, out=out, out_coff=out_coff, in_shared=in_shared and i == 0)
+                z = self._conv(v, layer, bias=False, in_shared=in_shared and i == 0)
+                v = self._act(self._bn(z, spec["bns"][i], relu=False), spec["act"], drop)
+            return v
         for i, layer in enumerate(layers):
             last = i == len(layers) - 1
             act = spec["act"] if (not last or spec["l_act"]) else hip.ACT_NONE

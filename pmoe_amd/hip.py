@@ -16,8 +16,11 @@ _LIB_PATH = Path(os.environ.get("PMOE_HIP_LIB") or Path(__file__).resolve().pare
 _lib = None
 
 DT_BF16, DT_F32 = 0, 1
-ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
-RES_NONE, RES_ADD, RES_DRELU, RES_DELU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+RES_NONE, RES_ADD, RES_DRELU, RES_DELU, RES_DTANH, RES_DSIGMOID = 0, 1, 2, 3, 4, 5
+# derivative mode that undoes each activation in the data-gradient epilogue (from the layer's saved output)
+RES_OF_ACT = {ACT_RELU: RES_DRELU, ACT_ELU: RES_DELU, ACT_TANH: RES_DTANH, ACT_SIGMOID: RES_DSIGMOID}
+ACT_BY_NAME = {"relu": ACT_RELU, "elu": ACT_ELU, "tanh": ACT_TANH, "sigmoid": ACT_SIGMOID}
 
 _TORCH_DT = {torch.bfloat16: DT_BF16, torch.float32: DT_F32}
 
@@ -73,6 +76,8 @@ SIGNATURES = {
     "pmoe_pack_conv_weights_gated": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_unpack_conv_wgrad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_bias": [_P, _P, _I, _I, _I, _P],
+    "pmoe_act_fwd": [_P, _P, _L, _I, _F, C.c_uint64, _I, _P],
+    "pmoe_act_bwd": [_P, _P, _P, _L, _I, _F, _I, _P],
     "pmoe_colstats": [_P, _L, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "pmoe_reduce_partials": [_P, _P, _I, _I, _I, _I, _P],
     "pmoe_bn_finalize": [_P, _I, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P],

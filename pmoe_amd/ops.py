@@ -160,6 +160,16 @@ def pack_bias(ptr_tab, dst, E, cout, coutp):
                                 stream_ptr()), "pmoe_pack_bias")
 
 
+def act_fwd(x, y, act, drop_p=0.0, seed=0):
+    check(load().pmoe_act_fwd(ptr(x, "x"), ptr(y, "y", x.dtype), x.numel(), act, float(drop_p), int(seed), dt(x), stream_ptr()),
+          "pmoe_act_fwd")
+
+
+def act_bwd(dy, y, dx, act, drop_p=0.0):
+    check(load().pmoe_act_bwd(ptr(dy, "dy"), ptr(y, "y", dy.dtype), ptr(dx, "dx", dy.dtype), dy.numel(), act, float(drop_p),
+                              dt(dy), stream_ptr()), "pmoe_act_bwd")
+
+
 def colstats(x2d_rows_per_expert, x, E, C_, part, nparts, ld=None, coff=0, shiftc=None):
     """partial sums of (x - c), (x - c)^2 with c = row 0 of each expert (stored to shiftc [E,C]); c = 0 if None."""
     check(load().pmoe_colstats(ptr(x, "x"), x2d_rows_per_expert, E, C_, ld if ld is not None else x.shape[-1], coff,

@@ -126,6 +126,102 @@ def test_lone_expert_forward(alt):
     assert statistics.median(errs) <= 5e-3 and max(errs) <= 0.15, (statistics.median(errs), max(errs))
 
 
+def test_mlp_activation_choices_tanh_sigmoid():
+    """make_mlp's `act` may be relu / tanh / sigmoid / elu (basics.py:23-28).  A mixture whose encoders use sigmoid and whose
+    heads use tanh, against the oracle: forward 1e-4, every gradient tensor within 5e-3 (median) / 0.15."""
+    import statistics
+    from oracle import pmoe_oracle as O, weights as W
+    from pmoe_amd.loss import moe_loss
+    from pmoe_amd.model.moe import get_model
+    from pmoe_amd.utils import stage2_model_cfg
+    from tests.parity_util import rel_l2
+
+    def tweak(cfg):
+        cfg.speed_encoder.act = cfg.command_encoder.act = "sigmoid"
+        cfg.action_head.act = cfg.speed_prediction.act = "tanh"
+        return cfg
+    ocfg = tweak(O.stage2_cfg("moe", 2))
+    oracle = O.get_model(ocfg)
+    W.fill_state_dict(oracle, seed=11)
+    oracle.train()
+    model = get_model(tweak(stage2_model_cfg("moe", 2, dropout=0.0)))
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model = model.cuda()
+    model.compute_dtype = torch.float32
+    model.train()
+    inp = W.make_inputs(4, 64, 64, seed=21)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+    od, os_ = oracle(inp["images"], inp["speed"], inp["command"])
+    for a, b in zip(dist.hip_params + (speeds,), (od.mixture_distribution.probs, od.component_distribution.base_dist.loc,
+                                                  od.component_distribution.base_dist.scale, os_)):
+        assert rel_err(a, b) <= 1e-4, rel_err(a, b)
+    moe_loss(dist, speeds, dev["control"], dev["target_speed"], ocfg.loss_coefs).backward()
+    O.moe_loss(od, os_, inp["control"], inp["target_speed"], ocfg.loss_coefs).backward()
+    og = dict(oracle.named_parameters())
+    errs = [rel_l2(p.grad, og[k].grad) for k, p in model.named_parameters() if og[k].grad.norm() > 0]
+    assert statistics.median(errs) <= 5e-3 and max(errs) <= 0.15, (statistics.median(errs), max(errs))
+    # and in bf16 with dropout: runs, finite, dropout masks reproducible under a fixed seed
+    m2 = get_model(tweak(stage2_model_cfg("moe", 2, dropout=0.3))).cuda()
+    m2.train()
+    torch.manual_seed(5)
+    d1, s1 = m2(dev["images"], dev["speed"], dev["command"])
+    moe_loss(d1, s1, dev["control"], dev["target_speed"], [0.7, 0.3]).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m2.parameters())
+
+
+def test_mlp_with_batchnorm1d_heads():
+    """make_mlp(bn=True) (docs/experiments.md:17-40, conf/stage_3.yaml:77-100): Linear without bias -> BatchNorm1d -> act ->
+    Dropout per hidden layer.  state_dict layout of SURVEY appendix B, forward 1e-4, gradients, BatchNorm1d buffers."""
+    import statistics
+    from oracle import pmoe_oracle as O, weights as W
+    from pmoe_amd.loss import moe_loss
+    from pmoe_amd.model.moe import get_model
+    from pmoe_amd.utils import stage2_model_cfg
+    from tests.parity_util import rel_l2
+
+    def tweak(cfg):
+        for k in ("speed_encoder", "command_encoder", "action_head", "speed_prediction"):
+            cfg[k].bn = True
+        cfg.command_encoder.act = "tanh"
+        return cfg
+    ocfg = tweak(O.stage2_cfg("moe", 2))
+    oracle = O.get_model(ocfg)
+    W.fill_state_dict(oracle, seed=13)
+    oracle.train()
+    model = get_model(tweak(stage2_model_cfg("moe", 2, dropout=0.0)))
+    sd = oracle.state_dict()
+    assert "moe.0.speed_encoder.1.running_mean" in sd and "moe.0.speed_encoder.0.bias" not in sd     # BN at index 1, no bias
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda()
+    model.compute_dtype = torch.float32
+    model.train()
+    inp = W.make_inputs(6, 64, 64, seed=23)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+    od, os_ = oracle(inp["images"], inp["speed"], inp["command"])
+    for a, b in zip(dist.hip_params + (speeds,), (od.mixture_distribution.probs, od.component_distribution.base_dist.loc,
+                                                  od.component_distribution.base_dist.scale, os_)):
+        assert rel_err(a, b) <= 1e-4, rel_err(a, b)
+    moe_loss(dist, speeds, dev["control"], dev["target_speed"], ocfg.loss_coefs).backward()
+    O.moe_loss(od, os_, inp["control"], inp["target_speed"], ocfg.loss_coefs).backward()
+    og = dict(oracle.named_parameters())
+    errs = [rel_l2(p.grad, og[k].grad) for k, p in model.named_parameters() if og[k].grad.norm() > 0]
+    assert statistics.median(errs) <= 5e-3 and max(errs) <= 0.15, (statistics.median(errs), max(errs))
+    osd, msd = oracle.state_dict(), model.state_dict()
+    for k in osd:
+        if k.endswith("num_batches_tracked"):
+            assert int(msd[k]) == int(osd[k]), k
+        elif "running_" in k and ("encoder" in k or "speed_pred" in k or "action_features" in k):
+            assert rel_err(msd[k], osd[k]) <= 1e-4, k
+    model.eval()
+    oracle.eval()
+    with torch.no_grad():
+        d2, _ = model(dev["images"], dev["speed"], dev["command"])
+        o2, _ = oracle(inp["images"], inp["speed"], inp["command"])
+    assert rel_err(d2.hip_params[1], o2.component_distribution.base_dist.loc) <= 1e-3
+
+
 def test_module_contract():
     """deepcopy (AveragedModel), freeze-by-name, state_dict round trip, frozen parameters get no grads."""
     from pmoe_amd.loss import moe_loss

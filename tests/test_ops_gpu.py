@@ -203,7 +203,8 @@ def test_conv_shared_input_and_epilogues(dtype):
     ops.pack_bias(hip.ptr_table(dev_b, DEV), bias, E, Nn, r64(Nn))
     xd = torch.zeros(ipe, 1, 1, 16, dtype=dtype, device=DEV)
     xd[:, 0, 0, :K] = x.to(dtype).to(DEV)
-    for act, fn in ((hip.ACT_RELU, torch.relu), (hip.ACT_ELU, F.elu), (hip.ACT_NONE, lambda t: t)):
+    for act, fn in ((hip.ACT_RELU, torch.relu), (hip.ACT_ELU, F.elu), (hip.ACT_TANH, torch.tanh), (hip.ACT_SIGMOID, torch.sigmoid),
+                    (hip.ACT_NONE, lambda t: t)):
         out = torch.zeros(E * ipe, 1, 1, 1536, dtype=dtype, device=DEV)
         ops.conv2d(xd, wf, out, cin=16, cout=Nn, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, in_shared=True,
                    out_coff=512, bias=bias, act=act)
@@ -230,6 +231,15 @@ def test_conv_shared_input_and_epilogues(dtype):
     ops.conv2d(xd, wf, out3, cin=16, cout=Nn, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, in_shared=True,
                res=ysd, res_mode=hip.RES_DELU)
     close(out3.view(E * ipe, Nn), lin * torch.where(y_saved > 0, torch.ones_like(y_saved), y_saved + 1), dtype, "delu")
+    # tanh' / sigmoid' from the saved output (make_mlp act choices of basics.py:23-28)
+    yt = torch.tanh(y_saved).to(dtype).float()
+    ops.conv2d(xd, wf, out3, cin=16, cout=Nn, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, in_shared=True,
+               res=yt.to(dtype).to(DEV).view(E * ipe, 1, 1, Nn).contiguous(), res_mode=hip.RES_DTANH)
+    close(out3.view(E * ipe, Nn), lin * (1 - yt * yt), dtype, "dtanh")
+    ysg = torch.sigmoid(y_saved).to(dtype).float()
+    ops.conv2d(xd, wf, out3, cin=16, cout=Nn, coutp=r64(Nn), ipe=ipe, ks=1, stride=1, pad=0, in_shared=True,
+               res=ysg.to(dtype).to(DEV).view(E * ipe, 1, 1, Nn).contiguous(), res_mode=hip.RES_DSIGMOID)
+    close(out3.view(E * ipe, Nn), lin * ysg * (1 - ysg), dtype, "dsigmoid")
 
 
 @pytest.mark.parametrize("case", [(4, 64, 512, 512), (4, 64, 1536, 512), (2, 37, 512, 5), (3, 70, 512, 1536), (1, 130, 48, 64)])

@@ -3,9 +3,9 @@
 separate --pmc passes, counter unit = KiB, FETCH doubled on gfx950.  Writes profiles/traffic.json.
 
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
-  python3 $R/tools/collect_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/bench.py --steps 4 --warmup 1 --only-steps
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o w -- python3 $R/bench.py --steps 4 --warmup 1 --only-steps
+  python3 $R/tools/collect_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write 5      (5 = steps the profiled command ran)
 """
 import csv
 import json
@@ -21,7 +21,7 @@ def read(dirpath, counter):
             for row in csv.DictReader(fh):
                 if row.get("Counter_Name") != counter:
                     continue
-                name = row["Kernel_Name"].split("(")[0][:80]
+                name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:80]
                 a = acc[name]
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
@@ -30,6 +30,7 @@ def read(dirpath, counter):
 
 def main():
     fdir, wdir = sys.argv[1], sys.argv[2]
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     fetch, write = read(fdir, "FETCH_SIZE"), read(wdir, "WRITE_SIZE")
     per, conv_b, conv_n = {}, 0.0, 0
     for name in sorted(set(fetch) | set(write)):
@@ -38,10 +39,20 @@ def main():
         n = max(fn, wn, 1)
         f2, w = fb * 1024 * 2 / n, wb * 1024 / n           # KiB units; gfx950: FETCH_SIZE counts half of the bytes
         per[name] = {"launches": n, "fetch_bytes_per_launch_x2": f2, "write_bytes_per_launch": w}
-        if "conv_igemm_kernel" in name or "conv3x3_res_kernel" in name:
+        if "conv_igemm" in name or "conv3x3_res_kernel" in name or "conv3x3_dma_kernel" in name:
             conv_b += (f2 + w) * n
             conv_n += n
+    total = sum((v["fetch_bytes_per_launch_x2"] + v["write_bytes_per_launch"]) * v["launches"] for v in per.values())
+    by_group = defaultdict(float)
+    for k, v in per.items():
+        grp = ("conv fwd/dgrad" if ("conv_igemm" in k or "conv3x3" in k or "gemm_skinny" in k) else "conv wgrad" if "wgrad" in k
+               else "batchnorm" if ("bn_" in k or "colstats" in k or "reduce_partials" in k) else "stem tail" if "stem_tail" in k
+               else "other")
+        by_group[grp] += (v["fetch_bytes_per_launch_x2"] + v["write_bytes_per_launch"]) * v["launches"]
     out = {"conv_igemm_bytes_per_launch": conv_b / max(conv_n, 1),
+           "steps_profiled": steps,
+           "hbm_gb_per_step": round(total / steps / 1e9, 2) if steps else None,
+           "hbm_gb_per_step_by_group": {k: round(v / steps / 1e9, 2) for k, v in by_group.items()} if steps else None,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units x1024, FETCH doubled (gfx950 "
                    "correction, MI355X_MICROARCH.md HBM section); average over conv_igemm_kernel* and conv3x3_res_kernel* "
                    "launches of python bench.py --steps 2 --warmup 1 (tools/collect_traffic.py)",
