@@ -232,6 +232,209 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the dense 3x3 stride-1 layers in bf16 (the 15 big launches of a step): the dY tile and the X halo
+// patch of the NEXT m-block travel global -> LDS by `buffer_load_dwordx4 ... lds` while the current m-block is computed
+// out of the other buffer pair: no staging registers (40 VGPRs of the kernel above), no commit pass, ONE barrier per
+// m-block instead of two.  LDS-DMA writes lane-linearly (8 pixel rows of 128 B per wave-instruction), so the 192-byte row
+// padding of the kernel above is not available; the transposed reads stay conflict-free through an XOR on the 64-byte half
+// of a row keyed by bit 1 of the pixel's COLUMN (the 4 rows of a ds_read_b64_tr_b16 block then hit 4 different 64-byte
+// bank ranges for every tap shift), applied to the per-lane SOURCE address and to the reads.  The key of a read is
+// lane-constant per tap column (3 precomputed offsets), so a tap still costs one immediate row offset.  Out-of-image
+// pixels, images beyond the expert's last and channels beyond Cin / Cout arrive as zeros from the buffer range check.
+template <bool PIN>
+__global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, const int magic_pw, const int magic_ph) {
+    constexpr int TAPS = 9, RS = 128, CKW = 64;
+    constexpr int WCI = 2, WCO = 2, WK = 2;
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ci_sub = wave % WCI, co_sub = (wave / WCI) % WCO, k_sub = wave / (WCI * WCO);
+
+    const int e = blockIdx.z;
+    const int n_ci_blk = (a.Cin + CKW - 1) / CKW;
+    const int npairs = n_ci_blk * ((a.Cout + CKW - 1) / CKW);
+    const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
+    const int nsplit = (int)(gridDim.x / npairs);
+    const int pair = (int)(flat % npairs), split = (int)(flat / npairs);
+    const int cob = pair / n_ci_blk, cib = pair % n_ci_blk;
+    const int co0 = cob * CKW, ci0 = cib * CKW;
+
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int PW = TW + 2, PH = TH + 2;
+    const int NPIX = a.TN * PH * PW;
+    const int NPIECE = (NPIX + 7) >> 3;
+    const int BMP = a.TN << (lTW + lTH);                 // 256
+    const int XB = NPIECE << 10;                         // bytes of one X patch buffer
+    const int pair_bytes = (BMP << 7) + XB;              // dY tile + X patch of one m-block
+    const int my_pieces = (NPIECE - wave + 7) >> 3;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+
+    const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
+    const int mb_begin = split * a.mb_per_wg;
+    int mb_end = mb_begin + a.mb_per_wg;
+    if (mb_end > mbpe) mb_end = mbpe;
+
+    // buffer resources: one expert's images (offsets < 2^31 bytes; the launcher checks)
+    const bf16* xb = (const bf16*)a.x + (a.x_shared ? (size_t)0 : (size_t)e * a.ipe * a.H * a.W * a.x_ld) + a.x_coff + ci0;
+    const bf16* dyb = (const bf16*)a.dy + (size_t)e * a.ipe * a.Ho * a.Wo * a.dy_ld + a.dy_coff + co0;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)xb, (short)0, (int)(((long long)a.ipe * a.H * a.W * a.x_ld - a.x_coff - ci0) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)dyb, (short)0, (int)(((long long)a.ipe * a.Ho * a.Wo * a.dy_ld - a.dy_coff - co0) * 2), 0x00020000);
+    constexpr int OOB = 0x7ff80000;
+
+    auto issue = [&](int mbi, int buf) {
+        int t = mbi;
+        const int px_t = t % a.tiles_x; t /= a.tiles_x;
+        const int py_t = t % a.tiles_y; t /= a.tiles_y;
+        const int n0 = t * a.TN;                         // image index inside the expert
+        const int oy0 = py_t * TH, ox0 = px_t * TW;
+        char* base = smem + buf * pair_bytes;
+        // dY tile: 32 pieces of 8 pixels, 4 per wave
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = ((wave + 8 * i) << 3) + (lane >> 3);
+            const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+            const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
+            const int j = (lane & 7) ^ (((p >> 1) & 1) << 2);
+            const bool ok = n < a.ipe && oy < a.Ho && ox < a.Wo && co0 + j * 8 < a.Cout;
+            const int voff = ok ? ((((n * a.Ho + oy) * a.Wo + ox) * a.dy_ld) << 1) + (j << 4) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void*)(base + ((wave + 8 * i) << 10)), 16, voff, 0, 0, 0);
+        }
+        // X halo patch: NPIECE pieces, up to 6 per wave
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i < my_pieces) {
+                const int pp = ((wave + 8 * i) << 3) + (lane >> 3);
+                const int rowq = (pp * magic_pw) >> 16, px = pp - rowq * PW;
+                const int pn = (rowq * magic_ph) >> 16, prow = rowq - pn * PH;
+                const int n = n0 + pn, Y = oy0 - a.pad + prow, X = ox0 - a.pad + px;
+                const int j = (lane & 7) ^ (((px >> 1) & 1) << 2);
+                const bool ok = pp < NPIX && n < a.ipe && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W &&
+                                ci0 + j * 8 < a.Cin;
+                const int voff = ok ? ((((n * a.H + Y) * a.W + X) * a.x_ld) << 1) + (j << 4) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(base + (BMP << 7) + ((wave + 8 * i) << 10)), 16,
+                                                         voff, 0, 0, 0);
+            }
+        }
+    };
+
+    // lane-constant parts of the transposed-fragment addresses (g = lane >> 4: channel block g & 1, k half g >> 1;
+    // q = (lane >> 2) & 3: pixel of the 4-row block this lane addresses; pc = lane & 3: 4-channel column group)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+    const int ca_sw = (((co_sub * 4 + (g & 1) * 2 + (pc >> 1)) ^ (((q >> 1) & 1) << 2)) << 4) + 8 * (pc & 1);
+    int cb_sw[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+        cb_sw[kx] = (((ci_sub * 4 + (g & 1) * 2 + (pc >> 1)) ^ ((((q + kx) >> 1) & 1) << 2)) << 4) + 8 * (pc & 1);
+
+    if (mb_begin < mb_end) issue(mb_begin, 0);
+    for (int mbi = mb_begin; mbi < mb_end; ++mbi) {
+        const int buf = (mbi - mb_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's pieces of m-block mbi; its reads of mbi-1
+        __builtin_amdgcn_s_barrier();                   // every wave's pieces are in LDS; the other buffer pair is free
+        if (mbi + 1 < mb_end) issue(mbi + 1, buf ^ 1);  // lands under this m-block's MFMAs
+        const char* dyt = smem + buf * pair_bytes;
+        const char* patch = dyt + (BMP << 7);
+        // k-blocks of 16 pixels; the X fragment of tap t+1 is read BEFORE the MFMA of tap t, order pinned: with one dY fragment
+        // per 9 MFMAs every MFMA otherwise waits for the two transposed reads hipcc sinks directly in front of it
+        // (interleaved A/B, tools/ab_conv.py: +8-10 % on layer1-4; a depth of 2, or reading ahead across k-block boundaries,
+        // adds nothing)
+        auto frag_addr = [&](int kb, int* pA, int* ppB) {
+            const int p0 = kb << 4;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int p = p0 + 8 * (g >> 1) + 4 * tt + q;
+                pA[tt] = p;
+                const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+                ppB[tt] = (pn * PH + my) * PW + mx;
+            }
+        };
+        auto read_a = [&](const int* pA) {
+            bf16x8 fa;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const s16x4 r = tr_read(dyt + pA[tt] * RS + ca_sw);
+                const bf16x4 rb = __builtin_bit_cast(bf16x4, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[4 * tt + i] = rb[i];
+            }
+            return fa;
+        };
+        auto read_b = [&](const int* ppB, int tap) {
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) * RS;                 // wave-uniform
+            bf16x8 fb;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const s16x4 r = tr_read(patch + ppB[tt] * RS + tapoff + cb_sw[tap % 3]);
+                const bf16x4 rb = __builtin_bit_cast(bf16x4, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fb[4 * tt + i] = rb[i];
+            }
+            return fb;
+        };
+#pragma unroll 2
+        for (int kb = k_sub; kb < (BMP >> 4); kb += WK) {
+            int pA[2], ppB[2];
+            frag_addr(kb, pA, ppB);
+            const bf16x8 fa = read_a(pA);
+            bf16x8 fbq[2];                                // static double buffer: tap t lives in fbq[t & 1]
+            fbq[0] = read_b(ppB, 0);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                if (tap + 1 < TAPS) fbq[(tap + 1) & 1] = read_b(ppB, tap + 1);
+                if (PIN) __builtin_amdgcn_sched_barrier(0);       // (PIN = false: A/B switch, hipcc places the reads)
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbq[tap & 1], acc[tap], 0, 0, 0);
+                if (PIN) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // flush (as in conv_wgrad_kernel): fixed-order fold of the two pixel halves through LDS, plain stores
+    constexpr int TPR = 3, TILE_WAVES = WCO * WCI;
+    float* red = reinterpret_cast<float*>(smem);
+    const int tw = wave % TILE_WAVES;
+    const int cin = ci0 + ci_sub * 32 + l31;
+    const size_t slab = a.per_image ? (size_t)e * a.ipe + split : (size_t)split * gridDim.z + e;
+    float* dst = (a.per_image || nsplit == 1) ? a.dw : a.part;
+#pragma unroll
+    for (int t0 = 0; t0 < TAPS; t0 += TPR) {
+        __syncthreads();
+        if (k_sub > 0) {
+#pragma unroll
+            for (int tp = 0; tp < TPR; ++tp)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[((((k_sub - 1) * TPR + tp) * TILE_WAVES + tw) * 16 + r) * 64 + lane] = acc[t0 + tp][r];
+        }
+        __syncthreads();
+        if (k_sub == 0) {
+#pragma unroll
+            for (int tp = 0; tp < TPR; ++tp) {
+                float* base = dst + ((slab * TAPS + t0 + tp) * a.CoutP) * a.CinP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[t0 + tp][r];
+#pragma unroll
+                    for (int k = 1; k < WK; ++k) v += red[((((k - 1) * TPR + tp) * TILE_WAVES + tw) * 16 + r) * 64 + lane];
+                    const int cout = co0 + co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    base[(size_t)cout * a.CinP + cin] = v;
+                }
+            }
+        }
+    }
+}
+
 // dw[i] = sum over the K-split slabs, fixed order (slab s at part + s * total)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            const int nsplit, const long long total4) {
@@ -316,6 +519,40 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
         const long long ws = (a.per_image || nsplit == 1) ? 0 : (long long)nsplit * E * a.ks * a.ks * a.CoutP * a.CinP;
         if (plan) { *ws_floats = ws; return 0; }
         if (ws > 0 && (!a.part || a.part_floats < ws)) return PMOE_ERR_ARG;
+        if constexpr (sizeof(T) == 2) {
+            // dense 3x3 stride 1 in bf16: the LDS-DMA variant (PMOE_WGRAD_DMA=0: A/B switch back to register staging)
+            const char* evd = getenv("PMOE_WGRAD_DMA");      // (read per launch: tools/ab_conv.py flips it inside one process)
+            const int dma_on = evd ? atoi(evd) : 1;
+            const long long xbytes = (long long)a.ipe * a.H * a.W * a.x_ld * 2, dybytes = (long long)a.ipe * a.Ho * a.Wo * a.dy_ld * 2;
+            const int npiece = (NPIX + 7) / 8;
+            const int mpw = 65536 / PW + 1, mph = 65536 / PH + 1;
+            bool exact = true;
+            for (int pp = 0; pp < npiece * 8 && exact; ++pp)
+                exact = ((pp * mpw) >> 16) == pp / PW && ((((pp / PW) * mph) >> 16) == (pp / PW) / PH);
+            if (dma_on && a.ks == 3 && a.stride == 1 && BMP == 256 && lTW >= 2 && npiece <= 48 && exact &&
+                xbytes < 0x7ff00000ll && dybytes < 0x7ff00000ll && 2 * ((size_t)BMP * 128 + (size_t)npiece * 1024) <= 160 * 1024) {
+                size_t sm = 2 * ((size_t)BMP * 128 + (size_t)npiece * 1024);
+                if (sm < 49152) sm = 49152;               // room for the flush's fold
+                const int nsp = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
+                dim3 grid(nsp * pairs / E, 1, E), block(512, 1, 1);
+                const char* evx = getenv("PMOE_WGRAD_PIPE");
+                if (evx && !atoi(evx)) {
+                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<false>>(160 * 1024)));
+                    hipLaunchKernelGGL(conv_wgrad_dma_kernel<false>, grid, block, sm, st, a, mpw, mph);
+                } else {
+                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<true>>(160 * 1024)));
+                    hipLaunchKernelGGL(conv_wgrad_dma_kernel<true>, grid, block, sm, st, a, mpw, mph);
+                }
+                HIP_RET(hipGetLastError());
+                if (!a.per_image && nsp > 1) {
+                    const long long total4 = (long long)E * 9 * a.CoutP * a.CinP / 4;
+                    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a.part,
+                                       a.dw, nsp, total4);
+                    HIP_RET(hipGetLastError());
+                }
+                return 0;
+            }
+        }
         if (need <= M1) return a.ks == 3 ? launch_wg<T, 9, M1>(a, E, smem, st) : launch_wg<T, 1, M1>(a, E, smem, st);
         return a.ks == 3 ? launch_wg<T, 9, M2>(a, E, smem, st) : launch_wg<T, 1, M2>(a, E, smem, st);
     }

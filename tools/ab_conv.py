@@ -46,11 +46,16 @@ def main():
 
         def dgrad():
             ops.conv2d(dy, wd, dx, cin=cout, cout=cin, coutp=cin, ipe=B, ks=3, stride=1, pad=1)
-        times = {(v, k): [] for v in values for k in ("fwd", "dgrad")}
+        wsb = torch.empty(E, 9, cout, cin, device="cuda")
+
+        def wgrad():
+            ops.conv2d_wgrad(x, dy, wsb, cin=cin, cout=cout, cinp=cin, coutp=cout, ipe=B, ks=3, stride=1, pad=1)
+        kinds = (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad))
+        times = {(v, k): [] for v in values for k, _ in kinds}
         for rnd in range(12):
             for v in values:
                 os.environ[var] = v
-                for k, fn in (("fwd", fwd), ("dgrad", dgrad)):
+                for k, fn in kinds:
                     fn()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -61,9 +66,10 @@ def main():
                     if rnd >= 2:
                         times[(v, k)].append(e0.elapsed_time(e1) / 5)
         for v in values:
-            f, d = statistics.median(times[(v, "fwd")]), statistics.median(times[(v, "dgrad")])
+            f, d, w = (statistics.median(times[(v, k)]) for k in ("fwd", "dgrad", "wgrad"))
             print(f"{name} {var}={v}: fwd {f:.3f} ms {flop / f / 1e9:7.1f} TF/s (min {min(times[(v, 'fwd')]):.3f}) | "
-                  f"dgrad {d:.3f} ms {flop / d / 1e9:7.1f} TF/s (min {min(times[(v, 'dgrad')]):.3f})", flush=True)
+                  f"dgrad {d:.3f} ms {flop / d / 1e9:7.1f} TF/s (min {min(times[(v, 'dgrad')]):.3f}) | "
+                  f"wgrad {w:.3f} ms {flop / w / 1e9:7.1f} TF/s (min {min(times[(v, 'wgrad')]):.3f})", flush=True)
 
 
 if __name__ == "__main__":
