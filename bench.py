@@ -389,6 +389,11 @@ def main():
         kdt = "f32" if args.dtype == "f32" else "bf16"
 
         def symbol(code):
+            if code == 7009:                      # LDS-DMA staged weight gradient (conv_wgrad.hip)
+                return "conv_wgrad_dma_kernel", "void conv_wgrad_dma_kernel<true>", 1
+            if 6000 <= code < 7000:               # conv_wgrad_kernel<T, taps, MAXV>
+                taps, maxv = (code - 6000) // 100, (code - 6000) % 100
+                return (f"conv_wgrad_kernel<{kdt},{taps},{maxv}>", f"_Z17conv_wgrad_kernelI{tname}Li{taps}ELi{maxv}EEv9WgradArgs", 1)
             if code >= 8000:                      # e4m3 operands (BASELINE config 5): same tiles, TL = fp8
                 r, m, n = symbol(code - 8000)
                 return r.replace("<bf16,", "<bf16+e4m3,"), m.replace(f"E{tname}Ev8ConvArgs", "E3fp8Ev8ConvArgs"), n
@@ -408,7 +413,7 @@ def main():
                     f"_Z17conv_igemm_kernelI{tname}Li{rb}ELi{wm}ELi{wn}E{tname}Ev8ConvArgs", 4 if four else 1)
         groups = {}
         for name, meta, ms_k in recs:
-            if name != "conv2d" or "kernel" not in meta:
+            if name not in ("conv2d", "conv2d_wgrad") or "kernel" not in meta:
                 continue
             readable, mangled, per_call = symbol(int(meta["kernel"]))
             g = groups.setdefault(mangled, {"kernel": readable, "ms": 0.0, "launches": 0, "flop": 0.0})
@@ -425,9 +430,12 @@ def main():
             tf = REPO / "profiles" / "traffic.json"
             if tf.exists():
                 pk = json.loads(tf.read_text()).get("per_kernel", {})
-                hit = [v for k, v in pk.items() if k.startswith(mangled)]
+                norm = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "")
+                hit = [v for k, v in pk.items() if norm(k).startswith(norm(mangled))]
                 if hit:
                     traffic = hit[0]["fetch_bytes_per_launch_x2"] + hit[0]["write_bytes_per_launch"]
+            # the dominant kernel = the MFMA kernel instantiation with the most time per step (forward / data-gradient and
+            # weight-gradient kernels alike); every instantiation's own figure is in `conv_kernels`
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "rocprof_name": mangled,
                                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic,

@@ -95,6 +95,13 @@ int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream) {
     return conv_wgrad_launch(a, d->dtype, (hipStream_t)stream);
 }
 
+int pmoe_conv2d_wgrad_plan(const pmoe_wgrad_desc* d) {
+    WgradArgs a;
+    const int rc = to_wgrad_args(d, a);
+    if (rc) return rc;
+    return conv_wgrad_plan(a, d->dtype);
+}
+
 int64_t pmoe_conv2d_wgrad_ws_floats(const pmoe_wgrad_desc* d) {
     WgradArgs a;
     const int rc = to_wgrad_args(d, a);

@@ -470,7 +470,7 @@ template <typename T, int TAPS, int MAXV> static int launch_wg(const WgradArgs& 
 }
 
 // plan == true: nothing is launched, *ws_floats receives the size of the K-split workspace the launch needs (0: none)
-template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool plan, long long* ws_floats) {
+template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool plan, long long* ws_floats, int* code = nullptr) {
     constexpr int CKW = 128 / (int)sizeof(T);
     constexpr int VEh = 16 / (int)sizeof(T);
     if (a.Cin % VEh || a.Cout % VEh || a.CinP < a.Cin || a.CoutP < a.Cout) return PMOE_ERR_ARG;
@@ -517,8 +517,8 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
         { const char* ev = getenv("PMOE_WGRAD_SLICE_FASTEST"); a.slice_fastest = ev ? atoi(ev) : 0; }
         const int nsplit = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
         const long long ws = (a.per_image || nsplit == 1) ? 0 : (long long)nsplit * E * a.ks * a.ks * a.CoutP * a.CinP;
-        if (plan) { *ws_floats = ws; return 0; }
-        if (ws > 0 && (!a.part || a.part_floats < ws)) return PMOE_ERR_ARG;
+        if (plan && !code) { *ws_floats = ws; return 0; }
+        if (!plan && ws > 0 && (!a.part || a.part_floats < ws)) return PMOE_ERR_ARG;
         if constexpr (sizeof(T) == 2) {
             // dense 3x3 stride 1 in bf16: the LDS-DMA variant (PMOE_WGRAD_DMA=0: A/B switch back to register staging)
             const char* evd = getenv("PMOE_WGRAD_DMA");      // (read per launch: tools/ab_conv.py flips it inside one process)
@@ -531,6 +531,7 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                 exact = ((pp * mpw) >> 16) == pp / PW && ((((pp / PW) * mph) >> 16) == (pp / PW) / PH);
             if (dma_on && a.ks == 3 && a.stride == 1 && BMP == 256 && lTW >= 2 && npiece <= 48 && exact &&
                 xbytes < 0x7ff00000ll && dybytes < 0x7ff00000ll && 2 * ((size_t)BMP * 128 + (size_t)npiece * 1024) <= 160 * 1024) {
+                if (plan) { *code = 7009; return 0; }       // conv_wgrad_dma_kernel
                 size_t sm = 2 * ((size_t)BMP * 128 + (size_t)npiece * 1024);
                 if (sm < 49152) sm = 49152;               // room for the flush's fold
                 const int nsp = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
@@ -553,6 +554,7 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                 return 0;
             }
         }
+        if (plan) { *code = 6000 + a.ks * a.ks * 100 + (need <= M1 ? M1 : M2); return 0; }      // conv_wgrad_kernel<T, taps, MAXV>
         if (need <= M1) return a.ks == 3 ? launch_wg<T, 9, M1>(a, E, smem, st) : launch_wg<T, 1, M1>(a, E, smem, st);
         return a.ks == 3 ? launch_wg<T, 9, M2>(a, E, smem, st) : launch_wg<T, 1, M2>(a, E, smem, st);
     }
@@ -564,6 +566,15 @@ int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
     if (dtype == PMOE_DT_BF16) return wgrad_dtype<bf16>(a, st, false, &ws);
     if (dtype == PMOE_DT_F32) return wgrad_dtype<float>(a, st, false, &ws);
     return PMOE_ERR_ARG;
+}
+
+// which kernel a descriptor runs on: 7009 = conv_wgrad_dma_kernel; 6000 + taps * 100 + MAXV = conv_wgrad_kernel<T, taps, MAXV>
+int conv_wgrad_plan(const WgradArgs& a, int dtype) {
+    long long ws = 0;
+    int code = 0;
+    const int rc = dtype == PMOE_DT_BF16 ? wgrad_dtype<bf16>(a, nullptr, true, &ws, &code)
+                 : dtype == PMOE_DT_F32 ? wgrad_dtype<float>(a, nullptr, true, &ws, &code) : PMOE_ERR_ARG;
+    return rc ? rc : code;
 }
 
 long long conv_wgrad_ws_floats(const WgradArgs& a, int dtype) {

@@ -64,3 +64,4 @@ int conv_igemm_mblocks(const ConvArgs& a, int dtype);
 int conv_igemm_plan(const ConvArgs& a, int dtype);
 int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);
 long long conv_wgrad_ws_floats(const WgradArgs& a, int dtype);
+int conv_wgrad_plan(const WgradArgs& a, int dtype);

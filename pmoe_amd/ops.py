@@ -117,6 +117,8 @@ def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, 
     if need > 0:
         part = _wgrad_part_ws(x.device, need)
         d.part_ws, d.part_ws_floats = ptr(part, "part_ws"), part.numel()
+    if _prof is not None:            # profiling: remember which kernel instantiation serves this launch
+        _launch_info["kernel"] = load().pmoe_conv2d_wgrad_plan(C.byref(d))
     check(load().pmoe_conv2d_wgrad(C.byref(d), stream_ptr()), "pmoe_conv2d_wgrad")
     return dw_ws
 
