@@ -284,6 +284,230 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round-2 variant for the 64 -> 64 layers (stem conv2, layer1; forward and data gradient): the filter bank stays RESIDENT
+// in LDS as above, but ALL 8 waves compute every tile (two waves per SIMD cover each other's LDS latency -- the ping-pong
+// kernel above has ONE MFMA-role wave per SIMD and hipcc sinks every fragment read to its use: ~9 k cycles for 4.6 k
+// cycles of MFMA per tile), and the halo patches arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`, zero fill through the
+// buffer range check, XOR swizzle on the source address keyed by the patch column) into two buffers: the patch of tile
+// i+1 is requested at the start of tile i and has the whole tile to land.  No barrier inside a tile's 9 taps; the
+// epilogue stages the tile as bf16 rows in the patch buffer it has just finished with (nothing is added before the
+// rounding that the ping-pong kernel did not also add after it: residual add on the rounded value, bias in the
+// accumulator), waits for the prefetched patch BEFORE issuing its stores (one in-order vmcnt counter), and carries the
+// BatchNorm partial sums in registers across tiles.
+// Wave tile = 64 pixels x 32 output channels (4 x 2 waves): 3 ds_read_b128 per 2 MFMAs, ~75 % LDS-array load.
+template <bool BIAS>
+__global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a, const int tiles_per_expert,
+                                                                const int wgs_per_expert, const int pbuf_bytes,
+                                                                const int magic_pw, const int magic_ph) {
+    constexpr int RB = 128, LOG_RBK = 7, VE = 8;
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int e = blockIdx.y, wg = blockIdx.x;
+    const int t0 = (int)((long long)wg * tiles_per_expert / wgs_per_expert);
+    const int t1 = (int)((long long)(wg + 1) * tiles_per_expert / wgs_per_expert);
+    const int ntile = t1 - t0;
+
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int PW = TW + 2, PH = TH + 2;
+    const int NPIX = a.TN * PH * PW;
+    const int NPIECE = (NPIX + 7) >> 3;
+    const int my_pieces = (NPIECE - wave + 7) >> 3;
+
+    char* Wl = smem;                                     // [9][64][128 B], chunks swizzled by row
+    char* pbuf = smem + 9 * 64 * RB;                     // 2 patch buffers
+    float* lbias = reinterpret_cast<float*>(pbuf + 2 * pbuf_bytes);
+    if (BIAS && tid < 64) lbias[tid] = a.bias[(size_t)e * a.CoutP + tid];
+
+    const bf16* inb = (const bf16*)a.in + (size_t)e * a.ipe * a.H * a.W * a.in_ld + a.in_coff;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)inb, (short)0, (int)(((long long)a.ipe * a.H * a.W * a.in_ld - a.in_coff) * 2), 0x00020000);
+    const bf16* wsrc = (const bf16*)a.w + (size_t)e * a.CoutP * 9 * a.Cin;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, (short)0, 64 * 9 * 64 * 2, 0x00020000);
+    constexpr int OOB = 0x7ff80000;
+
+    // resident filter bank: 72 pieces of 8 rows (piece = tap * 8 + row block), 9 per wave
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int piece = wave + 8 * i;
+        const int tap = piece >> 3, row = ((piece & 7) << 3) + (lane >> 3);
+        const int voff = ((row * 9 + tap) * 64 * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(Wl + (piece << 10)), 16, voff, 0, 0, 0);
+    }
+
+    auto tile_geo = [&](int t, int& n0, int& oy0, int& ox0) {
+        int qq = t0 + t;
+        const int px = qq % a.tiles_x; qq /= a.tiles_x;
+        const int py = qq % a.tiles_y; qq /= a.tiles_y;
+        n0 = qq * a.TN;                                  // image index inside the expert
+        oy0 = py * TH; ox0 = px * TW;
+    };
+    auto issue_patch = [&](int t, int buf) {
+        int n0, oy0, ox0;
+        tile_geo(t, n0, oy0, ox0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i < my_pieces) {
+                const int pp = ((wave + 8 * i) << 3) + (lane >> 3);
+                const int rowq = (pp * magic_pw) >> 16, px = pp - rowq * PW;
+                const int pn = (rowq * magic_ph) >> 16, prow = rowq - pn * PH;
+                const int n = n0 + pn, Y = oy0 - 1 + prow, X = ox0 - 1 + px;
+                const bool ok = pp < NPIX && n < a.ipe && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+                const int voff = ok ? ((((n * a.H + Y) * a.W + X) * a.in_ld) << 1) + (((lane & 7) ^ ((px >> 1) & 7)) << 4) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(pbuf + buf * pbuf_bytes + ((wave + 8 * i) << 10)), 16,
+                                                         voff, 0, 0, 0);
+            }
+        }
+    };
+
+    // fragment addressing: B = pixels wm*64 + mt*32 + l31 (columns of D), A = couts wn*32 + l31 (rows of D)
+    int pbase[2], pcol[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int p = wm * 64 + mt * 32 + l31;
+        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+        pbase[mt] = ((pn * PH + my) * PW + mx) << LOG_RBK;
+        pcol[mt] = mx;
+    }
+    int aoff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int row = wn * 32 + l31;
+        aoff[ks] = row * RB + (((ks * 2 + hh) ^ ((row >> 1) & 7)) << 4);
+    }
+
+    float s1[VE], s2[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) s1[i] = s2[i] = 0.f;
+    const int cc = tid & 7, pr = tid >> 3;               // read-out: 8 channel chunks x 64 pixel rows of threads
+    const bool cvalid = cc * VE < a.Cout;
+    bf16* out = (bf16*)a.out;
+    const bf16* res = (const bf16*)a.res;
+
+    if (ntile > 0) issue_patch(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // filter bank + first patch
+    __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntile) issue_patch(t + 1, buf ^ 1);  // its buffer was released by the barrier that ended tile t-1
+        const char* patch = pbuf + buf * pbuf_bytes;
+        f32x16 acc[2];
+        if (BIAS) {
+            // accumulators start from the channel bias (acc[mt][4g+i] is cout wn*32 + 8g + 4hh + i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + wn * 32 + g * 8 + hh * 4);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[mt][4 * g + k] = b[k];
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[mt][k] = 0.f;
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char* wt = Wl + tap * 64 * RB;
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RBK;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const v4i af = *reinterpret_cast<const v4i*>(wt + aoff[ks]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const v4i bfr = *reinterpret_cast<const v4i*>(patch + pbase[mt] + tapoff +
+                                                                  (((ks * 2 + hh) ^ (((pcol[mt] + (tap % 3)) >> 1) & 7)) << 4));
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr),
+                                                                      acc[mt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: bf16 rows [256 px][128 B] (16-byte chunks XOR-swizzled by pixel) in this tile's patch buffer
+        char* stage = pbuf + buf * pbuf_bytes;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // every wave is done reading the patch
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int p = wm * 64 + mt * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (bf16)acc[mt][4 * g + i];
+                *reinterpret_cast<bf16x4*>(stage + p * 128 + (((wn * 4 + g) ^ (p & 7)) << 4) + 8 * hh) = v;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // + the next tile's patch, AHEAD of this tile's stores
+        __builtin_amdgcn_s_barrier();
+        int n0, oy0, ox0;
+        tile_geo(t, n0, oy0, ox0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = pr + 64 * u;
+            const v4i raw = *reinterpret_cast<const v4i*>(stage + p * 128 + ((cc ^ (p & 7)) << 4));
+            const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+            const int nn = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
+            if (cvalid && nn < a.ipe && oy < a.Ho && ox < a.Wo) {
+                const size_t opix = (((size_t)e * a.ipe + nn) * a.Ho + oy) * a.Wo + ox;
+                v4i pk = raw;
+                if (a.res_mode == PMOE_RES_ADD) {
+                    float v[VE], rv[VE];
+                    unpack16<bf16>(raw, v);
+                    unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cc * VE), rv);
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) v[i] += rv[i];
+                    pk = pack16<bf16>(v);
+                }
+                if (a.stats) {
+                    float rr[VE];
+                    unpack16<bf16>(pk, rr);
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
+                }
+                stg16(out + opix * a.out_ld + a.out_coff + cc * VE, pk);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // staging read out: the buffer may receive the patch of tile t+2
+    }
+
+    if (a.stats) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [8 waves][2][64]  (the filter bank is dead by now)
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                s1[i] += __shfl_xor(s1[i], off);
+                s2[i] += __shfl_xor(s2[i], off);
+            }
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                red[(wave * 2 + 0) * 64 + cc * VE + i] = s1[i];
+                red[(wave * 2 + 1) * 64 + cc * VE + i] = s2[i];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, c = tid & 63;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += red[(w * 2 + which) * 64 + c];
+            a.stats[(((size_t)e * wgs_per_expert + wg) * 2 + which) * a.CoutP + c] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan) {
     static int res_on = -1;       // PMOE_CONV_RES=0: route the <=64-channel layers to the generic kernel (A/B runs)
     if (res_on < 0) { const char* ev = getenv("PMOE_CONV_RES"); res_on = ev ? atoi(ev) : 1; }
@@ -327,6 +551,30 @@ int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
     const int E = a.N / a.ipe;
     const int region = (int)((p.smem - (size_t)9 * 64 * (1 << p.log_rb)) / 2);
     dim3 grid(p.wgs_per_expert, E), block(512);
+    if (p.log_rb == 7 && !a.in_shared) {
+        // all-waves-compute / LDS-DMA variant (PMOE_RES_DMA=0: A/B switch back to the ping-pong kernel; read per launch)
+        const char* ev = getenv("PMOE_RES_DMA");
+        const int PW = (1 << p.lTW) + 2, PH = (1 << p.lTH) + 2;
+        const int npiece = (p.TN * PH * PW + 7) / 8;
+        int pb = npiece * 1024;
+        if (pb < 256 * 128) pb = 256 * 128;
+        const int mpw = 65536 / PW + 1, mph = 65536 / PH + 1;
+        bool exact = true;
+        for (int pp = 0; pp < npiece * 8 && exact; ++pp)
+            exact = ((pp * mpw) >> 16) == pp / PW && ((((pp / PW) * mph) >> 16) == (pp / PW) / PH);
+        const size_t sm = (size_t)9 * 64 * 128 + 2 * (size_t)pb + 256;
+        if ((!ev || atoi(ev)) && npiece <= 48 && exact && sm <= 163840 && p.lTW >= 4 &&
+            (long long)a.ipe * a.H * a.W * a.in_ld * 2 < 0x7ff00000ll) {
+            if (a.bias) {
+                HIP_RET((ensure_dyn_lds<conv3x3_resdma_kernel<true>>(163840)));
+                hipLaunchKernelGGL(conv3x3_resdma_kernel<true>, grid, block, sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb, mpw, mph);
+            } else {
+                HIP_RET((ensure_dyn_lds<conv3x3_resdma_kernel<false>>(163840)));
+                hipLaunchKernelGGL(conv3x3_resdma_kernel<false>, grid, block, sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb, mpw, mph);
+            }
+            return (int)hipGetLastError();
+        }
+    }
     if (p.log_rb == 7 && a.bias) {
         HIP_RET((ensure_dyn_lds<conv3x3_res_kernel<7, true>>(163840)));
         hipLaunchKernelGGL((conv3x3_res_kernel<7, true>), grid, block, p.smem + 256, st, a, p.tiles_per_expert,
