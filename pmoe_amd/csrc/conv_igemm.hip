@@ -527,6 +527,7 @@ struct ResPlan {
     size_t smem;
 };
 bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan);
+bool conv_res_dma_ok(const ConvArgs& a, const ResPlan& p, int* pbuf, int* magic_pw, int* magic_ph, size_t* smem);
 int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st);
 
 // stride-2 3x3 data gradient (forward pad 1) by output parity class instead of a zero-dilated source: dx[2a+py][2b+px]
@@ -590,7 +591,8 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
     return PMOE_ERR_ARG;
 }
 
-// which kernel a descriptor runs on (no launch): 3000 = gemm_skinny_kernel; 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; 2000 + LOG_RB =
+// which kernel a descriptor runs on (no launch): 3000 = gemm_skinny_kernel; 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; 1107 =
+// conv3x3_resdma_kernel; 5007 = conv3x3_dma_kernel; 2000 + LOG_RB =
 // conv_igemm_lite_kernel<T, LOG_RB>; LOG_RB*100 + WM*10 + WN = conv_igemm_kernel<T, LOG_RB, WM, WN>; + 4000 = the four
 // parity-class launches of a stride-2 data gradient
 int conv_igemm_plan(const ConvArgs& a, int dtype) {
@@ -609,7 +611,11 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         extra = 4000;
     } else {
         ResPlan plan;
-        if (conv_res_plan(a, dtype, &plan)) return 1000 + plan.log_rb;
+        if (conv_res_plan(a, dtype, &plan)) {
+            int pb, mpw, mph;
+            size_t sm;
+            return 1000 + plan.log_rb + (conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) ? 100 : 0);
+        }
         ConvArgs d = a;
         int mbd, pb;
         size_t sm;

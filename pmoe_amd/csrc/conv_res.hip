@@ -413,21 +413,26 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[mt][k] = 0.f;
         }
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const char* wt = Wl + tap * 64 * RB;
+        auto read_step = [&](int st, v4i& af, v4i* bfr) {     // fragments of step st = tap * 4 + ks
+            const int tap = st >> 2, ks = st & 3;
             const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RBK;
+            af = *reinterpret_cast<const v4i*>(Wl + tap * 64 * RB + aoff[ks]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const v4i af = *reinterpret_cast<const v4i*>(wt + aoff[ks]);
+            for (int mt = 0; mt < 2; ++mt)
+                bfr[mt] = *reinterpret_cast<const v4i*>(patch + pbase[mt] + tapoff +
+                                                        (((ks * 2 + hh) ^ (((pcol[mt] + (tap % 3)) >> 1) & 7)) << 4));
+        };
+        // (measured and dropped, interleaved A/B: a one-step read-ahead pinned with sched_barrier -- within 1 %; keeping 12 / 20
+        //  / all 36 weight fragments of the wave in registers instead of re-reading them from LDS -- 0..-3 % / x0.5 (spills): the
+        //  loop is not LDS-bandwidth bound)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const v4i bfr = *reinterpret_cast<const v4i*>(patch + pbase[mt] + tapoff +
-                                                                  (((ks * 2 + hh) ^ (((pcol[mt] + (tap % 3)) >> 1) & 7)) << 4));
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr),
-                                                                      acc[mt], 0, 0, 0);
-                }
-            }
+        for (int st = 0; st < 36; ++st) {
+            v4i af, bfr[2];
+            read_step(st, af, bfr);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr[mt]),
+                                                                  acc[mt], 0, 0, 0);
         }
         // ---- epilogue: bf16 rows [256 px][128 B] (16-byte chunks XOR-swizzled by pixel) in this tile's patch buffer
         char* stage = pbuf + buf * pbuf_bytes;
@@ -546,34 +551,41 @@ bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan) {
     return true;
 }
 
+// does the all-waves-compute / LDS-DMA variant (conv3x3_resdma_kernel) take this plan?  PMOE_RES_DMA=0: A/B switch back to
+// the ping-pong kernel (read per launch)
+bool conv_res_dma_ok(const ConvArgs& a, const ResPlan& p, int* pbuf, int* magic_pw, int* magic_ph, size_t* smem) {
+    if (p.log_rb != 7 || a.in_shared) return false;
+    const char* ev = getenv("PMOE_RES_DMA");
+    if (ev && !atoi(ev)) return false;
+    const int PW = (1 << p.lTW) + 2, PH = (1 << p.lTH) + 2;
+    const int npiece = (p.TN * PH * PW + 7) / 8;
+    int pb = npiece * 1024;
+    if (pb < 256 * 128) pb = 256 * 128;
+    const int mpw = 65536 / PW + 1, mph = 65536 / PH + 1;
+    for (int pp = 0; pp < npiece * 8; ++pp)
+        if (((pp * mpw) >> 16) != pp / PW || ((((pp / PW) * mph) >> 16) != (pp / PW) / PH)) return false;
+    const size_t sm = (size_t)9 * 64 * 128 + 2 * (size_t)pb + 256;
+    if (npiece > 48 || sm > 163840 || p.lTW < 4 || (long long)a.ipe * a.H * a.W * a.in_ld * 2 >= 0x7ff00000ll) return false;
+    *pbuf = pb; *magic_pw = mpw; *magic_ph = mph; *smem = sm;
+    return true;
+}
+
 int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
     a.lTW = p.lTW; a.lTH = p.lTH; a.TN = p.TN; a.n_groups = p.n_groups; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
     const int E = a.N / a.ipe;
     const int region = (int)((p.smem - (size_t)9 * 64 * (1 << p.log_rb)) / 2);
     dim3 grid(p.wgs_per_expert, E), block(512);
-    if (p.log_rb == 7 && !a.in_shared) {
-        // all-waves-compute / LDS-DMA variant (PMOE_RES_DMA=0: A/B switch back to the ping-pong kernel; read per launch)
-        const char* ev = getenv("PMOE_RES_DMA");
-        const int PW = (1 << p.lTW) + 2, PH = (1 << p.lTH) + 2;
-        const int npiece = (p.TN * PH * PW + 7) / 8;
-        int pb = npiece * 1024;
-        if (pb < 256 * 128) pb = 256 * 128;
-        const int mpw = 65536 / PW + 1, mph = 65536 / PH + 1;
-        bool exact = true;
-        for (int pp = 0; pp < npiece * 8 && exact; ++pp)
-            exact = ((pp * mpw) >> 16) == pp / PW && ((((pp / PW) * mph) >> 16) == (pp / PW) / PH);
-        const size_t sm = (size_t)9 * 64 * 128 + 2 * (size_t)pb + 256;
-        if ((!ev || atoi(ev)) && npiece <= 48 && exact && sm <= 163840 && p.lTW >= 4 &&
-            (long long)a.ipe * a.H * a.W * a.in_ld * 2 < 0x7ff00000ll) {
-            if (a.bias) {
-                HIP_RET((ensure_dyn_lds<conv3x3_resdma_kernel<true>>(163840)));
-                hipLaunchKernelGGL(conv3x3_resdma_kernel<true>, grid, block, sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb, mpw, mph);
-            } else {
-                HIP_RET((ensure_dyn_lds<conv3x3_resdma_kernel<false>>(163840)));
-                hipLaunchKernelGGL(conv3x3_resdma_kernel<false>, grid, block, sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb, mpw, mph);
-            }
-            return (int)hipGetLastError();
+    int pb = 0, mpw = 0, mph = 0;
+    size_t sm = 0;
+    if (conv_res_dma_ok(a, p, &pb, &mpw, &mph, &sm)) {
+        if (a.bias) {
+            HIP_RET((ensure_dyn_lds<conv3x3_resdma_kernel<true>>(163840)));
+            hipLaunchKernelGGL(conv3x3_resdma_kernel<true>, grid, block, sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb, mpw, mph);
+        } else {
+            HIP_RET((ensure_dyn_lds<conv3x3_resdma_kernel<false>>(163840)));
+            hipLaunchKernelGGL(conv3x3_resdma_kernel<false>, grid, block, sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb, mpw, mph);
         }
+        return (int)hipGetLastError();
     }
     if (p.log_rb == 7 && a.bias) {
         HIP_RET((ensure_dyn_lds<conv3x3_res_kernel<7, true>>(163840)));

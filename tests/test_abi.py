@@ -78,7 +78,7 @@ def test_conv_plan_reports_the_kernel_instantiation():
         d.in_ld, d.out_ld, d.ipe, d.ks, d.stride, d.pad, d.dilate = cin, cout, B, ks, stride, pad, int(dilate)
         d.dtype = 0 if dtype == torch.bfloat16 else 1
         return load().pmoe_conv2d_plan(C.byref(d))
-    assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1007                 # conv3x3_res_kernel<7>
+    assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1107                 # conv3x3_resdma_kernel (filter bank resident, LDS-DMA patches)
     assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1005                 # 12(16)-channel stem on the resident kernel
     assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 5007                # conv3x3_dma_kernel (LDS-DMA staged, conv_dma.hip)
     assert plan(128, 256, 64, 1, 2, torch.bfloat16) == 2007                # 1x1 stride 2: conv_igemm_lite_kernel<bf16,7>, 2 workgroups / CU

@@ -171,17 +171,24 @@ BASELINE_CONV_CASES = [
     ((2, 32, 512, 512, 16, 16, 3, 1), (5007, 5007, 256)),      # layer4: 8 chunks, one 16 x 16 image per tile (two patch rows per
                                                                # 32-lane fragment: the column-keyed swizzle), 2 experts
     ((1, 5, 128, 256, 40, 24, 3, 1), (5007, 5007, 200)),       # ragged: 24-wide rows in 32-wide tiles, 40 rows in strips of 8, 5 images
-    ((1, 1, 64, 64, 256, 256, 3, 1), (1007, 1007, 256)),       # stem conv2: conv3x3_res_kernel<7>, 256 tiles of one image
-    ((2, 2, 64, 64, 128, 128, 3, 1), (1007, 1007, 256)),       # layer1: resident kernel, persistent workgroups per expert
+    ((1, 1, 64, 64, 256, 256, 3, 1), (1107, 1107, 256)),       # stem conv2: conv3x3_resdma_kernel, 256 tiles of one image
+    ((2, 2, 64, 64, 128, 128, 3, 1), (1107, 1107, 256)),       # layer1: resident kernel, persistent workgroups per expert
     ((1, 4, 64, 128, 128, 128, 3, 2), (642, 4741, 256)),       # layer2.0.conv1: stride-2 forward, parity-class data gradient
     ((1, 4, 64, 128, 128, 128, 1, 2), (2007, 741, 128)),       # layer2.0.downsample (1x1: LITE tile over the used pixels)
-    ((1, 1, 12, 64, 256, 256, 3, 1), (1005, 1007, 256)),       # stem conv1 (12 -> 16 input channels): resident kernel, 32-byte rows
+    ((1, 1, 12, 64, 256, 256, 3, 1), (1005, 1107, 256)),       # stem conv1 (12 -> 16 input channels): resident kernel, 32-byte rows
 ]
 
 
 @pytest.mark.parametrize("case,plan", BASELINE_CONV_CASES)
 def test_conv_baseline_layer_shapes_bf16(case, plan):
     _conv_case(case, torch.bfloat16, plan)
+
+
+def test_conv_resident_pingpong_fallback(monkeypatch):
+    """PMOE_RES_DMA=0 (read per launch) routes the 64-channel layers back to conv3x3_res_kernel<7>, the kernel that also
+    serves shapes the LDS-DMA variant declines: same parity bar, plan code 1007."""
+    monkeypatch.setenv("PMOE_RES_DMA", "0")
+    _conv_case((2, 2, 64, 64, 128, 128, 3, 1), torch.bfloat16, (1007, 1007, 256))
 
 
 @pytest.mark.parametrize("case", [c for c, _ in BASELINE_CONV_CASES[:4]])

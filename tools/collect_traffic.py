@@ -39,7 +39,7 @@ def main():
         n = max(fn, wn, 1)
         f2, w = fb * 1024 * 2 / n, wb * 1024 / n           # KiB units; gfx950: FETCH_SIZE counts half of the bytes
         per[name] = {"launches": n, "fetch_bytes_per_launch_x2": f2, "write_bytes_per_launch": w}
-        if "conv_igemm" in name or "conv3x3_res_kernel" in name or "conv3x3_dma_kernel" in name:
+        if "conv_igemm" in name or "conv3x3_" in name:
             conv_b += (f2 + w) * n
             conv_n += n
     total = sum((v["fetch_bytes_per_launch_x2"] + v["write_bytes_per_launch"]) * v["launches"] for v in per.values())
