@@ -192,10 +192,12 @@ int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, c
                   int32_t dtype, void* stream);
 /* backward reduce: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat -> part [E][nparts][2][C].
  * y may be NULL when relu is set and the forward had no residual: the mask is then recomputed as
- * x*scale+shift > 0 and the saved output is not read at all (one tensor pass less). */
+ * x*scale+shift > 0 and the saved output is not read at all (one tensor pass less).
+ * gmask_out (may be NULL): g itself is stored there -- pmoe_bn_bwd_apply then takes it as dy with relu = 0 and y = NULL
+ * (it no longer reads the saved output) and the residual branch takes it as its gradient. */
 int pmoe_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                        const float* scale, const float* shift, int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, float* part, int32_t nparts,
-                       int32_t dtype, void* stream);
+                       void* gmask_out, int32_t dtype, void* stream);
 /* dgamma/dbeta [E][C] (written to the grad arena) + the two per-channel means used by bwd_apply */
 int pmoe_bn_bwd_finalize(const float* part, int32_t nparts, int64_t count, float* dgamma, float* dbeta, float* c1,
                          float* c2, int32_t E, int32_t C, void* stream);

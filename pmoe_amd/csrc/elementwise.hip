@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
                                                       const float* __restrict__ invstd, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, long long rpe, int C, int ld,
                                                       int coff, int relu, float* __restrict__ part, int nparts,
-                                                      float* __restrict__ shiftc) {
+                                                      float* __restrict__ shiftc, T* __restrict__ gmask) {
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE, RL = 256 / CV;
     const int tid = threadIdx.x, cv = tid % CV, rl = tid / CV;
@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
 #pragma unroll
                 for (int i = 0; i < VE; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
             }
+            if (gmask) stg16(gmask + off, pack16<T>(gv));      // the masked gradient: what the apply pass and the residual path consume
 #pragma unroll
             for (int i = 0; i < VE; ++i) { s1[i] += gv[i]; s2[i] += gv[i] * (xv[i] - mu[i]) * is[i]; }
         }
@@ -95,16 +96,16 @@ __global__ void __launch_bounds__(256) colstats_kernel(const T* __restrict__ x, 
 template <typename T>
 static int colstats_launch(const void* x, const void* dy, const void* y, const float* mean, const float* invstd,
                            const float* scale, const float* shift, long long rpe, int E, int C, int ld, int coff, int relu, float* part, int nparts, int mode,
-                           float* shiftc, hipStream_t st) {
+                           float* shiftc, hipStream_t st, void* gmask = nullptr) {
     constexpr int VE = 16 / (int)sizeof(T);
     if (C % VE || !pow2(C / VE) || C / VE > 256 || nparts < 1) return PMOE_ERR_ARG;
     dim3 grid(nparts, E), block(256);
     if (mode == 0)
         hipLaunchKernelGGL((colstats_kernel<T, 0>), grid, block, 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, rpe, C, ld, coff, 0, part, nparts, shiftc);
+                           nullptr, nullptr, rpe, C, ld, coff, 0, part, nparts, shiftc, nullptr);
     else
         hipLaunchKernelGGL((colstats_kernel<T, 1>), grid, block, 0, st, (const T*)x, (const T*)dy, (const T*)y, mean,
-                           invstd, scale, shift, rpe, C, ld, coff, relu, part, nparts, nullptr);
+                           invstd, scale, shift, rpe, C, ld, coff, relu, part, nparts, nullptr, (T*)gmask);
     return (int)hipGetLastError();
 }
 
@@ -652,10 +653,10 @@ int pmoe_colstats(const void* x, int64_t rows_per_expert, int32_t E, int32_t C, 
 
 int pmoe_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                        const float* scale, const float* shift, int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, float* part, int32_t nparts,
-                       int32_t dtype, void* stream) {
+                       void* gmask_out, int32_t dtype, void* stream) {
     if (relu && !y && (!scale || !shift)) return PMOE_ERR_ARG;
     DISPATCH_DT(dtype, return colstats_launch<T>(x, dy, y, mean, invstd, scale, shift, rows_per_expert, E, C, C, 0, relu, part,
-                                                 nparts, 1, nullptr, (hipStream_t)stream));
+                                                 nparts, 1, nullptr, (hipStream_t)stream, gmask_out));
 }
 
 int pmoe_reduce_partials(const float* part_in, float* part_out, int32_t E, int32_t nin, int32_t nout, int32_t width,

@@ -344,6 +344,246 @@ __global__ void __launch_bounds__(256) stem_tail_pool_kernel(const T* __restrict
     }
 }
 
+// ---- row-walking variants of the pool pass and of backward phase 3 (the default; PMOE_STEM_WALK=0 = the gather kernels above) ----
+// A group of CV lanes (one 16-byte channel vector each) owns 2*KO adjacent input columns = KO pooled columns and walks DOWN a
+// strip of rows: every z2 element is loaded once (+ one halo column, + one halo row per strip) and its two BatchNorm+ReLU
+// evaluated once, instead of 2.25 gathers and 2.25 evaluations per element; the pooled gradient / winning taps of the <= 2
+// pooled rows a pixel row touches stay in registers.  Same arithmetic, same tie rule (first maximum in (row, column) scan
+// order of values rounded to T), same summation order as the kernels above: results are bit-identical.
+__device__ __forceinline__ void put_byte(unsigned (&w)[2], int i, unsigned code) {
+    const int sh = 8 * (i & 3);
+    w[i >> 2] = (w[i >> 2] & ~(0xffu << sh)) | (code << sh);
+}
+__device__ __forceinline__ unsigned get_byte(const unsigned (&w)[2], int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; }
+
+// Pool pass, bf16: a3 >= 0, so the bf16 bit pattern orders like the value and "first maximum in scan order" becomes ONE
+// unsigned max over keys  (bf16(a3) << 16) | (8 - tap) << 1 | [a2 > 0]  -- no per-element compare/select chains.
+// Horizontal: max over the 3 columns with (2 - column) << 1 in the low bits; vertical: + 6 * (2 - row).
+template <int KO>
+__global__ void __launch_bounds__(256) stem_tail_pool_walk_kernel(const bf16* __restrict__ z2, bf16* __restrict__ y,
+                                                                 uint8_t* __restrict__ am, const float* __restrict__ sc2a,
+                                                                 const float* __restrict__ sh2a, const float* __restrict__ sc1a,
+                                                                 const float* __restrict__ sh1a, const float* __restrict__ mu2a,
+                                                                 const float* __restrict__ mu1a, int N, int ipe, int H, int W,
+                                                                 int C, int Ho, int Wo, int G, int NS, int SR, int lcv) {
+    constexpr int VE = 8, NP = 2 * KO + 1;
+    const int CV = 1 << lcv, cv = threadIdx.x & (CV - 1);
+    const long long gi = ((long long)blockIdx.x * 256 + threadIdx.x) >> lcv;
+    if (gi >= (long long)N * NS * G) return;
+    const int g = (int)(gi % G), strip = (int)((gi / G) % NS), n = (int)(gi / ((long long)G * NS)), e = n / ipe;
+    float sc2[VE], sh2[VE], sc1[VE], sh1[VE], mu2[VE], mu1[VE];
+#pragma unroll
+    for (int q = 0; q < VE; ++q) {
+        const int c = e * C + cv * VE + q;
+        sc2[q] = sc2a[c]; sh2[q] = sh2a[c]; sc1[q] = sc1a[c]; sh1[q] = sh1a[c]; mu2[q] = mu2a[c]; mu1[q] = mu1a[c];
+    }
+    const int x0 = 2 * KO * g - 1;                                  // input column of pixel slot 0 (slot p <-> x0 + p)
+    const bf16* zim = z2 + (size_t)n * H * W * C + cv * VE;
+    auto load_row = [&](int yy, v4i (&raw)[NP]) {
+        const bf16* zr = zim + (size_t)yy * W * C;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int xx = x0 + p;
+            raw[p] = v4i{0, 0, 0, 0};
+            if ((unsigned)xx < (unsigned)W) raw[p] = ldg16(zr + (size_t)xx * C);
+        }
+    };
+    // one row: keys of the KO windows' best column, low bits (2 - column) << 1 | [a2 > 0]
+    auto hrow = [&](const v4i (&raw)[NP], unsigned (&hk)[KO][VE]) {
+#pragma unroll
+        for (int k = 0; k < KO; ++k)
+#pragma unroll
+            for (int q = 0; q < VE; ++q) hk[k][q] = 0u;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int xx = x0 + p;
+            if ((unsigned)xx >= (unsigned)W) continue;           // padding column: no candidate (a valid key is never 0)
+            float v[VE];
+            unpack16<bf16>(raw[p], v);
+            unsigned base[VE];
+#pragma unroll
+            for (int q = 0; q < VE; ++q) {
+                const float a2 = fmaxf((v[q] - mu2[q]) * sc2[q] + sh2[q], 0.f);
+                const bf16 a3 = from_f32<bf16>(fmaxf((a2 - mu1[q]) * sc1[q] + sh1[q], 0.f));
+                base[q] = ((unsigned)__builtin_bit_cast(unsigned short, a3) << 16) | (a2 > 0.f ? 1u : 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < KO; ++k) {
+                const int q3 = p - 2 * k;
+                if (q3 < 0 || q3 > 2) continue;
+#pragma unroll
+                for (int q = 0; q < VE; ++q) hk[k][q] = max(hk[k][q], base[q] | (unsigned)((2 - q3) << 1));
+            }
+        }
+    };
+    const int oy0 = strip * SR, oy1 = min(oy0 + SR, Ho);
+    unsigned hp[KO][VE];                                            // the row above the current window (row 2*oy - 1)
+#pragma unroll
+    for (int k = 0; k < KO; ++k)
+#pragma unroll
+        for (int q = 0; q < VE; ++q) hp[k][q] = 0u;
+    if (2 * oy0 - 1 >= 0) {
+        v4i raw[NP];
+        load_row(2 * oy0 - 1, raw);
+        hrow(raw, hp);
+    }
+    v4i rawA[NP], rawC[NP];
+    load_row(2 * oy0, rawA);
+    if (2 * oy0 + 1 < H) load_row(2 * oy0 + 1, rawC);
+    for (int oy = oy0; oy < oy1; ++oy) {
+        const bool haveC = 2 * oy + 1 < H;
+        unsigned hA[KO][VE], hC[KO][VE];
+        hrow(rawA, hA);
+        if (haveC) hrow(rawC, hC);
+        if (oy + 1 < oy1) {                                         // next window's rows: in flight during this one's arithmetic
+            load_row(2 * oy + 2, rawA);
+            if (2 * oy + 3 < H) load_row(2 * oy + 3, rawC);
+        }
+#pragma unroll
+        for (int k = 0; k < KO; ++k) {
+            unsigned yw[VE / 2], cw[2] = {0u, 0u};
+#pragma unroll
+            for (int q = 0; q < VE; ++q) {
+                unsigned best = max(hA[k][q] + 6u, hp[k][q] ? hp[k][q] + 12u : 0u);
+                if (haveC) best = max(best, hC[k][q]);
+                const unsigned low = best & 0xffffu;
+                const unsigned code = (8u - (low >> 1)) | ((low & 1u) << 7);
+                cw[q >> 2] |= code << (8 * (q & 3));
+                if (q & 1) yw[q >> 1] |= best & 0xffff0000u; else yw[q >> 1] = best >> 16;
+                hp[k][q] = haveC ? hC[k][q] : 0u;
+            }
+            const int ox = KO * g + k;
+            if (ox >= Wo) continue;
+            const size_t off = (((size_t)n * Ho + oy) * Wo + ox) * C + cv * VE;
+            stg16(y + off, v4i{(int)yw[0], (int)yw[1], (int)yw[2], (int)yw[3]});
+            *reinterpret_cast<uint2*>(am + off) = make_uint2(cw[0], cw[1]);
+        }
+    }
+}
+
+// backward phase 3 (dz2), row-walking: a lane group owns 2*KO input columns and walks SR input rows.  The pooled gradient and the
+// winning taps of the two pooled rows a pixel row can belong to stay in registers; per pixel row the taps are re-based once, four
+// bytes at a time ((taps | 0x80) - 3*window_row: bit 7 keeps the byte lanes from borrowing), so that a candidate test is one
+// byte compare.  The next row's z2 and the next pooled row are loaded while the current row is evaluated.
+template <typename T, int KO>
+__global__ void __launch_bounds__(256) stem_tail_dz_walk_kernel(const T* __restrict__ z2, const T* __restrict__ dpool,
+                                                               const uint8_t* __restrict__ amax, T* __restrict__ dz2,
+                                                               TailConsts k, int N, int ipe, int H, int W, int C, int Ho, int Wo,
+                                                               int G, int NS, int SR, int lcv) {
+    constexpr int VE = 16 / (int)sizeof(T), NX = 2 * KO, NPC = KO + 1, AW = VE / 4;
+    const int CV = 1 << lcv, cv = threadIdx.x & (CV - 1);
+    const long long gi = ((long long)blockIdx.x * 256 + threadIdx.x) >> lcv;
+    if (gi >= (long long)N * NS * G) return;
+    const int g = (int)(gi % G), strip = (int)((gi / G) % NS), n = (int)(gi / ((long long)G * NS)), e = n / ipe;
+    float sc2[VE], sh2[VE], mu2[VE], sc1[VE], sh1[VE], mu1[VE], is1[VE], P[VE], Q[VE], is2[VE], R[VE], S[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+        const int c = e * C + cv * VE + i;
+        sc2[i] = k.sc2[c]; sh2[i] = k.sh2[c]; mu2[i] = k.mu2[c];
+        sc1[i] = k.sc1[c]; sh1[i] = k.sh1[c]; mu1[i] = k.mu1[c]; is1[i] = k.is1[c];
+        P[i] = -sc1[i] * k.c21[c];
+        Q[i] = -sc1[i] * k.c11[c];
+        is2[i] = k.is2[c];
+        R[i] = -sc2[i] * k.c22[c];
+        S[i] = -sc2[i] * k.c12[c];
+    }
+    const int xb = NX * g, oxb = KO * g;                           // first input column / first pooled column of the group
+    struct PRow { v4i d[NPC]; unsigned a[NPC][AW]; };
+    auto load_prow = [&](int oy, PRow& r) {
+        const size_t base = (((size_t)n * Ho + oy) * Wo) * C + cv * VE;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) {
+            const int ox = oxb + j;
+#pragma unroll
+            for (int w = 0; w < AW; ++w) r.a[j][w] = 0xffffffffu;   // tap 0x7f: matches nothing
+            r.d[j] = v4i{0, 0, 0, 0};
+            if (ox < Wo) {
+                const size_t po = base + (size_t)ox * C;
+                r.d[j] = ldg16(dpool + po);
+                if (VE == 8) { const uint2 w = *reinterpret_cast<const uint2*>(amax + po); r.a[j][0] = w.x; r.a[j][AW - 1] = w.y; }
+                else r.a[j][0] = *reinterpret_cast<const unsigned*>(amax + po);
+            }
+        }
+    };
+    const int y0 = strip * SR, y1 = min(y0 + SR, H);               // SR even: y0 even
+    const T* zim = z2 + (size_t)n * H * W * C + cv * VE;
+    T* dim_ = dz2 + (size_t)n * H * W * C + cv * VE;
+    auto load_z = [&](int yy, v4i (&zr)[NX]) {
+#pragma unroll
+        for (int p = 0; p < NX; ++p) {
+            zr[p] = v4i{0, 0, 0, 0};
+            if (xb + p < W) zr[p] = ldg16(zim + ((size_t)yy * W + xb + p) * C);
+        }
+    };
+    PRow cur, nxt;                                                  // pooled rows yy>>1 and (yy>>1)+1
+    load_prow(y0 >> 1, cur);
+    nxt = cur;
+    v4i zr[NX], zn[NX];
+    load_z(y0, zr);
+    for (int yy = y0; yy < y1; ++yy) {
+        const int oyA = yy >> 1, oyB = (yy + 1) >> 1;
+        const bool twoRows = oyB != oyA && oyB < Ho;
+        if (!(yy & 1) && oyA + 1 < Ho) load_prow(oyA + 1, nxt);     // used from the next (odd) row on
+        if (yy + 1 < y1) load_z(yy + 1, zn);
+        const unsigned subA = 0x01010101u * (unsigned)((yy - (2 * oyA - 1)) * 3), subB = 0x01010101u * (unsigned)((yy - (2 * oyB - 1)) * 3);
+        unsigned relA[NPC][AW], relB[NPC][AW];
+#pragma unroll
+        for (int j = 0; j < NPC; ++j)
+#pragma unroll
+            for (int w = 0; w < AW; ++w) {
+                relA[j][w] = (cur.a[j][w] | 0x80808080u) - subA;
+                relB[j][w] = (nxt.a[j][w] | 0x80808080u) - subB;
+            }
+#pragma unroll
+        for (int p = 0; p < NX; ++p) {
+            const int xx = xb + p;
+            if (xx >= W) continue;
+            float zv[VE], a2[VE], g3[VE];
+            unpack16<T>(zr[p], zv);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) { a2[i] = fmaxf((zv[i] - mu2[i]) * sc2[i] + sh2[i], 0.f); g3[i] = 0.f; }
+            const int jA = p >> 1, jB = (p + 1) >> 1;               // pooled column slots (relative to oxb)
+            const unsigned tqA = 0x80u + (unsigned)(p - (2 * jA - 1)), tqB = 0x80u + (unsigned)(p - (2 * jB - 1));
+            const bool twoCols = jB != jA && oxb + jB < Wo;
+            auto gather = [&](const v4i& dr, const unsigned (&rel)[AW], unsigned want) {
+                float d[VE];
+                unpack16<T>(dr, d);
+#pragma unroll
+                for (int i = 0; i < VE; ++i)
+                    if (((rel[i >> 2] >> (8 * (i & 3))) & 0xffu) == want) g3[i] += d[i];
+            };
+            gather(cur.d[jA], relA[jA], tqA);
+            if (twoCols) gather(cur.d[jB], relA[jB], tqB);
+            if (twoRows) {
+                gather(nxt.d[jA], relB[jA], tqA);
+                if (twoCols) gather(nxt.d[jB], relB[jB], tqB);
+            }
+            float o[VE];
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                const float g3m = ((a2[i] - mu1[i]) * sc1[i] + sh1[i]) > 0.f ? g3[i] : 0.f;
+                const float da2 = g3m * sc1[i] + (((a2[i] - mu1[i]) * is1[i]) * P[i] + Q[i]);
+                const float g2 = a2[i] > 0.f ? da2 : 0.f;
+                o[i] = g2 * sc2[i] + (((zv[i] - mu2[i]) * is2[i]) * R[i] + S[i]);
+            }
+            stg16(dim_ + ((size_t)yy * W + xx) * C, pack16<T>(o));
+        }
+        if (twoRows) cur = nxt;
+#pragma unroll
+        for (int p = 0; p < NX; ++p) zr[p] = zn[p];
+    }
+}
+
+static inline int walk_enabled() {
+    const char* ev = getenv("PMOE_STEM_WALK");
+    return !ev || atoi(ev);
+}
+static inline int walk_ko() {                    // pooled columns per lane group (tools/ab_stem_tail.py: 2 vs 4)
+    const char* ev = getenv("PMOE_STEM_WALK_KO");
+    return ev && atoi(ev) == 4 ? 4 : 2;
+}
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
 static inline bool pow2i(int v) { return v > 0 && !(v & (v - 1)); }
 
 extern "C" {
@@ -372,6 +612,18 @@ int pmoe_stem_tail_pool(const void* z2, void* y, uint8_t* argmax, const float* s
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int ve = dtype == PMOE_DT_BF16 ? 8 : 4;
     if (C % ve || N % ipe || !pow2i(C / ve) || C / ve > 256) return PMOE_ERR_ARG;   // one channel vector per thread
+    if (walk_enabled() && dtype == PMOE_DT_BF16) {            // (f32 is the parity mode: gather kernel)
+        const int KO = walk_ko(), SR = 8;
+        const int G = (Wo + KO - 1) / KO, NS = (Ho + SR - 1) / SR, lcv = ilog2(C / ve);
+        const long long groups = (long long)N * NS * G, wgs = (groups * (C / ve) + 255) / 256;
+        if (wgs > 0x7fffffffll) return PMOE_ERR_ARG;
+#define POOL_WALK(K)                                                                                                        \
+        hipLaunchKernelGGL((stem_tail_pool_walk_kernel<K>), dim3((int)wgs), dim3(256), 0, (hipStream_t)stream, (const bf16*)z2, \
+                           (bf16*)y, argmax, sc2, sh2, sc1, sh1, mu2, mu1, N, ipe, H, W, C, Ho, Wo, G, NS, SR, lcv)
+        if (KO == 4) POOL_WALK(4); else POOL_WALK(2);
+#undef POOL_WALK
+        return (int)hipGetLastError();
+    }
     long long g = ((long long)N * Ho * Wo * (C / ve) + 255) / 256;
     if (g > 16384) g = 16384;
     if (dtype == PMOE_DT_BF16)
@@ -396,6 +648,20 @@ int pmoe_stem_tail_bwd(int32_t phase, const void* z2, const void* dpool, const u
     if (C % ve || !pow2i(C / ve) || C / ve > 256 || nparts < 1 || phase < 1 || phase > 3) return PMOE_ERR_ARG;
     dim3 grid(nparts, E), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (phase == 3 && walk_enabled()) {
+        const int KO = walk_ko(), SR = 16;
+        const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, N = E * ipe;
+        const int G = (W + 2 * KO - 1) / (2 * KO), NS = (H + SR - 1) / SR, lcv = ilog2(C / ve);
+        const long long groups = (long long)N * NS * G, wgs = (groups * (C / ve) + 255) / 256;
+        if (wgs > 0x7fffffffll || (dtype != PMOE_DT_BF16 && dtype != PMOE_DT_F32)) return PMOE_ERR_ARG;
+#define DZ_WALK(TT, K)                                                                                                       \
+        hipLaunchKernelGGL((stem_tail_dz_walk_kernel<TT, K>), dim3((int)wgs), block, 0, st, (const TT*)z2, (const TT*)dpool, argmax, \
+                           (TT*)dz2, k, N, ipe, H, W, C, Ho, Wo, G, NS, SR, lcv)
+        if (dtype == PMOE_DT_BF16) { if (KO == 4) DZ_WALK(bf16, 4); else DZ_WALK(bf16, 2); }
+        else { if (KO == 4) DZ_WALK(float, 4); else DZ_WALK(float, 2); }
+#undef DZ_WALK
+        return (int)hipGetLastError();
+    }
 #define TAIL_LAUNCH(TT, M)                                                                                           \
     hipLaunchKernelGGL((stem_tail_kernel<TT, M>), grid, block, 0, st, (const TT*)z2, (const TT*)dpool, argmax, (TT*)dz2, k, \
                        part, nparts, ipe, H, W, C, nullptr, nullptr)

@@ -159,6 +159,9 @@ class ExpertGroupEngine:
         self.fold_bn_eval = True      # inference: eval-mode BatchNorm folded into the conv weights / epilogue
         self.pooled_stem_bwd = True   # stem-tail BatchNorm reductions from the pooled tensors (train mode)
         self.fold_eca_gate = True     # ECA gate folded into per-image conv weights (no gated activation in memory)
+        # residual-block BatchNorm backward: the reduce pass stores the ReLU-masked gradient, the apply pass reads it (7 tensor
+        # passes per block output instead of 8).  PMOE_BN_MASK_IN_REDUCE=0: A/B switch
+        self.bn_mask_in_reduce = os.environ.get("PMOE_BN_MASK_IN_REDUCE", "1") != "0"
         # BASELINE config 5: e4m3 weights + e4m3 activations on the fp8 matrix cores for the layer1-4 forward convolutions
         # (policy: include/pmoe_hip.h, pmoe_pack_conv_weights_fp8).  fp8_min_cin: smallest input-channel count that takes it
         self.fp8 = False
@@ -567,8 +570,12 @@ class ExpertGroupEngine:
         nparts = self._nparts(rpe)
         part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
         nb = z.t.numel() * z.t.element_size()
-        ops.set_meta(name=layer.name, bytes=nb * (3 if ysrc is not None else 2))
-        ops.bn_bwd_reduce(dy, ysrc, z.t, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts)
+        want_res = res is not None and res.needs_grad
+        # residual blocks: the reduce pass also stores the masked gradient (the residual branch needs it anyway), and the
+        # apply pass then reads that instead of dy AND the saved output: one tensor pass less per block
+        gm = torch.empty_like(z.t) if (want_res and relu and ysrc is not None and self.bn_mask_in_reduce) else None
+        ops.set_meta(name=layer.name, bytes=nb * ((3 if ysrc is not None else 2) + (gm is not None)))
+        ops.bn_bwd_reduce(dy, ysrc, z.t, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts, gmask=gm)
         part, nparts = self._fold_parts(part, nparts, 2 * C_)
         c1, c2 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(2))
         dgamma, dbeta, store = self._bn_grad_views(layer)
@@ -578,15 +585,19 @@ class ExpertGroupEngine:
         if not train:          # eval-mode BN is an affine map: no batch-statistics terms
             c1.zero_()
             c2.zero_()
-        want_res = res is not None and res.needs_grad
         dz = torch.empty_like(z.t) if z.needs_grad else None
-        gm = torch.empty_like(z.t) if want_res else None
-        if dz is None and gm is None:
-            return
-        if dz is None:
-            dz = torch.empty_like(z.t)
-        ops.set_meta(name=layer.name, bytes=nb * (2 + (ysrc is not None) + 1 + (gm is not None)))
-        ops.bn_bwd_apply(dy, ysrc, z.t, mean, invstd, scale, shift, c1, c2, dz, gm, rpe, E, C_, relu)
+        if gm is not None:
+            if dz is not None:
+                ops.set_meta(name=layer.name, bytes=nb * 3)
+                ops.bn_bwd_apply(gm, None, z.t, mean, invstd, scale, shift, c1, c2, dz, None, rpe, E, C_, False)
+        else:
+            gm = torch.empty_like(z.t) if want_res else None
+            if dz is None and gm is None:
+                return
+            if dz is None:
+                dz = torch.empty_like(z.t)
+            ops.set_meta(name=layer.name, bytes=nb * (2 + (ysrc is not None) + 1 + (gm is not None)))
+            ops.bn_bwd_apply(dy, ysrc, z.t, mean, invstd, scale, shift, c1, c2, dz, gm, rpe, E, C_, relu)
         if self.debug_grads is not None:
             self.debug_grads[layer.name + ":dz"] = dz.detach().clone()
             self.debug_grads[layer.name + ":stats"] = (mean.clone(), invstd.clone(), c1.clone(), c2.clone())

@@ -83,7 +83,7 @@ SIGNATURES = {
     "pmoe_reduce_partials": [_P, _P, _I, _I, _I, _I, _P],
     "pmoe_bn_finalize": [_P, _I, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P],
     "pmoe_bn_apply": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
-    "pmoe_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _I, _P],
+    "pmoe_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P],
     "pmoe_bn_bwd_finalize": [_P, _I, _L, _P, _P, _P, _P, _I, _I, _P],
     "pmoe_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "pmoe_stem_tail_stats": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -200,11 +200,12 @@ def bn_apply(x, res, y, scale, shift, mean, rpe, E, C_, relu, y_coff=0):
                                E, C_, int(relu), y.shape[-1], y_coff, dt(x), stream_ptr()), "pmoe_bn_apply")
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts):
-    """y=None (relu, no residual in forward): the ReLU mask is recomputed from x, the saved output is not read."""
+def bn_bwd_reduce(dy, y, x, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts, gmask=None):
+    """y=None (relu, no residual in forward): the ReLU mask is recomputed from x, the saved output is not read.
+    gmask: the masked gradient is stored there (bn_bwd_apply then takes it as dy with relu=False, y=None)."""
     check(load().pmoe_bn_bwd_reduce(ptr(dy, "dy"), ptr(y, "y", dy.dtype), ptr(x, "x", dy.dtype), ptr(mean), ptr(invstd),
-                                    ptr(scale), ptr(shift), rpe, E, C_, int(relu), ptr(part, "part", torch.float32), nparts, dt(dy),
-                                    stream_ptr()), "pmoe_bn_bwd_reduce")
+                                    ptr(scale), ptr(shift), rpe, E, C_, int(relu), ptr(part, "part", torch.float32), nparts,
+                                    ptr(gmask, "gmask", dy.dtype), dt(dy), stream_ptr()), "pmoe_bn_bwd_reduce")
 
 
 def bn_bwd_finalize(part, nparts, count, dgamma, dbeta, c1, c2, E, C_):

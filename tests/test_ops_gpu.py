@@ -426,6 +426,13 @@ def test_batchnorm_fwd_bwd(shape, dtype):
     for e in range(E):
         close(dgam[e], gr[e].grad, dtype, "dgamma")
         close(dbet[e], br[e].grad, dtype, "dbeta")
+    # the reduce pass can store the masked gradient itself; the apply pass then takes it as dy (relu off, saved output unread):
+    # bit-identical partial sums, residual gradient and dx
+    bpart2, gm2, dx2 = torch.empty_like(bpart), torch.empty_like(xd), torch.empty_like(xd)
+    ops.bn_bwd_reduce(dyd, y, xd, mean, invstd, scale, shift, rpe, E, C_, True, bpart2, nparts, gmask=gm2)
+    assert torch.equal(bpart2, bpart) and torch.equal(gm2, gm)
+    ops.bn_bwd_apply(gm2, None, xd, mean, invstd, scale, shift, c1, c2, dx2, None, rpe, E, C_, False)
+    assert torch.equal(dx2, dx)
     # no-residual ReLU: the mask is recomputed from x (y = None) and must equal the y-based mask
     y2 = torch.empty_like(xd)
     ops.bn_apply(xd, None, y2, scale, shift, mean, rpe, E, C_, True)
@@ -807,3 +814,36 @@ def test_batchnorm_statistics_are_centred():
     ref_is = 1.0 / torch.sqrt(xe.var(dim=2, unbiased=False) + 1e-5)
     assert ((invstd.cpu().double() - ref_is).abs() / ref_is).max().item() < 1e-5
     assert ((mean.cpu().double() - xe.mean(dim=2)).abs().max().item()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 3, 75, 53), (1, 2, 64, 96), (3, 1, 17, 8)])
+def test_stem_tail_row_walking_kernels_match_gather_kernels(dtype, shape, monkeypatch):
+    """stem_tail_pool_walk_kernel / stem_tail_dz_walk_kernel (each z2 element loaded and evaluated once, taps as max-keys / SWAR
+    bytes) against the per-output gather kernels they replace (PMOE_STEM_WALK=0, themselves checked against the unfused chain in
+    test_model_gpu): pooled output and winning taps bit-identical, dz2 within one rounding of the output type; odd sizes, image
+    and expert boundaries."""
+    E, B, H, W = shape
+    C_, N = 64, E * B
+    g = torch.Generator().manual_seed(11)
+    z2 = rnd((N, H, W, C_), g, dtype).to(dtype).to(DEV)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dp = rnd((N, Ho, Wo, C_), g, dtype).to(dtype).to(DEV)
+    u = lambda lo, hi: (torch.rand(E, C_, generator=g) * (hi - lo) + lo).to(DEV)
+    sc2, sh2, sc1, sh1, mu1, is1, mu2, is2 = u(.5, 1.5), u(-.3, .3), u(.5, 1.5), u(-.3, .3), u(.2, .5), u(.8, 1.2), u(-.1, .1), u(.8, 1.2)
+    consts = [sc2, sh2, sc1, sh1, mu1, is1, mu2, is2, u(-.01, .01), u(-.01, .01), u(-.01, .01), u(-.01, .01)]
+    part = torch.empty(E, 4, 2, C_, device=DEV)
+    out = {}
+    for walk in ("0", "1"):
+        monkeypatch.setenv("PMOE_STEM_WALK", walk)
+        y = torch.full((N, Ho, Wo, C_), 7.0, dtype=dtype, device=DEV)
+        am = torch.full((N, Ho, Wo, C_), 99, dtype=torch.uint8, device=DEV)
+        dz = torch.full_like(z2, 7.0)
+        ops.stem_tail_pool(z2, y, am, sc2, sh2, sc1, sh1, mu2, mu1, B)
+        ops.stem_tail_bwd(3, z2, dp, am, dz, consts, part, 4, E, B)
+        out[walk] = (y, am, dz)
+    assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1])
+    assert int(out["0"][1].max()) <= 0x88
+    a, b = out["1"][2].float(), out["0"][2].float()
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -21
+    assert ((a - b).abs() <= ulp * b.abs().clamp_min(1e-3)).all()
