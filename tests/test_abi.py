@@ -79,7 +79,7 @@ def test_conv_plan_reports_the_kernel_instantiation():
         d.dtype = 0 if dtype == torch.bfloat16 else 1
         return load().pmoe_conv2d_plan(C.byref(d))
     assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1107                 # conv3x3_resdma_kernel (filter bank resident, LDS-DMA patches)
-    assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1005                 # 12(16)-channel stem on the resident kernel
+    assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1316                 # 12(16)-channel stem: conv3x3_c16_kernel (direct form)
     assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 5007                # conv3x3_dma_kernel (LDS-DMA staged, conv_dma.hip)
     assert plan(128, 256, 64, 1, 2, torch.bfloat16) == 2007                # 1x1 stride 2: conv_igemm_lite_kernel<bf16,7>, 2 workgroups / CU
     assert plan(256, 256, 32, 3, 1, torch.float32) == 722                  # f32: 4-wave 128x128 tile, 32-channel chunks
