@@ -59,14 +59,23 @@ int pmoe_conv2d_igemm(const pmoe_conv_desc* d, void* stream) {
     return conv_igemm_launch(to_args(d), d->dtype, (hipStream_t)stream);
 }
 
+// planning descriptors may leave the leading dimensions 0 = dense rows (cin / cout wide): the kernel choice depends on them
+// (32-bit offset ranges), so the launch and the planning call must see the same values
+static ConvArgs to_plan_args(const pmoe_conv_desc* d) {
+    ConvArgs a = to_args(d);
+    if (a.in_ld <= 0) a.in_ld = a.in_coff + a.Cin;
+    if (a.out_ld <= 0) a.out_ld = a.out_coff + a.Cout;
+    return a;
+}
+
 int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d) {
     if (!d || d->ipe <= 0) return PMOE_ERR_ARG;
-    return conv_igemm_mblocks(to_args(d), d->dtype);
+    return conv_igemm_mblocks(to_plan_args(d), d->dtype);
 }
 
 int pmoe_conv2d_plan(const pmoe_conv_desc* d) {
     if (!d || d->ipe <= 0) return PMOE_ERR_ARG;
-    return conv_igemm_plan(to_args(d), d->dtype);
+    return conv_igemm_plan(to_plan_args(d), d->dtype);
 }
 
 static int to_wgrad_args(const pmoe_wgrad_desc* d, WgradArgs& a) {

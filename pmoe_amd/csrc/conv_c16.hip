@@ -46,10 +46,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c16_kernel(ConvArgs a, int til
     // all addressing is (uniform 32-bit byte offset in an SGPR) + (per-lane constant): buffer loads / stores whose per-lane
     // offset is pushed out of range where the pixel column or the channel chunk does not exist (reads return 0, writes drop)
     // (the input descriptor starts ONE PIXEL BEFORE the tensor: lane offsets of the left tap column stay non-negative)
+    // one descriptor per EXPERT (in_bytes / out_bytes are per-expert sizes): the 32-bit offsets only span one expert's images
+    const size_t in_img0 = a.in_shared ? 0 : (size_t)e * a.ipe, out_img0 = (size_t)e * a.ipe;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<const bf16*>(a.in) + a.in_coff - a.in_ld), (short)0, (int)(in_bytes + (unsigned)a.in_ld * 2u), 0x00020000);
+        (void*)(reinterpret_cast<const bf16*>(a.in) + in_img0 * a.H * a.W * a.in_ld + a.in_coff - a.in_ld), (short)0,
+        (int)(in_bytes + (unsigned)a.in_ld * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<bf16*>(a.out) + a.out_coff), (short)0, (int)out_bytes, 0x00020000);
+        (void*)(reinterpret_cast<bf16*>(a.out) + out_img0 * a.H * a.W * a.out_ld + a.out_coff), (short)0, (int)out_bytes, 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
     const int px_l = lane & 31, kh = lane >> 5;
     const unsigned ld2 = (unsigned)a.in_ld * 2u, old2 = (unsigned)a.out_ld * 2u;
@@ -72,8 +75,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c16_kernel(ConvArgs a, int til
     // (never inside a branch: the compiler's vmcnt bookkeeping assumes the fewest younger requests of any path, so one skipped
     // prefetch would turn every wait into "everything issued so far"; `live` = false parks all offsets out of range instead)
     auto load_tile = [&](const Pos& p, v4u (&raw)[9], bool live) {
-        const int in_img = a.in_shared ? p.img : e * a.ipe + p.img;
-        const unsigned row0 = ((unsigned)(in_img * a.H + p.y) * (unsigned)a.W + (unsigned)p.xt * 32u) * ld2;   // (y, first pixel of the tile)
+        const unsigned row0 = ((unsigned)(p.img * a.H + p.y) * (unsigned)a.W + (unsigned)p.xt * 32u) * ld2;   // (y, first pixel of the tile)
         const int px = p.xt * 32 + px_l;
         unsigned vq[3];
         vq[0] = live && px >= 1 && px - 1 < a.W ? vin - ld2 : OOB;
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c16_kernel(ConvArgs a, int til
         }
         // every store instruction writes 8 whole 128-byte pixel rows, and a lane keeps ONE channel chunk for all pixels and
         // tiles, so the BatchNorm sums need 16 registers instead of 64
-        const unsigned osoff = ((unsigned)((e * a.ipe + pc.img) * a.H + pc.y) * (unsigned)a.W + (unsigned)pc.xt * 32u) * old2;
+        const unsigned osoff = ((unsigned)(pc.img * a.H + pc.y) * (unsigned)a.W + (unsigned)pc.xt * 32u) * old2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = i * 8 + (lane >> 3), c = lane & 7;
@@ -188,8 +190,8 @@ bool conv_c16_plan(const ConvArgs& a, int dtype, int* wgs_per_expert, int* tiles
     if (a.bias || a.act != PMOE_ACT_NONE || a.res_mode != PMOE_RES_NONE || a.drop_p > 0.f) return false;
     if (a.N % a.ipe || a.Ho != a.H || a.Wo != a.W) return false;
     if (a.in_ld % 8 || a.in_coff % 8 || a.out_ld % 8 || a.out_coff % 8) return false;
-    // 32-bit byte offsets inside one buffer descriptor each (the kernel marks missing pixels with offsets >= 0xfffffff0)
-    if ((long long)a.N * a.H * a.W * (a.in_ld > a.out_ld ? a.in_ld : a.out_ld) * 2 >= 0xfff00000ll) return false;
+    // 32-bit byte offsets inside one buffer descriptor per expert (the kernel marks missing pixels with offsets >= 0xfffffff0)
+    if ((long long)a.ipe * a.H * a.W * (a.in_ld > a.out_ld ? a.in_ld : a.out_ld) * 2 >= 0xfff00000ll) return false;
     const int E = a.N / a.ipe, tx = (a.W + 31) / 32;
     const long long tpe = (long long)a.ipe * a.H * tx;
     if (tpe > 0x7fffffffll || tpe < 64) return false;                // tiny inputs: the tiled kernels' launch shapes are fine
@@ -204,8 +206,8 @@ bool conv_c16_plan(const ConvArgs& a, int dtype, int* wgs_per_expert, int* tiles
 int conv_c16_launch(const ConvArgs& a, hipStream_t st) {
     int wpe, tx, tpe;
     if (!conv_c16_plan(a, PMOE_DT_BF16, &wpe, &tx, &tpe)) return PMOE_ERR_ARG;
-    const long long in_b = (long long)(a.in_shared ? a.ipe : a.N) * a.H * a.W * a.in_ld * 2 - (long long)a.in_coff * 2;
-    const long long out_b = (long long)a.N * a.H * a.W * a.out_ld * 2 - (long long)a.out_coff * 2;
+    const long long in_b = (long long)a.ipe * a.H * a.W * a.in_ld * 2 - (long long)a.in_coff * 2;
+    const long long out_b = (long long)a.ipe * a.H * a.W * a.out_ld * 2 - (long long)a.out_coff * 2;
     hipLaunchKernelGGL(conv3x3_c16_kernel, dim3(wpe, a.N / a.ipe), dim3(256), 0, st, a, tx, tpe, wpe, (unsigned)in_b, (unsigned)out_b);
     return (int)hipGetLastError();
 }

@@ -390,7 +390,8 @@ class ExpertGroupEngine:
         f8 = layer.w_f8 is not None and bias is False and act == hip.ACT_NONE
         if want_stats:
             rows = ops.conv2d_stat_rows(self.N, H, W, Ho, Wo, layer.cinp, layer.cout_st, layer.coutp, self.B, layer.ks,
-                                        layer.stride, layer.pad, self.dtype, w_fp8=f8)
+                                        layer.stride, layer.pad, self.dtype, w_fp8=f8, in_ld=x.t.shape[-1],
+                                        out_ld=o.t.shape[-1], in_shared=in_shared)
             stats = torch.empty(rows, 2, layer.coutp, dtype=F32, device=self.dev)
         seed = (next(self._seed_counter) * 0x9E3779B1 + self.base_seed) & 0xFFFFFFFFFFFF if drop_p > 0 else 0
         flop = 2.0 * self.N * Ho * Wo * layer.cout * layer.cin * layer.taps
@@ -763,7 +764,7 @@ class ExpertGroupEngine:
         stats = None
         if self.training and self.fuse_conv_stats and self.dtype == torch.bfloat16:
             rows = ops.conv2d_stat_rows(N, h, w, Ho, Wo, layer.cinp, layer.cout_st, layer.coutp, 1, layer.ks, layer.stride,
-                                        layer.pad, self.dtype)
+                                        layer.pad, self.dtype, in_ld=x.t.shape[-1], out_ld=o.t.shape[-1])
             stats = torch.empty(rows, 2, layer.coutp, dtype=F32, device=self.dev)
         flop = 2.0 * N * Ho * Wo * layer.cout * layer.cin * layer.taps
         ops.set_meta(flop=flop, name=layer.name)

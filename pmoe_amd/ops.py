@@ -63,15 +63,25 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
         raise ValueError("conv2d: packed weight tensor too small")
     if plan_only:
         return load().pmoe_conv2d_plan(C.byref(d))
+    if stats is not None:
+        # the launch writes exactly pmoe_conv2d_stat_rows(d) partial-sum rows: a buffer sized from a different descriptor
+        # (other row lengths can mean another kernel) would be folded with unwritten rows
+        rows = load().pmoe_conv2d_stat_rows(C.byref(d))
+        if stats.dim() != 3 or stats.shape[0] != rows or stats.shape[1] != 2 or stats.shape[2] != coutp:
+            raise ValueError(f"conv2d: stats must be [{rows}, 2, {coutp}] for this launch, got {tuple(stats.shape)}")
     if _prof is not None:            # profiling: remember which kernel instantiation serves this launch
         _launch_info["kernel"] = load().pmoe_conv2d_plan(C.byref(d))
     check(load().pmoe_conv2d_igemm(C.byref(d), stream_ptr()), "pmoe_conv2d_igemm")
     return out
 
 
-def conv2d_stat_rows(n, h, w_, ho, wo, cin, cout, coutp, ipe, ks, stride, pad, dtype, w_fp8=False):
+def conv2d_stat_rows(n, h, w_, ho, wo, cin, cout, coutp, ipe, ks, stride, pad, dtype, w_fp8=False, in_ld=0, out_ld=0,
+                     in_shared=False):
+    """Partial-sum rows the launch will write.  in_ld / out_ld: row lengths (elements) of the tensors the launch will get --
+    the kernel choice can depend on them (0 = dense)."""
     d = ConvDesc()
     d.w_fp8, d.in_scale = int(w_fp8), 1.0
+    d.in_ld, d.out_ld, d.in_shared = in_ld, out_ld, int(in_shared)
     d.n, d.h, d.w_, d.cin, d.ho, d.wo, d.cout, d.coutp = n, h, w_, cin, ho, wo, cout, coutp
     d.ipe, d.ks, d.stride, d.pad, d.dtype = ipe, ks, stride, pad, hip._TORCH_DT[dtype]
     rows = load().pmoe_conv2d_stat_rows(C.byref(d))

@@ -91,6 +91,28 @@ def test_conv_plan_reports_the_kernel_instantiation():
     assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 4741   # stride-2 dgrad: 4 class launches <7,4,1>
 
 
+def test_planning_calls_see_the_same_descriptor_as_the_launch():
+    """The kernel choice can depend on the row lengths (32-bit offset ranges): a planning descriptor that leaves them 0 means
+    DENSE rows, and must agree with the one the launch gets -- at E=8, B=64 (BASELINE config 3's shard) the 16-channel stem
+    convolution once sized its BatchNorm partial-sum buffer for a different kernel than the one that ran."""
+    import ctypes as C
+    from pmoe_amd.hip import ConvDesc, load
+
+    def desc(E, B, cin, cout, H, in_ld, out_ld):
+        d = ConvDesc()
+        d.n, d.h, d.w_, d.cin, d.ho, d.wo, d.cout, d.coutp = E * B, H, H, cin, H, H, cout, 64
+        d.in_ld, d.out_ld, d.ipe, d.ks, d.stride, d.pad, d.dtype, d.in_shared = in_ld, out_ld, B, 3, 1, 1, 0, 1
+        return d
+    for E, B in ((4, 64), (8, 64), (1, 1)):
+        a, b = desc(E, B, 16, 64, 256, 0, 0), desc(E, B, 16, 64, 256, 16, 64)
+        assert load().pmoe_conv2d_plan(C.byref(a)) == load().pmoe_conv2d_plan(C.byref(b)) == 1316
+        assert load().pmoe_conv2d_stat_rows(C.byref(a)) == load().pmoe_conv2d_stat_rows(C.byref(b)) > 0
+    # rows 16x as long (a window of a wide buffer): one expert's images no longer fit 32-bit offsets -> another kernel, and the
+    # planning call says so
+    wide = desc(8, 64, 16, 64, 256, 16, 1024)
+    assert load().pmoe_conv2d_plan(C.byref(wide)) == 1005
+
+
 def test_cycle_stamped_tools_build_compiles(tmp_path):
     """tools/stamp_conv.py's -DPMOE_STAMP variant of the dominant conv kernel (never the product build) keeps compiling."""
     import shutil

@@ -851,3 +851,30 @@ def test_stem_tail_row_walking_kernels_match_gather_kernels(dtype, shape, monkey
     a, b = out["1"][2].float(), out["0"][2].float()
     ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -21
     assert ((a - b).abs() <= ulp * b.abs().clamp_min(1e-3)).all()
+
+
+def test_conv_c16_shared_input_and_stats_shape_guard():
+    """conv3x3_c16_kernel with the input shared by the experts (the stem's first convolution reads the ONE batch of frames for
+    every expert, model/moe.py:90-92) against F.conv2d per expert, fused BatchNorm sums included; a statistics buffer sized for
+    another descriptor is refused instead of being folded with unwritten rows."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    E, ipe, cin, cout, H, W = 3, 2, 12, 64, 40, 72
+    x = rnd((ipe, cin, H, W), g, dtype)
+    ws = [rnd((cout, cin, 3, 3), g, dtype, 0.2) for _ in range(E)]
+    wf, _, _ = pack(ws, 3, dtype)
+    xd = nhwc(x, 16, dtype)
+    out = torch.full((E * ipe, H, W, cout), 7.0, dtype=dtype, device=DEV)
+    kw = dict(cin=16, cout=cout, coutp=64, ipe=ipe, ks=3, stride=1, pad=1, in_shared=True)
+    assert ops.conv2d(xd, wf, out, plan_only=True, **kw) == 1316
+    rows = ops.conv2d_stat_rows(E * ipe, H, W, H, W, 16, cout, 64, ipe, 3, 1, 1, dtype, in_ld=16, out_ld=cout, in_shared=True)
+    stats = torch.zeros(rows, 2, 64, device=DEV)
+    ops.conv2d(xd, wf, out, stats=stats, **kw)
+    ref = torch.cat([F.conv2d(x, w, padding=1) for w in ws])
+    close(from_nhwc(out, cout), ref, dtype, "c16 shared input")
+    st = stats.view(E, rows // E, 2, 64).sum(1).cpu()
+    yo = out.float().cpu().reshape(E, -1, cout)
+    close(st[:, 0], yo.sum(1), dtype, "c16 stats sum")
+    close(st[:, 1], (yo * yo).sum(1), dtype, "c16 stats sumsq")
+    with pytest.raises(ValueError, match="stats must be"):
+        ops.conv2d(xd, wf, out, stats=torch.zeros(rows + 3, 2, 64, device=DEV), **kw)
