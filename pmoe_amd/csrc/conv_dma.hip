@@ -382,11 +382,11 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
 
 // Which launches take this kernel: bf16, dense 3x3 stride 1 pad 1 (forward, or the flipped-filter data gradient), whole
 // 64-channel chunks, >= 128 output-channel rows, per-expert maps of >= 4096 pixels that tile into 16- or 32-pixel-wide
-// strips.  PMOE_CONV_DMA=0 sends them back to conv_igemm_lite_kernel (A/B runs).
+// strips.  PMOE_CONV_DMA=0 sends them back to conv_igemm_lite_kernel (A/B runs; read per launch, so that tools/ab_conv.py can
+// interleave the two in one process).
 bool conv_dma_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf) {
-    static int on = -1;
-    if (on < 0) { const char* ev = getenv("PMOE_CONV_DMA"); on = ev ? atoi(ev) : 1; }
-    if (!on || dtype != PMOE_DT_BF16 || a.w_fp8) return false;
+    const char* ev = getenv("PMOE_CONV_DMA");
+    if ((ev && !atoi(ev)) || dtype != PMOE_DT_BF16 || a.w_fp8) return false;
     if (a.ks != 3 || a.kh != 3 || a.kw != 3 || a.use_tapmap || a.stride != 1 || a.pad != 1 || a.dilate || a.in_shared) return false;
     if (a.out_step != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     if (a.Cin % CK || a.CoutP % BN || a.Cout % 8 || a.N % a.ipe) return false;
