@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
 // bank ranges for every tap shift), applied to the per-lane SOURCE address and to the reads.  The key of a read is
 // lane-constant per tap column (3 precomputed offsets), so a tap still costs one immediate row offset.  Out-of-image
 // pixels, images beyond the expert's last and channels beyond Cin / Cout arrive as zeros from the buffer range check.
-template <bool PIN>
+template <int PIN>
 __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, const int magic_pw, const int magic_ph) {
     constexpr int TAPS = 9, RS = 128, CKW = 64;
     constexpr int WCI = 2, WCO = 2, WK = 2;
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
         // k-blocks of 16 pixels; the X fragment of tap t+1 is read BEFORE the MFMA of tap t, order pinned: with one dY fragment
         // per 9 MFMAs every MFMA otherwise waits for the two transposed reads hipcc sinks directly in front of it
         // (interleaved A/B, tools/ab_conv.py: +8-10 % on layer1-4; a depth of 2, or reading ahead across k-block boundaries,
-        // adds nothing)
+        // adds nothing; an explicit cross-k-block prefetch of the dY and first X fragment measured 2-3 % SLOWER)
         auto frag_addr = [&](int kb, int* pA, int* ppB) {
             const int p0 = kb << 4;
 #pragma unroll
@@ -387,15 +387,24 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
         for (int kb = k_sub; kb < (BMP >> 4); kb += WK) {
             int pA[2], ppB[2];
             frag_addr(kb, pA, ppB);
+            if (PIN >= 2) {   // tools build (-DPMOE_STAMP) only, timing, WRONG results: 2 = one X fragment per k-block, 3 = no LDS reads at all
+                              // (layer4: 0.306 ms as shipped, 0.274 / 0.209 ms = 1481 TFLOP/s: what a stream of 32x32x16 bf16 MFMAs
+                              // sustains on this part under its power limit)
+                bf16x8 fa = PIN == 2 ? read_a(pA) : __builtin_bit_cast(bf16x8, v4i{kb, lane, kb, lane});
+                bf16x8 fb = PIN == 2 ? read_b(ppB, 0) : __builtin_bit_cast(bf16x8, v4i{lane, kb, lane, kb});
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                continue;
+            }
             const bf16x8 fa = read_a(pA);
             bf16x8 fbq[2];                                // static double buffer: tap t lives in fbq[t & 1]
             fbq[0] = read_b(ppB, 0);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 if (tap + 1 < TAPS) fbq[(tap + 1) & 1] = read_b(ppB, tap + 1);
-                if (PIN) __builtin_amdgcn_sched_barrier(0);       // (PIN = false: A/B switch, hipcc places the reads)
+                if (PIN == 1) __builtin_amdgcn_sched_barrier(0);       // (PIN = 0: A/B switch, hipcc places the reads)
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbq[tap & 1], acc[tap], 0, 0, 0);
-                if (PIN) __builtin_amdgcn_sched_barrier(0);
+                if (PIN == 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -537,12 +546,21 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                 const int nsp = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
                 dim3 grid(nsp * pairs / E, 1, E), block(512, 1, 1);
                 const char* evx = getenv("PMOE_WGRAD_PIPE");
+#ifdef PMOE_STAMP          // tools build only (tools/stamp_conv.py --build): timing modes with WRONG results, see the kernel's main loop
+                if (evx && atoi(evx) == 2) {
+                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<2>>(160 * 1024)));
+                    hipLaunchKernelGGL(conv_wgrad_dma_kernel<2>, grid, block, sm, st, a, mpw, mph);
+                } else if (evx && atoi(evx) == 3) {
+                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<3>>(160 * 1024)));
+                    hipLaunchKernelGGL(conv_wgrad_dma_kernel<3>, grid, block, sm, st, a, mpw, mph);
+                } else
+#endif
                 if (evx && !atoi(evx)) {
-                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<false>>(160 * 1024)));
-                    hipLaunchKernelGGL(conv_wgrad_dma_kernel<false>, grid, block, sm, st, a, mpw, mph);
+                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<0>>(160 * 1024)));
+                    hipLaunchKernelGGL(conv_wgrad_dma_kernel<0>, grid, block, sm, st, a, mpw, mph);
                 } else {
-                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<true>>(160 * 1024)));
-                    hipLaunchKernelGGL(conv_wgrad_dma_kernel<true>, grid, block, sm, st, a, mpw, mph);
+                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<1>>(160 * 1024)));
+                    hipLaunchKernelGGL(conv_wgrad_dma_kernel<1>, grid, block, sm, st, a, mpw, mph);
                 }
                 HIP_RET(hipGetLastError());
                 if (!a.per_image && nsp > 1) {

@@ -118,7 +118,7 @@ def test_cycle_stamped_tools_build_compiles(tmp_path):
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    for name in ("conv_igemm", "conv_dma"):
+    for name in ("conv_igemm", "conv_dma", "conv_wgrad"):
         src = REPO / "pmoe_amd" / "csrc" / f"{name}.hip"
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DPMOE_STAMP",
                                "-c", str(src), "-o", str(tmp_path / f"{name}_stamp.o")], stderr=subprocess.DEVNULL)

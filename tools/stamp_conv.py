@@ -21,12 +21,12 @@ def build():
     csrc, bld = ROOT / "pmoe_amd" / "csrc", ROOT / "build"
     subprocess.check_call([str(ROOT / "build.sh")])
     objs = []
-    for src in ("conv_igemm", "conv_dma"):
+    for src in ("conv_igemm", "conv_dma", "conv_wgrad"):
         obj = bld / f"{src}_stamp.o"
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                                "-Wno-unused-result", "-DPMOE_STAMP", "-c", str(csrc / f"{src}.hip"), "-o", str(obj)])
         objs.append(str(obj))
-    skip = ("conv_igemm.o", "conv_igemm_stamp.o", "conv_dma.o", "conv_dma_stamp.o")
+    skip = ("conv_igemm.o", "conv_igemm_stamp.o", "conv_dma.o", "conv_dma_stamp.o", "conv_wgrad.o", "conv_wgrad_stamp.o")
     others = [str(o) for o in sorted(bld.glob("*.o")) if o.name not in skip]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + objs + others)
     print("built", LIB)
