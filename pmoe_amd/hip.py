@@ -137,11 +137,67 @@ def lib_path():
     return _LIB_PATH
 
 
+# ---- launch recording (pmoe_amd/infer.py:PlannedMixture): every library call made while a LaunchRecorder is active is kept as
+# (ctypes function, converted arguments) and can be re-issued without any of the Python above it -- the descriptors, pointer
+# tables and scalar arguments are exactly the ones of the recorded run.
+_recorder = None
+_NOT_LAUNCHES = frozenset(("pmoe_error_string", "pmoe_abi_sizeof", "pmoe_conv2d_plan", "pmoe_conv2d_stat_rows",
+                           "pmoe_conv2d_wgrad_plan", "pmoe_conv2d_wgrad_ws_floats"))
+
+
+class LaunchRecorder:
+    """``with LaunchRecorder() as plan: ...`` records the launches of the block (they also run); ``plan.replay()`` issues them again
+    on the stream they were recorded on.  The caller keeps every buffer of the recorded run alive and in place (PlannedMixture
+    runs it inside a private ``torch.cuda.MemPool``)."""
+
+    def __init__(self):
+        self.calls = []
+        self.stream = None
+
+    def __enter__(self):
+        global _recorder
+        if _recorder is not None:
+            raise RuntimeError("a LaunchRecorder is already active")
+        self.stream = torch.cuda.current_stream().cuda_stream
+        _recorder = self
+        return self
+
+    def __exit__(self, *exc):
+        global _recorder
+        _recorder = None
+        return False
+
+    def replay(self):
+        if torch.cuda.current_stream().cuda_stream != self.stream:
+            raise RuntimeError("LaunchRecorder.replay: the plan was recorded on another stream")
+        for fn, args in self.calls:
+            rc = fn(*args)
+            if rc:
+                check(rc, fn.__name__)
+
+
+class _RecordingLib:
+    def __init__(self, lib, rec):
+        self._lib, self._rec = lib, rec
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in _NOT_LAUNCHES:
+            return fn
+        rec = self._rec
+
+        def call(*args):
+            rc = fn(*args)
+            rec.calls.append((fn, args))
+            return rc
+        return call
+
+
 def load():
     """Load (once) and return the shared library; raise HipUnavailable if it has not been built."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if _recorder is None else _RecordingLib(_lib, _recorder)
     if not _LIB_PATH.exists():
         raise HipUnavailable(
             f"{_LIB_PATH} not found: build it with ./build.sh (hipcc --offload-arch=gfx950). "

@@ -8,6 +8,7 @@ call :meth:`GraphedMixture.refresh` after loading new weights.
 """
 import torch
 
+from . import hip
 from .model.moe import MixtureDistribution
 
 
@@ -42,6 +43,48 @@ class GraphedMixture:
                 raise ValueError(f"GraphedMixture was captured for input shape {tuple(dst.shape)}, got {tuple(src.shape)}")
             dst.copy_(src)
         self.graph.replay()
+        return self.static_out
+
+    def sample(self, images, speed, command):
+        probs, mean, std, _ = self(images, speed, command)
+        return MixtureDistribution(probs, mean, std).sample()
+
+
+class PlannedMixture:
+    """The same tick WITHOUT graph capture: the launches of one eval-mode ``model.mixture_params`` call are recorded once
+    (``hip.LaunchRecorder``: C-ABI function + its converted arguments, descriptors included) and re-issued per tick straight
+    through ctypes -- none of the engine's Python (shape logic, descriptor filling, allocation, pointer validation) runs
+    again.  The recorded run allocates from a private ``torch.cuda.MemPool`` that lives as long as the plan, so every
+    recorded pointer stays valid and nothing else is handed that memory.  Same contract as :class:`GraphedMixture`: fixed
+    input shapes, ``refresh()`` after a weight change, replay on the stream the plan was recorded on.  Inputs must already be
+    float32 and contiguous (then the chain contains no torch kernel, only library launches)."""
+
+    def __init__(self, model, images, speed, command):
+        if model.training:
+            raise RuntimeError("PlannedMixture records the eval-mode chain: call model.eval() first")
+        for t in (images, speed, command):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("PlannedMixture: inputs must be contiguous float32 tensors")
+        self.model = model
+        self.static_in = [images.clone(), speed.clone(), command.clone()]
+        self.refresh()
+
+    def refresh(self):
+        model = self.model
+        with torch.no_grad():
+            for _ in range(2):                           # packs weights, builds pointer tables (cached on the parameters' versions)
+                model.mixture_params(*self.static_in)
+            self.pool = torch.cuda.MemPool()
+            with torch.cuda.use_mem_pool(self.pool), hip.LaunchRecorder() as plan:
+                self.static_out = model.mixture_params(*self.static_in)
+        self.plan = plan
+
+    def __call__(self, images, speed, command):
+        for dst, src in zip(self.static_in, (images, speed, command)):
+            if dst.shape != src.shape:
+                raise ValueError(f"PlannedMixture was recorded for input shape {tuple(dst.shape)}, got {tuple(src.shape)}")
+            dst.copy_(src)
+        self.plan.replay()
         return self.static_out
 
     def sample(self, images, speed, command):

@@ -113,6 +113,27 @@ def test_planning_calls_see_the_same_descriptor_as_the_launch():
     assert load().pmoe_conv2d_plan(C.byref(wide)) == 1005
 
 
+def test_launch_recorder_is_transparent_for_planning_calls():
+    """hip.LaunchRecorder (pmoe_amd/infer.py:PlannedMixture): planning / query entry points pass through unrecorded, and the
+    proxy is only in place while a recorder is active."""
+    import ctypes as C
+    from pmoe_amd import hip
+    if torch.cuda.is_available():
+        pytest.skip("the recorder's stream query is exercised by tests/test_model_gpu.py on a GPU")
+    lib = hip.load()
+    assert not isinstance(lib, hip._RecordingLib)
+    rec = hip.LaunchRecorder()
+    hip._recorder = rec                        # (entering the context needs a GPU stream)
+    try:
+        proxy = hip.load()
+        assert isinstance(proxy, hip._RecordingLib)
+        assert proxy.pmoe_abi_sizeof(0) == C.sizeof(hip.ConvDesc)
+        assert rec.calls == []
+    finally:
+        hip._recorder = None
+    assert hip.load() is lib
+
+
 def test_cycle_stamped_tools_build_compiles(tmp_path):
     """tools/stamp_conv.py's -DPMOE_STAMP variant of the dominant conv kernel (never the product build) keeps compiling."""
     import shutil

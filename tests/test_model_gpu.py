@@ -400,6 +400,43 @@ def test_graph_captured_inference_matches_eager():
         GraphedMixture(model, dev["images"], dev["speed"], dev["command"])
 
 
+def test_planned_inference_replays_the_recorded_launches():
+    """pmoe_amd.infer.PlannedMixture (host launch cost): the eval-mode B=1 chain recorded as a list of C-ABI
+    calls and re-issued without the engine's Python equals the eager path bit for bit, follows new inputs, survives unrelated
+    allocations (its buffers live in a private memory pool), and must be refreshed after a weight change."""
+    from pmoe_amd.infer import PlannedMixture
+    g = torch.load(GOLDEN / "g2_moe_e4_b1_224_eval.pt", weights_only=False)
+    _, _, model, inp = build_pair(g, torch.bfloat16)
+    dev = {k: v.cuda().float().contiguous() for k, v in inp.items()}
+    model.eval()
+    with torch.no_grad():
+        ref = [t.clone() for t in model.mixture_params(dev["images"], dev["speed"], dev["command"])]
+    pm = PlannedMixture(model, dev["images"], dev["speed"], dev["command"])
+    assert len(pm.plan.calls) > 20
+    for a, b in zip(ref, pm(dev["images"], dev["speed"], dev["command"])):
+        assert torch.equal(a, b)
+    junk = [torch.full((1 << 20,), float(i), device="cuda") for i in range(8)]       # would land in the plan's buffers if they were free
+    img2 = dev["images"].flip(-1).contiguous()
+    with torch.no_grad():
+        ref2 = [t.clone() for t in model.mixture_params(img2, dev["speed"], dev["command"])]
+    for a, b in zip(ref2, pm(img2, dev["speed"], dev["command"])):
+        assert torch.equal(a, b)
+    del junk
+    assert pm.sample(img2, dev["speed"], dev["command"]).shape == (1, 2)
+    with pytest.raises(ValueError, match="recorded for input shape"):
+        pm(dev["images"][:, :, :, :64].contiguous(), dev["speed"], dev["command"])
+    with torch.no_grad():                                  # weight change: stale until refresh()
+        for p_ in model.parameters():
+            p_.mul_(1.01)
+        ref3 = [t.clone() for t in model.mixture_params(img2, dev["speed"], dev["command"])]
+    pm.refresh()
+    for a, b in zip(ref3, pm(img2, dev["speed"], dev["command"])):
+        assert torch.equal(a, b)
+    model.train()
+    with pytest.raises(RuntimeError, match="eval"):
+        PlannedMixture(model, dev["images"], dev["speed"], dev["command"])
+
+
 @pytest.mark.parametrize("shape", [(1, 70, 54), (3, 33, 47), (2, 130, 64)])
 def test_ragged_shapes_f32_against_live_oracle(shape):
     """Edge cases the goldens do not carry: batch of ONE in train mode, odd and non-square image sides (pooling /

@@ -49,6 +49,20 @@ def main():
     print(f"E={E} B=1 224x224 eval  HIP graph: {graphed:.3f} ms/tick ({eager / graphed:.1f}x)", flush=True)
     a = gm.sample(img, spd, cmd)
     assert a.shape == (1, 2)
+
+    from pmoe_amd.infer import PlannedMixture
+    pm = PlannedMixture(model, img, spd, cmd)
+    got = pm(img, spd, cmd)
+    torch.cuda.synchronize()
+    for x, y in zip(ref, got):
+        assert torch.equal(x, y), "launch-plan replay differs from the eager chain"
+    t0 = time.perf_counter()
+    for _ in range(n):
+        got = pm(img, spd, cmd)
+    torch.cuda.synchronize()
+    planned = (time.perf_counter() - t0) / n * 1e3
+    print(f"E={E} B=1 224x224 eval  recorded launch plan ({len(pm.plan.calls)} C-ABI calls, no capture): {planned:.3f} ms/tick "
+          f"({eager / planned:.1f}x)", flush=True)
     if "--profile" in sys.argv:
         from pmoe_amd import ops
         ops.profile_begin()
