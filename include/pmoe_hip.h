@@ -191,6 +191,11 @@ int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const voi
 int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, const float* mean,
                   int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t y_ld, int32_t y_coff,
                   int32_t dtype, void* stream);
+/* pmoe_bn_apply (no residual, dense y) that ALSO returns pmoe_gap_partial(y)'s partial sums [N][nparts][C], bit-identical to a
+ * separate pmoe_gap_partial pass over the stored y: BatchNorm -> ReLU -> EfficientBlock of the stem (basics.py:113-123) without
+ * re-reading the activation for the block's global average pool.  N images, ipe images per expert, HW pixels per image. */
+int pmoe_bn_apply_gap(const void* x, void* y, const float* scale, const float* shift, const float* mean, float* gap_part,
+                      int32_t nparts, int32_t N, int32_t ipe, int64_t HW, int32_t C, int32_t relu, int32_t dtype, void* stream);
 /* backward reduce: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat -> part [E][nparts][2][C].
  * y may be NULL when relu is set and the forward had no residual: the mask is then recomputed as
  * x*scale+shift > 0 and the saved output is not read at all (one tensor pass less).

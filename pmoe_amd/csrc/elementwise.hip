@@ -400,6 +400,58 @@ __global__ void __launch_bounds__(256) gap_partial_kernel(const T* __restrict__ 
     }
 }
 
+// y = [relu]((x - mean) * scale + shift) AND the per-(image, channel) partial sums over HW of the stored y, in gap_partial_kernel's
+// own decomposition and summation order (bit-identical `part`): the ECA block that follows a BatchNorm (stem: bn -> relu ->
+// EfficientBlock, basics.py:113-123) gets its global-average-pool input from the pass that writes the activation instead of
+// re-reading 2.1 GB.  grid (nparts, N)
+template <typename T>
+__global__ void __launch_bounds__(256) bn_apply_gap_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ mean, float* __restrict__ part,
+                                                          long long HW, int C, int nparts, int ipe, int relu) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int CV = C / VE, RL = 256 / CV;
+    const int tid = threadIdx.x, cv = tid % CV, rl = tid / CV;
+    const int n = blockIdx.y, pi = blockIdx.x, e = n / ipe;
+    const long long rpp = (HW + nparts - 1) / nparts;
+    long long r0 = (long long)pi * rpp, r1 = r0 + rpp;
+    if (r1 > HW) r1 = HW;
+    float s[VE], sc[VE], sh[VE], mu[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+        s[i] = 0.f;
+        const int c = e * C + (rl < RL ? cv : 0) * VE + i;
+        sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c];
+    }
+    if (rl >= RL) r0 = r1;
+    for (long long r = r0 + rl; r < r1; r += RL) {
+        const size_t off = ((size_t)n * HW + r) * C + cv * VE;
+        float xv[VE];
+        unpack16<T>(ldg16(x + off), xv);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            xv[i] = (xv[i] - mu[i]) * sc[i] + sh[i];
+            if (relu) xv[i] = fmaxf(xv[i], 0.f);
+        }
+        const v4i pk = pack16<T>(xv);
+        stg16(y + off, pk);
+        float yv[VE];
+        unpack16<T>(pk, yv);                                   // the STORED value, as gap_partial_kernel would read it back
+#pragma unroll
+        for (int i = 0; i < VE; ++i) s[i] += yv[i];
+    }
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int i = 0; i < VE; ++i)
+        if (rl < RL) red[rl * C + cv * VE + i] = s[i];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float t = 0.f;
+        for (int k = 0; k < RL; ++k) t += red[k * C + c];
+        part[((size_t)n * nparts + pi) * C + c] = t;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) gap_finish_kernel(const float* __restrict__ part, T* __restrict__ out, int N,
                                                         int C, int nparts, float inv_hw, int out_ld, int out_coff) {
@@ -777,6 +829,18 @@ int pmoe_gap_partial(const void* a, const void* b, float* part, int32_t N, int64
         if (C % VE || C / VE > 256 || nparts < 1) return PMOE_ERR_ARG;
         hipLaunchKernelGGL((gap_partial_kernel<T>), dim3(nparts, N), dim3(256), 0, (hipStream_t)stream, (const T*)a,
                            (const T*)b, part, (long long)HW, C, nparts, b_shared_ipe);
+        return (int)hipGetLastError();
+    });
+}
+
+int pmoe_bn_apply_gap(const void* x, void* y, const float* scale, const float* shift, const float* mean, float* gap_part,
+                      int32_t nparts, int32_t N, int32_t ipe, int64_t HW, int32_t C, int32_t relu, int32_t dtype, void* stream) {
+    if (!x || !y || !scale || !shift || !mean || !gap_part || nparts < 1 || N < 1 || ipe < 1 || N % ipe || HW < 1) return PMOE_ERR_ARG;
+    DISPATCH_DT(dtype, {
+        constexpr int VE = 16 / (int)sizeof(T);
+        if (C % VE || C / VE > 256) return PMOE_ERR_ARG;
+        hipLaunchKernelGGL((bn_apply_gap_kernel<T>), dim3(nparts, N), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, scale,
+                           shift, mean, gap_part, (long long)HW, C, nparts, ipe, relu);
         return (int)hipGetLastError();
     });
 }

@@ -36,11 +36,12 @@ def r64(c):
 
 class Var:
     """A device activation [N,H,W,ld] (+ channel window) with its gradient slot."""
-    __slots__ = ("t", "coff", "c", "g", "needs_grad", "act", "drop_p", "base")
+    __slots__ = ("t", "coff", "c", "g", "needs_grad", "act", "drop_p", "base", "gap_part")
 
     def __init__(self, t, c=None, coff=0, needs_grad=False, base=None):
         self.t, self.coff, self.c = t, coff, (c if c is not None else t.shape[-1])
         self.g, self.needs_grad, self.act, self.drop_p, self.base = None, needs_grad, hip.ACT_NONE, 0.0, base
+        self.gap_part = None                 # (part [N,nparts,C], nparts): channel sums left by the pass that wrote t (_bn, want_gap)
 
     @property
     def grad(self):
@@ -162,6 +163,8 @@ class ExpertGroupEngine:
         # residual-block BatchNorm backward: the reduce pass stores the ReLU-masked gradient, the apply pass reads it (7 tensor
         # passes per block output instead of 8).  PMOE_BN_MASK_IN_REDUCE=0: A/B switch
         self.bn_mask_in_reduce = os.environ.get("PMOE_BN_MASK_IN_REDUCE", "1") != "0"
+        # stem: the BatchNorm+ReLU pass that writes a1 also leaves the ECA block's per-image channel sums (no GAP pass over a1)
+        self.fuse_bn_gap = os.environ.get("PMOE_FUSE_BN_GAP", "1") != "0"
         # BASELINE config 5: e4m3 weights + e4m3 activations on the fp8 matrix cores for the layer1-4 forward convolutions
         # (policy: include/pmoe_hip.h, pmoe_pack_conv_weights_fp8).  fp8_min_cin: smallest input-channel count that takes it
         self.fp8 = False
@@ -532,8 +535,10 @@ class ExpertGroupEngine:
                             self._tab("rv", layer), layer.momentum, layer.eps, False, scale, shift, mean, invstd, E, C_)
         return scale, shift, mean, invstd
 
-    def _bn(self, z, layer, relu, res=None, stats=None, out=None, out_coff=0):
-        """y = [relu](bn(z) [+ res]); train mode: batch statistics (fused conv partials or a colstats pass)."""
+    def _bn(self, z, layer, relu, res=None, stats=None, out=None, out_coff=0, want_gap=False):
+        """y = [relu](bn(z) [+ res]); train mode: batch statistics (fused conv partials or a colstats pass).
+        want_gap: the pass also leaves the per-image channel sums of y in ``y.gap_part`` (part, nparts) for the ECA block that
+        follows (_eca_conv_folded), instead of a separate pass over y."""
         E, C_ = self.E, layer.C
         n, h, w, _ = z.t.shape
         rpe = self.B * h * w
@@ -550,7 +555,13 @@ class ExpertGroupEngine:
         else:
             y = out.window(out_coff, C_)
         ops.set_meta(name=layer.name, bytes=z.t.numel() * z.t.element_size() * (3 if res is not None else 2))
-        ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, mean, rpe, E, C_, relu, y_coff=y.coff)
+        if want_gap and res is None and out is None and self.fuse_bn_gap:
+            nparts = self._gap_parts(h * w)
+            part = torch.empty(n, nparts, C_, dtype=F32, device=self.dev)
+            ops.bn_apply_gap(z.t, y.t, scale, shift, mean, part, nparts, self.B, relu)
+            y.gap_part = (part, nparts)
+        else:
+            ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, mean, rpe, E, C_, relu, y_coff=y.coff)
         y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
         if out is not None and y.needs_grad:
             out.needs_grad = True
@@ -748,9 +759,12 @@ class ExpertGroupEngine:
         nx, h, w, c = x.t.shape
         hw = h * w
         N, B_, E = self.N, self.B, self.E
-        nparts = self._gap_parts(hw)
-        part = torch.empty(nx, nparts, c, dtype=F32, device=self.dev)
-        ops.gap_partial(x.t, None, part, nparts)
+        if getattr(x, "gap_part", None) is not None:          # left by the BatchNorm pass that wrote x (_bn, want_gap)
+            part, nparts = x.gap_part
+        else:
+            nparts = self._gap_parts(hw)
+            part = torch.empty(nx, nparts, c, dtype=F32, device=self.dev)
+            ops.gap_partial(x.t, None, part, nparts)
         gate = torch.empty(N, c, dtype=F32, device=self.dev)
         gapmean = torch.empty(N, c, dtype=F32, device=self.dev)
         ops.eca_gate(part, nparts, hw, self._tab("eca", ecal), ecal.k, gate, gapmean, N, B_, 0, c, ecal.creal)
@@ -948,17 +962,18 @@ class ExpertGroupEngine:
         (backbone.py:63-70, basics.py:79-134)."""
         H, W = x0.t.shape[1], x0.t.shape[2]
         hw_ok = H * W >= 256                                 # per-image filter gradients need one tile <= one image
+        fold2 = self.fold_eca_gate and hw_ok and self.conv2.cin % 64 == 0
         if self.fold_stem_input and self.taping and hw_ok and (self.conv1.trainable or self.eca1.trainable):
             # backward of (ECA gate -> conv1) from per-image filter gradients: no data-gradient conv (heads.hip)
             x0s, gate, gapmean = self._eca(x0, self.eca1, shared=True, tape=False)
             z1, st = self._conv_stats(x0s, self.conv1, tape=False)
             z1.needs_grad = True
             self.tape.append(lambda: self._stem_in_bwd(x0, z1, gate, gapmean))
-            a1 = self._bn(z1, self.bn_c1, relu=True, stats=st)
+            a1 = self._bn(z1, self.bn_c1, relu=True, stats=st, want_gap=fold2)
         else:
             x0s = self._eca(x0, self.eca1, shared=True)
             a1 = self._conv_bn(x0s, self.conv1, self.bn_c1, relu=True)
-        if self.fold_eca_gate and hw_ok and self.conv2.cin % 64 == 0:
+        if fold2:
             z2, st = self._eca_conv_folded(a1, self.eca2, self.conv2)
         else:
             a1s = self._eca(a1, self.eca2, shared=False)

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pmoe_maxpool3s2_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pmoe_maxpool3s2_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pmoe_gap_partial": [_P, _P, _P, _I, _L, _I, _I, _I, _I, _P],
+    "pmoe_bn_apply_gap": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _I, _P],
     "pmoe_gap_finish": [_P, _P, _I, _I, _I, _L, _I, _I, _I, _P],
     "pmoe_gap_bwd": [_P, _P, _I, _L, _I, _I, _I, _I, _P],
     "pmoe_eca_gate": [_P, _I, _L, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],

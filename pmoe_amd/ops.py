@@ -290,6 +290,14 @@ def gap_partial(a, b, part, nparts, b_shared_ipe=0):
                                   nparts, b_shared_ipe, dt(a), stream_ptr()), "pmoe_gap_partial")
 
 
+def bn_apply_gap(x, y, scale, shift, mean, part, nparts, ipe, relu):
+    """bn_apply (no residual) + gap_partial(y) in one pass over the activation; part [N, nparts, C] f32."""
+    n, h, w_, c = _nhwc(x, "x")
+    check(load().pmoe_bn_apply_gap(ptr(x, "x"), ptr(y, "y", x.dtype), ptr(scale), ptr(shift), ptr(mean, "mean", torch.float32),
+                                   ptr(part, "part", torch.float32), nparts, n, ipe, h * w_, c, int(relu), dt(x), stream_ptr()),
+          "pmoe_bn_apply_gap")
+
+
 def gap_finish(part, out, n, c, nparts, hw, out_ld, out_coff):
     check(load().pmoe_gap_finish(ptr(part, "part", torch.float32), ptr(out, "out"), n, c, nparts, hw, out_ld, out_coff,
                                  dt(out), stream_ptr()), "pmoe_gap_finish")
@@ -422,7 +430,7 @@ def _timed(fn):
 
 
 for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "stem_tail_pooled", "stem_tail_combine", "conv2d", "conv2d_wgrad", "pack_conv_weights", "pack_conv_weights_scaled", "pack_conv_weights_gated", "unpack_conv_wgrad", "pack_bias", "colstats",
-           "reduce_partials", "bn_finalize", "bn_apply", "bn_bwd_reduce", "bn_bwd_finalize", "bn_bwd_apply",
+           "reduce_partials", "bn_finalize", "bn_apply", "bn_apply_gap", "bn_bwd_reduce", "bn_bwd_finalize", "bn_bwd_apply",
            "maxpool_fwd", "maxpool_bwd", "gap_partial", "gap_finish", "gap_bwd", "eca_gate", "eca_scale",
            "eca_bwd_small", "eca_bwd_apply", "eca_stem_fold", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",
            "moe_loss"):

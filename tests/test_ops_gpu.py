@@ -878,3 +878,29 @@ def test_conv_c16_shared_input_and_stats_shape_guard():
     close(st[:, 1], (yo * yo).sum(1), dtype, "c16 stats sumsq")
     with pytest.raises(ValueError, match="stats must be"):
         ops.conv2d(xd, wf, out, stats=torch.zeros(rows + 3, 2, 64, device=DEV), **kw)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_apply_with_fused_global_average_pool(dtype):
+    """pmoe_bn_apply_gap = pmoe_bn_apply followed by pmoe_gap_partial over the stored activation, bit for bit (activation and
+    partial sums), for a partition of the image that does not divide evenly and a channel count that leaves idle lanes."""
+    g = torch.Generator().manual_seed(9)
+    E, ipe, H, W = 2, 3, 23, 31
+    for C_ in (64, 48):
+        x = rnd((E * ipe, H, W, C_), g, dtype).to(dtype).to(DEV)
+        scale, shift, mean = (torch.rand(E, C_, generator=g).to(DEV) + 0.5 for _ in range(3))
+        for nparts in (1, 5):
+            y1, y2 = torch.empty_like(x), torch.full_like(x, 3.0)
+            p1 = torch.zeros(E * ipe, nparts, C_, device=DEV)
+            p2 = torch.full_like(p1, -1.0)
+            ops.bn_apply(x, None, y1, scale, shift, mean, ipe * H * W, E, C_, True) if C_ == 64 else None
+            if C_ != 64:      # bn_apply keeps one channel vector per thread (power-of-two vector counts): reference in torch
+                xf = x.float().view(E, ipe, H, W, C_)
+                y1 = torch.relu((xf - mean.view(E, 1, 1, 1, C_)) * scale.view(E, 1, 1, 1, C_) + shift.view(E, 1, 1, 1, C_)).to(dtype).view_as(x)
+            ops.gap_partial(y1, None, p1, nparts)
+            ops.bn_apply_gap(x, y2, scale, shift, mean, p2, nparts, ipe, True)
+            if C_ == 64:
+                assert torch.equal(y1, y2) and torch.equal(p1, p2)
+            else:
+                close(y2, y1.float().cpu(), dtype, "bn_apply_gap y")
+                close(p2, p1.cpu(), torch.float32, "bn_apply_gap sums")
