@@ -400,6 +400,25 @@ def test_graph_captured_inference_matches_eager():
         GraphedMixture(model, dev["images"], dev["speed"], dev["command"])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_side_stream_weight_gradients_equal_the_main_stream_ones(dtype):
+    """engine.overlap_wgrad (PMOE_OVERLAP_WGRAD=1): weight / bias gradients on a second HIP stream with their own K-split
+    scratch, ordered against the main stream by events.  Every reduction is fixed-order, so the result must be bit-identical."""
+    from pmoe_amd.loss import moe_loss
+    g = torch.load(GOLDEN / "g5_moe_e3_b3_96.pt", weights_only=False)
+    res = []
+    for overlap in (False, True):
+        _, _, model, inp = build_pair(g, dtype)
+        model._engine().overlap_wgrad = overlap
+        dev = {k: v.cuda() for k, v in inp.items()}
+        dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+        moe_loss(dist, speeds, dev["control"], dev["target_speed"], [0.7, 0.3]).backward()
+        torch.cuda.synchronize()
+        res.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
 def test_planned_inference_replays_the_recorded_launches():
     """pmoe_amd.infer.PlannedMixture (host launch cost): the eval-mode B=1 chain recorded as a list of C-ABI
     calls and re-issued without the engine's Python equals the eager path bit for bit, follows new inputs, survives unrelated
