@@ -27,7 +27,7 @@ def main():
         for v in ("0", "1"):
             os.environ["PMOE_CONV_C16"] = "0" if v == "0" else "1"
             os.environ["PMOE_C16_LDS_STORE"] = "0" if v == "2" else "1"
-            rows = ops.conv2d_stat_rows(N, H, H, H, H, cin, cout, cout, B, 3, 1, 1, dt)
+            rows = ops.conv2d_stat_rows(N, H, H, H, H, cin, cout, cout, B, 3, 1, 1, dt, in_ld=cin, out_ld=cout, in_shared=True)
             stats = torch.zeros(rows, 2, cout, device="cuda")
             y = torch.empty(N, H, H, cout, dtype=dt, device="cuda")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
