@@ -61,6 +61,14 @@ def main():
             d[1] += 1
         for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:14]:
             print(f"  {k:22s} {t:8.2f} ms  {n:4d} launches")
+        # conv launches grouped by (layer name, kernel plan code): where the 300 conv launches spend their time
+        conv = {}
+        for name, meta, ms_ in rows:
+            if name in ("conv2d", "conv2d_wgrad"):
+                d = conv.setdefault((name, meta.get("name", "?"), meta.get("kernel", "?")), [0.0, 0, 0.0])
+                d[0] += ms_; d[1] += 1; d[2] += meta.get("flop", 0.0)
+        for (op, lname, code), (t, n, fl) in sorted(conv.items(), key=lambda kv: -kv[1][0])[:28]:
+            print(f"  {op:13s} {lname:34s} plan {code!s:>6}  {t:7.2f} ms  {n:3d} launches  {fl / max(t, 1e-9) / 1e9:7.0f} TFLOP/s")
 
 
 if __name__ == "__main__":
