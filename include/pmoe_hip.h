@@ -121,7 +121,7 @@ int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
  * descriptor are not read. */
 int64_t pmoe_conv2d_wgrad_ws_floats(const pmoe_wgrad_desc* d);
 /* which kernel serves the descriptor (nothing is launched; bench.py attributes launch times to rocprof symbols with it):
- *   7009 = conv_wgrad_dma_kernel (LDS-DMA staged, dense 3x3 stride 1, bf16);  6000 + taps * 100 + MAXV = conv_wgrad_kernel<T, taps, MAXV> */
+ *   7009 = conv_wgrad_dma_kernel (LDS-DMA staged, dense 3x3 stride 1, bf16; 7109 = its wave layout for <= 32 input channels);  6000 + taps * 100 + MAXV = conv_wgrad_kernel<T, taps, MAXV> */
 int pmoe_conv2d_wgrad_plan(const pmoe_wgrad_desc* d);
 
 /* Master weights live in the reference's own layout (one f32 OIHW / [out][in] tensor per expert,

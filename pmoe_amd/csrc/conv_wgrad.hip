@@ -242,10 +242,12 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
 // bank ranges for every tap shift), applied to the per-lane SOURCE address and to the reads.  The key of a read is
 // lane-constant per tap column (3 precomputed offsets), so a tap still costs one immediate row offset.  Out-of-image
 // pixels, images beyond the expert's last and channels beyond Cin / Cout arrive as zeros from the buffer range check.
-template <int PIN>
+// WCI = 1 (layers with <= 32 input channels: the per-image gradient of the 16-channel stem convolution): the 8 waves are
+// 2 (cout) x 4 (pixel quarters) instead of 2 x 2 x 2 -- with WCI = 2 half of them multiplied the zero-filled channels 32..63.
+template <int PIN, int WCI = 2>
 __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, const int magic_pw, const int magic_ph) {
     constexpr int TAPS = 9, RS = 128, CKW = 64;
-    constexpr int WCI = 2, WCO = 2, WK = 2;
+    constexpr int WCO = 2, WK = 8 / (WCI * WCO);
     typedef __attribute__((address_space(3))) void lds_void;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -438,6 +440,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
                     for (int k = 1; k < WK; ++k) v += red[((((k - 1) * TPR + tp) * TILE_WAVES + tw) * 16 + r) * 64 + lane];
                     const int cout = co0 + co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     base[(size_t)cout * a.CinP + cin] = v;
+                    if (WCI == 1 && cin + 32 < a.CinP) base[(size_t)cout * a.CinP + cin + 32] = 0.f;   // columns nobody computes
                 }
             }
         }
@@ -540,7 +543,9 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                 exact = ((pp * mpw) >> 16) == pp / PW && ((((pp / PW) * mph) >> 16) == (pp / PW) / PH);
             if (dma_on && a.ks == 3 && a.stride == 1 && BMP == 256 && lTW >= 2 && npiece <= 48 && exact &&
                 xbytes < 0x7ff00000ll && dybytes < 0x7ff00000ll && 2 * ((size_t)BMP * 128 + (size_t)npiece * 1024) <= 160 * 1024) {
-                if (plan) { *code = 7009; return 0; }       // conv_wgrad_dma_kernel
+                const char* evn = getenv("PMOE_WGRAD_NARROW");           // A/B: 0 = the 2 x 2 x 2 wave layout for every layer
+                const bool narrow = a.Cin <= 32 && !(evn && !atoi(evn));
+                if (plan) { *code = narrow ? 7109 : 7009; return 0; }       // conv_wgrad_dma_kernel<1, 1> / <1, 2>
                 size_t sm = 2 * ((size_t)BMP * 128 + (size_t)npiece * 1024);
                 if (sm < 49152) sm = 49152;               // room for the flush's fold
                 const int nsp = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
@@ -555,7 +560,11 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                     hipLaunchKernelGGL(conv_wgrad_dma_kernel<3>, grid, block, sm, st, a, mpw, mph);
                 } else
 #endif
-                if (evx && !atoi(evx)) {
+                if (narrow) {
+                    if (sm < (size_t)3 * 3 * 2 * 4096) sm = (size_t)3 * 3 * 2 * 4096;      // fold room: (WK - 1) x 3 taps x 2 tile waves
+                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<1, 1>>(160 * 1024)));
+                    hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 1>), grid, block, sm, st, a, mpw, mph);
+                } else if (evx && !atoi(evx)) {
                     HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<0>>(160 * 1024)));
                     hipLaunchKernelGGL(conv_wgrad_dma_kernel<0>, grid, block, sm, st, a, mpw, mph);
                 } else {
@@ -586,7 +595,7 @@ int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
     return PMOE_ERR_ARG;
 }
 
-// which kernel a descriptor runs on: 7009 = conv_wgrad_dma_kernel; 6000 + taps * 100 + MAXV = conv_wgrad_kernel<T, taps, MAXV>
+// which kernel a descriptor runs on: 7009 = conv_wgrad_dma_kernel (7109: its <= 32-input-channel wave layout); 6000 + taps * 100 + MAXV = conv_wgrad_kernel<T, taps, MAXV>
 int conv_wgrad_plan(const WgradArgs& a, int dtype) {
     long long ws = 0;
     int code = 0;

@@ -113,6 +113,25 @@ def test_planning_calls_see_the_same_descriptor_as_the_launch():
     assert load().pmoe_conv2d_plan(C.byref(wide)) == 1005
 
 
+def test_wgrad_plan_reports_the_kernel_instantiation():
+    """pmoe_conv2d_wgrad_plan: the LDS-DMA weight-gradient kernel for the dense 3x3 bf16 layers, its 2 x 4 wave layout for layers
+    with <= 32 input channels (the stem's first convolution), the register-staged kernel for the strided ones."""
+    import ctypes as C
+    from pmoe_amd.hip import WgradDesc, load
+
+    def plan(cin, cinp, cout, H, ks, stride, B=64, E=4, per_image=0):
+        d = WgradDesc()
+        pad = ks // 2
+        Ho = (H + 2 * pad - ks) // stride + 1
+        d.n, d.h, d.w_, d.cin, d.cinp, d.ho, d.wo, d.cout, d.coutp = E * B, H, H, cin, cinp, Ho, Ho, cout, (cout + 63) // 64 * 64
+        d.x_ld, d.dy_ld, d.ipe, d.ks, d.stride, d.pad, d.dtype, d.per_image = cin, cout, B, ks, stride, pad, 0, per_image
+        return load().pmoe_conv2d_wgrad_plan(C.byref(d))
+    assert plan(64, 64, 64, 128, 3, 1) == 7009
+    assert plan(256, 256, 256, 32, 3, 1) == 7009
+    assert plan(16, 64, 64, 256, 3, 1) == 7109
+    assert 6000 <= plan(64, 64, 128, 128, 3, 2) < 7000
+
+
 def test_launch_recorder_is_transparent_for_planning_calls():
     """hip.LaunchRecorder (pmoe_amd/infer.py:PlannedMixture): planning / query entry points pass through unrecorded, and the
     proxy is only in place while a recorder is active."""
