@@ -904,3 +904,27 @@ def test_bn_apply_with_fused_global_average_pool(dtype):
             else:
                 close(y2, y1.float().cpu(), dtype, "bn_apply_gap y")
                 close(p2, p1.cpu(), torch.float32, "bn_apply_gap sums")
+
+
+def test_conv_c16_channel_windows():
+    """conv3x3_c16_kernel reading a 16-channel window of wider rows and writing a 64-channel window of wider rows (buffer
+    descriptors start at the window, row strides are the full row lengths): bit-identical to the dense launch, nothing written
+    outside the window."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(6)
+    E, ipe, cout, H, W = 2, 2, 64, 24, 72
+    x = rnd((E * ipe, 16, H, W), g, dtype)
+    ws = [rnd((cout, 16, 3, 3), g, dtype, 0.2) for _ in range(E)]
+    wf, _, _ = pack(ws, 3, dtype)
+    xd = nhwc(x, 16, dtype)
+    dense = torch.empty(E * ipe, H, W, cout, dtype=dtype, device=DEV)
+    kw = dict(cin=16, cout=cout, coutp=64, ipe=ipe, ks=3, stride=1, pad=1)
+    assert ops.conv2d(xd, wf, dense, plan_only=True, **kw) == 1316
+    ops.conv2d(xd, wf, dense, **kw)
+    xw = torch.full((E * ipe, H, W, 48), 5.0, dtype=dtype, device=DEV)
+    xw[..., 16:32] = xd
+    ow = torch.full((E * ipe, H, W, 160), 7.0, dtype=dtype, device=DEV)
+    assert ops.conv2d(xw, wf, ow, in_coff=16, out_coff=64, plan_only=True, **kw) == 1316
+    ops.conv2d(xw, wf, ow, in_coff=16, out_coff=64, **kw)
+    assert torch.equal(ow[..., 64:128], dense)
+    assert (ow[..., :64] == 7.0).all() and (ow[..., 128:] == 7.0).all()
