@@ -387,6 +387,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
     const bool cvalid = cc * VE < a.Cout;
     bf16* out = (bf16*)a.out;
     const bf16* res = (const bf16*)a.res;
+    const bool res_pref = a.res_mode == PMOE_RES_ADD && a.prefetch;      // (a.prefetch: launcher, PMOE_RES_PREFETCH=0 = A/B)
 
     if (ntile > 0) issue_patch(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // filter bank + first patch
@@ -395,6 +396,23 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntile) issue_patch(t + 1, buf ^ 1);  // its buffer was released by the barrier that ended tile t-1
+        // residual add (a data gradient accumulating into the gradient another consumer left): the four 16-byte pieces this thread
+        // will add in the read-out are requested NOW and arrive under the MFMAs -- loaded in the epilogue they cost +50 % on the
+        // layer1 launches (0.31 -> 0.47 ms), every wave waiting on its own global loads between two barriers
+        v4i rpre[4];
+        if (res_pref) {
+            int n0, oy0, ox0;
+            tile_geo(t, n0, oy0, ox0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = pr + 64 * u;
+                const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+                const int nn = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
+                rpre[u] = v4i{0, 0, 0, 0};
+                if (cvalid && nn < a.ipe && oy < a.Ho && ox < a.Wo)
+                    rpre[u] = ldg16(res + ((((size_t)e * a.ipe + nn) * a.Ho + oy) * a.Wo + ox) * a.res_ld + a.res_coff + cc * VE);
+            }
+        }
         const char* patch = pbuf + buf * pbuf_bytes;
         f32x16 acc[2];
         if (BIAS) {
@@ -465,7 +483,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
                 if (a.res_mode == PMOE_RES_ADD) {
                     float v[VE], rv[VE];
                     unpack16<bf16>(raw, v);
-                    unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cc * VE), rv);
+                    unpack16<bf16>(res_pref ? rpre[u] : ldg16(res + opix * a.res_ld + a.res_coff + cc * VE), rv);
 #pragma unroll
                     for (int i = 0; i < VE; ++i) v[i] += rv[i];
                     pk = pack16<bf16>(v);
@@ -578,6 +596,8 @@ int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
     int pb = 0, mpw = 0, mph = 0;
     size_t sm = 0;
     if (conv_res_dma_ok(a, p, &pb, &mpw, &mph, &sm)) {
+        const char* evp = getenv("PMOE_RES_PREFETCH");
+        a.prefetch = !(evp && !atoi(evp));
         if (a.bias) {
             HIP_RET((ensure_dyn_lds<conv3x3_resdma_kernel<true>>(163840)));
             hipLaunchKernelGGL(conv3x3_resdma_kernel<true>, grid, block, sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb, mpw, mph);
