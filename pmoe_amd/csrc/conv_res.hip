@@ -11,6 +11,8 @@
 // and commits the halo patch of tile t+1 whose global loads it issued one full tile earlier
 // (issue early / write late).  Then the roles swap.  Three workgroup barriers per tile, no weight
 // traffic, no prologue / epilogue bubble: the MFMA pipe of each SIMD always has one wave feeding it.
+// (Since round 2 the 64 -> 64 layers run on conv3x3_resdma_kernel further down -- all 8 waves compute, halo patches by LDS-DMA,
+// +16-25 % -- and the 16-channel stem convolution on conv_c16.hip; this kernel serves what those two decline and their A/B switches.)
 #include "conv_common.h"
 #include <stdlib.h>
 #include "kernels.h"
