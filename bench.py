@@ -408,6 +408,8 @@ def main():
             if code >= 2000:
                 return (f"conv_igemm_lite_kernel<{kdt},{code - 2000}>" + (" (4 parity-class launches per stride-2 dgrad)" if four else ""),
                         f"_Z22conv_igemm_lite_kernelI{tname}Li{code - 2000}E{tname}Ev8ConvArgs", 4 if four else 1)
+            if code in (1402, 1404):              # 1x1 convolutions over many pixels, direct form (conv_c1x1.hip)
+                return f"conv1x1_direct_kernel<{code - 1400}>", f"void (anonymous namespace)::conv1x1_direct_kernel<{code - 1400}>", 1
             if code == 1316:                      # 16-channel stem convolution, direct form (conv_c16.hip)
                 return "conv3x3_c16_kernel", "void (anonymous namespace)::conv3x3_c16_kernel", 1
             if code >= 1100:                      # filter bank resident in LDS, halo patches by LDS-DMA (conv_res.hip)

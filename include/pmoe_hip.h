@@ -88,6 +88,7 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
  * to attribute measured launch times to kernel symbols that a rocprofv3 kernel trace shows):
  *   3000                     gemm_skinny_kernel<4|8>               (expert MLP layers / <= 2048 output pixels per expert, bf16)
  *   1000 + LOG_RB            conv3x3_res_kernel<LOG_RB>            (resident-filter kernel, conv_res.hip)
+ *   1400 + MT                conv1x1_direct_kernel<MT>             (1x1, stride 1 | 2, >= 8192 pixels per expert, 64..512 input channels, conv_c1x1.hip)
  *   1316                     conv3x3_c16_kernel                    (16 input channels: direct MFMA form, no LDS staging, conv_c16.hip)
  *   1107                     conv3x3_resdma_kernel                 (resident filter bank, halo patches by LDS-DMA, conv_res.hip)
  *   2000 + LOG_RB            conv_igemm_lite_kernel<T, LOG_RB>     (8-wave 256 x 128 tile, two workgroups per CU)

@@ -530,6 +530,8 @@ bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan);
 bool conv_res_dma_ok(const ConvArgs& a, const ResPlan& p, int* pbuf, int* magic_pw, int* magic_ph, size_t* smem);
 bool conv_c16_plan(const ConvArgs& a, int dtype, int* wgs_per_expert, int* tiles_x, int* tiles_per_expert);
 int conv_c16_launch(const ConvArgs& a, hipStream_t st);
+bool conv_c1x1_plan(const ConvArgs& a, int dtype, int* wgs_per_expert, int* tiles_per_expert, int* n_slabs, int* mt, size_t* smem);
+int conv_c1x1_launch(const ConvArgs& a, hipStream_t st);
 int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st);
 
 // stride-2 3x3 data gradient (forward pad 1) by output parity class instead of a zero-dilated source: dx[2a+py][2b+px]
@@ -581,8 +583,10 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
         return launch_stride2_1x1_inplace(a, dtype, st);
     if (gemm_skinny_ok(a, dtype)) return gemm_skinny_launch(a, st);
     {
-        int wpe, tx, tpe;
+        int wpe, tx, tpe, slabs, mt;
+        size_t sm;
         if (conv_c16_plan(a, dtype, &wpe, &tx, &tpe)) return conv_c16_launch(a, st);
+        if (conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &sm)) return conv_c1x1_launch(a, st);
     }
     ResPlan plan;
     if (conv_res_plan(a, dtype, &plan)) return conv_res_launch(a, plan, st);
@@ -598,7 +602,7 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
 }
 
 // which kernel a descriptor runs on (no launch): 3000 = gemm_skinny_kernel; 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; 1107 =
-// conv3x3_resdma_kernel; 1316 = conv3x3_c16_kernel; 5007 = conv3x3_dma_kernel; 2000 + LOG_RB =
+// conv3x3_resdma_kernel; 1316 = conv3x3_c16_kernel; 1400 + MT = conv1x1_direct_kernel<MT>; 5007 = conv3x3_dma_kernel; 2000 + LOG_RB =
 // conv_igemm_lite_kernel<T, LOG_RB>; LOG_RB*100 + WM*10 + WN = conv_igemm_kernel<T, LOG_RB, WM, WN>; + 4000 = the four
 // parity-class launches of a stride-2 data gradient
 int conv_igemm_plan(const ConvArgs& a, int dtype) {
@@ -616,8 +620,10 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         if (c.Ho <= 0 || c.Wo <= 0) return PMOE_ERR_ARG;
         extra = 4000;
     } else {
-        int wpe, tx, tpe;
+        int wpe, tx, tpe, slabs, mt;
+        size_t smx;
         if (conv_c16_plan(a, dtype, &wpe, &tx, &tpe)) return 1316;             // conv3x3_c16_kernel
+        if (conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &smx)) return 1400 + mt;   // conv1x1_direct_kernel<MT>
         ResPlan plan;
         if (conv_res_plan(a, dtype, &plan)) {
             int pb, mpw, mph;
@@ -645,6 +651,9 @@ int conv_igemm_mblocks(const ConvArgs& a, int dtype) {
         int wpe, tx, tpe;
         // (a launch that asks for statistics never takes the skinny kernel: no gemm_skinny_ok test here, as for the resident kernel)
         if (conv_c16_plan(a, dtype, &wpe, &tx, &tpe)) return (a.N / a.ipe) * wpe;
+        int slabs, mt;
+        size_t smx;
+        if (conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &smx)) return (a.N / a.ipe) * wpe;
     }
     ResPlan plan;
     if (conv_res_plan(a, dtype, &plan)) return (a.N / a.ipe) * plan.wgs_per_expert;

@@ -81,7 +81,8 @@ def test_conv_plan_reports_the_kernel_instantiation():
     assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1107                 # conv3x3_resdma_kernel (filter bank resident, LDS-DMA patches)
     assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1316                 # 12(16)-channel stem: conv3x3_c16_kernel (direct form)
     assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 5007                # conv3x3_dma_kernel (LDS-DMA staged, conv_dma.hip)
-    assert plan(128, 256, 64, 1, 2, torch.bfloat16) == 2007                # 1x1 stride 2: conv_igemm_lite_kernel<bf16,7>, 2 workgroups / CU
+    assert plan(128, 256, 64, 1, 2, torch.bfloat16) == 1404                # 1x1 stride 2 (downsample): conv1x1_direct_kernel<4>
+    assert plan(256, 512, 32, 1, 2, torch.bfloat16) == 1402                # ... 64-channel slabs from 256 input channels
     assert plan(256, 256, 32, 3, 1, torch.float32) == 722                  # f32: 4-wave 128x128 tile, 32-channel chunks
     assert plan(1536, 512, 1, 1, 1, torch.bfloat16) == 3000                # expert MLP GEMM: gemm_skinny_kernel
     assert plan(1536, 512, 1, 1, 1, torch.float32) == 722                  # ... in f32: generic 4-wave tile

@@ -174,7 +174,7 @@ BASELINE_CONV_CASES = [
     ((1, 1, 64, 64, 256, 256, 3, 1), (1107, 1107, 256)),       # stem conv2: conv3x3_resdma_kernel, 256 tiles of one image
     ((2, 2, 64, 64, 128, 128, 3, 1), (1107, 1107, 256)),       # layer1: resident kernel, persistent workgroups per expert
     ((1, 4, 64, 128, 128, 128, 3, 2), (642, 4741, 256)),       # layer2.0.conv1: stride-2 forward, parity-class data gradient
-    ((1, 4, 64, 128, 128, 128, 1, 2), (2007, 741, 128)),       # layer2.0.downsample (1x1: LITE tile over the used pixels)
+    ((1, 4, 64, 128, 128, 128, 1, 2), (1404, 741, 128)),       # layer2.0.downsample (1x1 stride 2: conv1x1_direct_kernel<4>)
     ((1, 1, 12, 64, 256, 256, 3, 1), (1316, 1107, 256)),       # stem conv1 (12 -> 16 input channels): direct-form conv3x3_c16_kernel
     ((2, 3, 12, 64, 40, 40, 3, 1), (1316, None, None)),        # ... ragged: 40-wide rows = one full + one 8-pixel tile, 2 experts x 3 images
     ((1, 2, 9, 48, 33, 96, 3, 1), (1316, None, None)),         # ... 9 input / 48 output channels (zero-padded filter rows, masked stores)
@@ -928,3 +928,47 @@ def test_conv_c16_channel_windows():
     ops.conv2d(xw, wf, ow, in_coff=16, out_coff=64, **kw)
     assert torch.equal(ow[..., 64:128], dense)
     assert (ow[..., :64] == 7.0).all() and (ow[..., 128:] == 7.0).all()
+
+
+@pytest.mark.parametrize("case", [
+    # E, ipe, cin, cout, H, W, stride, bias, expected plan
+    (2, 3, 64, 120, 130, 130, 2, True, 1404),      # ragged: 65x65 outputs (last tile partial), 120 of 128 channels, bias
+    (1, 2, 128, 256, 96, 96, 1, False, 1404),      # two 128-channel slabs
+    (2, 2, 256, 512, 72, 72, 1, True, 1402),       # 64-channel slabs (8 of them), two k chunks
+    (1, 2, 192, 64, 160, 160, 2, False, 1402),     # K not a multiple of the 128-channel chunk
+])
+def test_conv1x1_direct_kernel(case):
+    """conv1x1_direct_kernel (downsample projections, transposed-convolution GEMMs) against F.conv2d per expert: outputs,
+    bias added before the rounding, fused BatchNorm partial sums, untouched channels beyond cout."""
+    E, ipe, cin, cout, H, W, stride, with_bias, code = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(17)
+    N = E * ipe
+    x = rnd((N, cin, H, W), g, dtype)
+    ws = [rnd((cout, cin, 1, 1), g, dtype, 0.1) for _ in range(E)]
+    bs = [rnd((cout,), g, torch.float32, 0.5) for _ in range(E)]
+    coutp = (cout + 127) // 128 * 128 if code == 1404 else r64(cout)
+    wf = torch.zeros(E, coutp, 1, cin, dtype=dtype, device=DEV)
+    for e in range(E):
+        wf[e, :cout, 0] = ws[e][:, :, 0, 0].to(dtype).to(DEV)
+    bias = None
+    if with_bias:
+        bias = torch.zeros(E, coutp, device=DEV)
+        for e in range(E):
+            bias[e, :cout] = bs[e].to(DEV)
+    xd = nhwc(x, cin, dtype)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.full((N, Ho, Wo, coutp), 7.0, dtype=dtype, device=DEV)
+    kw = dict(cin=cin, cout=cout, coutp=coutp, ipe=ipe, ks=1, stride=stride, pad=0, bias=bias)
+    assert ops.conv2d(xd, wf, out, plan_only=True, **kw) == code
+    rows = ops.conv2d_stat_rows(N, H, W, Ho, Wo, cin, cout, coutp, ipe, 1, stride, 0, dtype, in_ld=cin, out_ld=coutp)
+    stats = torch.zeros(rows, 2, coutp, device=DEV)
+    ops.conv2d(xd, wf, out, stats=stats, **kw)
+    ref = torch.cat([F.conv2d(x[e * ipe:(e + 1) * ipe], ws[e], bs[e] if with_bias else None, stride=stride) for e in range(E)])
+    close(from_nhwc(out, cout), ref, dtype, "1x1 direct")
+    if coutp > cout:
+        assert (out[..., cout:] == 7.0).all()
+    st = stats.view(E, rows // E, 2, coutp).sum(1).cpu()
+    yo = out.float().cpu()[..., :cout].reshape(E, -1, cout)
+    close(st[:, 0, :cout], yo.sum(1), dtype, "1x1 direct stats sum")
+    close(st[:, 1, :cout], (yo * yo).sum(1), dtype, "1x1 direct stats sumsq")
