@@ -39,13 +39,13 @@ def main():
         n = max(fn, wn, 1)
         f2, w = fb * 1024 * 2 / n, wb * 1024 / n           # KiB units; gfx950: FETCH_SIZE counts half of the bytes
         per[name] = {"launches": n, "fetch_bytes_per_launch_x2": f2, "write_bytes_per_launch": w}
-        if "conv_igemm" in name or "conv3x3_" in name:
+        if "conv_igemm" in name or "conv3x3_" in name or "conv1x1_" in name:
             conv_b += (f2 + w) * n
             conv_n += n
     total = sum((v["fetch_bytes_per_launch_x2"] + v["write_bytes_per_launch"]) * v["launches"] for v in per.values())
     by_group = defaultdict(float)
     for k, v in per.items():
-        grp = ("conv fwd/dgrad" if ("conv_igemm" in k or "conv3x3" in k or "gemm_skinny" in k) else "conv wgrad" if "wgrad" in k
+        grp = ("conv fwd/dgrad" if ("conv_igemm" in k or "conv3x3" in k or "conv1x1" in k or "gemm_skinny" in k) else "conv wgrad" if "wgrad" in k
                else "batchnorm" if ("bn_" in k or "colstats" in k or "reduce_partials" in k) else "stem tail" if "stem_tail" in k
                else "other")
         by_group[grp] += (v["fetch_bytes_per_launch_x2"] + v["write_bytes_per_launch"]) * v["launches"]
