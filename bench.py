@@ -155,9 +155,9 @@ def sub_configs(dev, args):
         per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
         return ev[0].elapsed_time(ev[n]) / n, per[n // 2]
 
-    def moe_case(experts, batch, fp8):
+    def moe_case(experts, batch, fp8, dtype=torch.bfloat16):
         model = get_model(stage2_model_cfg("moe", experts, dropout=args.dropout)).to(dev)
-        model.compute_dtype = torch.bfloat16
+        model.compute_dtype = dtype
         model.fp8_weights = fp8
         model.train()
         images, speed, command, control, target = make_batch(batch, args.size, 99, dev)
@@ -177,6 +177,11 @@ def sub_configs(dev, args):
                               "the fp8 matrix cores for the layer1-4 forward convolutions (bf16 stem / backward)")
     gc.collect(); torch.cuda.empty_cache()
     out["C2_bf16_b128"] = dict(moe_case(args.experts, 128, False), what="same shape as C5 in plain bf16 (the A/B partner)")
+    gc.collect(); torch.cuda.empty_cache()
+    out["C2_f32_b16"] = dict(moe_case(args.experts, 16, False, torch.float32), what="4-expert MoE, batch 16, exact-f32 path "
+                             "(v_mfma_f32_32x32x2_f32, f32 activations): the path the 1e-4 parity claims rest on; its roof is "
+                             "the 157.3 TFLOP/s f32 matrix rate")
+    out["C2_f32_b16"]["frac_of_f32_mfma_peak"] = round(out["C2_f32_b16"]["tflops_algorithmic"] / 157.3, 4)
     gc.collect(); torch.cuda.empty_cache()
     # C4: PUNetExpert (the constructor reads checkpoint files in the reference's layouts: write random-init ones)
     from tests.punet_util import build_product
@@ -232,15 +237,39 @@ def stage1_step(dev, batch=10, size=224, frames=6, steps=3):
                     f"{size}x{size} T=4 F={frames} bf16 (conf/stage_1.yaml)"}
 
 
+def self_launch(args):
+    """--gpus N > 1 without a launcher: run this script under torch.distributed.run (one rank per GPU, RCCL) as a child
+    process and relay it.  PMOE_BENCH_SHARE_GPU=1 (rehearsal: every rank on device 0 over gloo) lifts the device check."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("PMOE_BENCH_SHARE_GPU") != "1":
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, this node shows {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` launches itself: one rank per GPU as a FRESH child job, started before this process
+        # has made any GPU call (torch is imported, nothing else: device_count() does not initialise the runtime), the
+        # child's output relayed, its exit code returned.  Never an exec of a process that holds the GPU.
+        raise SystemExit(self_launch(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus {args.gpus} does it)")
     # rehearsal of the N-rank control flow on a ONE-GPU box: PMOE_BENCH_SHARE_GPU=1 puts every rank on device 0 and
     # uses gloo (RCCL refuses two ranks on one device); the real multi-GPU run is one rank per GPU over RCCL
     share = os.environ.get("PMOE_BENCH_SHARE_GPU") == "1"
@@ -331,9 +360,13 @@ def main():
         "loss": round(float(loss.item()), 5),
     }
 
+    if use_dist:
+        devs = [None] * world
+        dist.all_gather_object(devs, int(local))
     if use_dist and rank == 0:
         from pmoe_amd import parallel as _par
-        out["dp"] = {"backend": dist.get_backend(), "world": world,
+        out["dp"] = {"backend": dist.get_backend(), "world": world, "rccl_ranks": dist.get_world_size(),
+                     "rank_devices": devs, "collective": _par.BucketedAllReduce.last_mode,
                      "buckets_issued_per_backward": _par.BucketedAllReduce.last_issued}
     if rank == 0:
         # ---- whole-step rooflines from the algorithmic work model
@@ -447,6 +480,9 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "rocprof_name": mangled,
                                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic,
+                               "traffic_source": ("profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc "
+                                                  "passes over this command (tools/collect_traffic.py), NOT counted in this run")
+                               if traffic is not None else None,
                                "launches_per_step": dom["launches"],
                                "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                                "flop_per_launch": dom["flop"] / dom["launches"],

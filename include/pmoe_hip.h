@@ -42,6 +42,11 @@ extern "C" {
 #define PMOE_RES_DTANH 4   /* out = acc * (1 - res^2)                                                  */
 #define PMOE_RES_DSIGMOID 5 /* out = acc * res (1 - res)                                               */
 
+/* ABI revision of this header: bumped whenever a descriptor struct, an argument list or a buffer contract changes
+ * (100: round 1; 200: round 2 -- pmoe_conv_desc 160 -> 176 bytes, pmoe_wgrad_desc.part_ws, pmoe_bn_bwd_reduce's gmask_out,
+ * dw_ws overwritten instead of accumulated; 300: round 3).  A binding compares pmoe_version() with the value it was
+ * written against before its first launch (pmoe_amd/hip.py:load does). */
+#define PMOE_ABI_VERSION 300
 int pmoe_version(void);
 const char* pmoe_error_string(int code);
 /* sizeof() of the descriptor structs as compiled (which: 0 = pmoe_conv_desc, 1 = pmoe_wgrad_desc);

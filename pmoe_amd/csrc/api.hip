@@ -38,7 +38,7 @@ static int check_conv(const pmoe_conv_desc* d) {
 
 extern "C" {
 
-int pmoe_version(void) { return 100; }
+int pmoe_version(void) { return PMOE_ABI_VERSION; }
 
 int pmoe_abi_sizeof(int which) {
     return which == 0 ? (int)sizeof(pmoe_conv_desc) : which == 1 ? (int)sizeof(pmoe_wgrad_desc)

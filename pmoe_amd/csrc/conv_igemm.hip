@@ -661,7 +661,9 @@ int conv_igemm_mblocks(const ConvArgs& a, int dtype) {
         ConvArgs d = a;
         int mbd, pb;
         size_t sm;
-        if (!gemm_skinny_ok(a, dtype) && conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return mbd;
+        // (no gemm_skinny_ok test: this function sizes the STATISTICS rows, and a launch that asks for statistics never takes
+        //  the skinny kernel -- plan and launch must see the same predicate)
+        if (conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return mbd;
     }
     int mb = 0;
     int rc = (dtype == PMOE_DT_BF16) ? launch_dtype<bf16>(a, nullptr, &mb) : launch_dtype<float>(a, nullptr, &mb);

@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
     const bool res_pref = a.res_mode == PMOE_RES_ADD && a.prefetch;      // (a.prefetch: launcher, PMOE_RES_PREFETCH=0 = A/B)
 
     if (ntile > 0) issue_patch(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // filter bank + first patch
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // filter bank + first patch (DMA), the bias row (ds_write)
     __builtin_amdgcn_s_barrier();
 
     for (int t = 0; t < ntile; ++t) {

@@ -84,9 +84,11 @@ class GroupedConv:
             self.w_f8 = torch.empty(E, self.coutp, self.taps, self.cinp, dtype=torch.uint8, device=dev)
             self.wscale = torch.empty(E, self.coutp, dtype=F32, device=dev)
             self.oscale = torch.empty(E, self.coutp, dtype=F32, device=dev)
+            self.w_fwd = None        # an fp8 layer's forward operand is w_f8: no (never packed) bf16 copy of the bank
         else:
             self.w_f8 = self.wscale = self.oscale = None
-        self.w_fwd = torch.empty(E, self.coutp, self.taps, self.cinp, dtype=dtype, device=dev)
+            self.w_fwd = torch.empty(E, self.coutp, self.taps, self.cinp, dtype=dtype, device=dev)
+        self._alloc_key = (dtype, dev, self.w_f8 is not None)
         self.w_dg = torch.empty(E, self.dg_rows, self.taps, self.dg_red, dtype=dtype, device=dev) if self.need_dgrad else None
         if self.biases is not None:
             self.bias_packed = torch.empty(E, self.coutp, dtype=F32, device=dev)
@@ -302,8 +304,7 @@ class ExpertGroupEngine:
         if self._built_for == key:
             return
         for layer in self.all_convs + ([self.head] if getattr(self.head, "parts", None) else []):
-            if (layer.w_fwd is None or layer.w_fwd.dtype != dtype or layer.w_fwd.device != dev
-                    or (layer.w_f8 is not None) != (layer.fp8 and dtype == torch.bfloat16)):
+            if getattr(layer, "_alloc_key", None) != (dtype, dev, bool(layer.fp8 and dtype == torch.bfloat16)):
                 layer.alloc(dtype, dev)
         self._ptr_key = None
         self._packed_version = None
@@ -390,7 +391,9 @@ class ExpertGroupEngine:
         else:
             o = out.window(out_coff, layer.cout_st)
         stats = None
-        f8 = layer.w_f8 is not None and bias is False and act == hip.ACT_NONE
+        f8 = layer.w_f8 is not None
+        if f8 and (bias is not False or act != hip.ACT_NONE):
+            raise RuntimeError(f"{layer.name}: an fp8-policy layer has only its e4m3 forward operand (bias-free, no activation)")
         if want_stats:
             rows = ops.conv2d_stat_rows(self.N, H, W, Ho, Wo, layer.cinp, layer.cout_st, layer.coutp, self.B, layer.ks,
                                         layer.stride, layer.pad, self.dtype, w_fp8=f8, in_ld=x.t.shape[-1],
@@ -902,7 +905,32 @@ class ExpertGroupEngine:
             self._slots[key] = (off, n, plist)
             self._order.append(key)
             off += n
-        self._arena_numel = off
+        self._arena_used = off
+        # padded so that every bucket boundary (multiples of 256 elements) divides by any world size up to 256: the
+        # reduce-scatter / all-gather buckets of pmoe_amd.parallel need length % world == 0
+        self._arena_numel = (off + 255) // 256 * 256
+
+    def _bucket_cuts(self, n_buckets):
+        """Bucket END offsets of the data-parallel exchange, by backward TIME rather than bytes.  The arena is in backward
+        order (heads, layer4, ..., layer1, stem): the bytes sit at its head (layer4 holds 60 % of an expert's parameters)
+        while the time sits at its tail (stem + layer1: ~45 % of backward for < 2 % of the parameters).  The last bucket
+        completes only when backward ends and is therefore never hidden, so it holds just that tail; the buckets before it
+        split the rest evenly by bytes."""
+        tail = None
+        for key in self._order:
+            layer = next((l for k, l, _ in self.params if self._key(k, l) == key), None)
+            name = getattr(layer[0] if isinstance(layer, tuple) else layer, "name", "")
+            if name.startswith("layer1.") or name.startswith("stem.") or name in ("bn1", "eca1", "eca2"):
+                tail = self._slots[key][0]
+                break
+        n = self._arena_numel
+        if tail is None or tail <= 0 or n_buckets < 2:
+            b = (n + n_buckets - 1) // n_buckets
+            return [min(n, (i + 1) * ((b + 255) // 256 * 256)) for i in range(n_buckets)]
+        tail = tail // 256 * 256
+        b = (tail + n_buckets - 2) // (n_buckets - 1)
+        b = (b + 255) // 256 * 256
+        return [min(tail, (i + 1) * b) for i in range(n_buckets - 1)] + [n]
 
     def _grad_slot(self, kind, layer):
         key = self._key(kind, layer)
@@ -1162,7 +1190,7 @@ class ExpertGroupEngine:
         reducer = None
         if self.dp_group is not None or (dist.is_initialized() and self.dp_enabled):
             reducer = BucketedAllReduce(self.dp_group, self.dp_buckets, self.dp_always)
-            reducer.begin(self._arena)
+            reducer.begin(self._arena, self._bucket_cuts(self.dp_buckets))
         self._tail_bwd(tape_state["tail"], *douts)
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else None

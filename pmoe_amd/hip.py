@@ -15,6 +15,7 @@ import torch
 _LIB_PATH = Path(os.environ.get("PMOE_HIP_LIB") or Path(__file__).resolve().parent / "libpmoe_hip.so")
 _lib = None
 
+ABI_VERSION = 300            # include/pmoe_hip.h: PMOE_ABI_VERSION
 DT_BF16, DT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_DRELU, RES_DELU, RES_DTANH, RES_DSIGMOID = 0, 1, 2, 3, 4, 5
@@ -208,6 +209,12 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
+    # the binding above was written against ONE revision of include/pmoe_hip.h: a library of another revision would take
+    # misaligned arguments silently (descriptor sizes are checked too, tests/test_abi.py)
+    if lib.pmoe_version() != ABI_VERSION:
+        raise HipUnavailable(f"{_LIB_PATH}: ABI revision {lib.pmoe_version()}, this binding expects {ABI_VERSION}: rebuild with ./build.sh")
+    if lib.pmoe_abi_sizeof(0) != C.sizeof(ConvDesc) or lib.pmoe_abi_sizeof(1) != C.sizeof(WgradDesc):
+        raise HipUnavailable(f"{_LIB_PATH}: descriptor layouts differ from pmoe_amd/hip.py (pmoe_abi_sizeof): rebuild with ./build.sh")
     _lib = lib
     return lib
 

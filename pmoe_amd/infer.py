@@ -3,13 +3,25 @@
 At B=1 the eval-mode forward is ~150 small launches and the tick time is launch latency, not kernel time.  The engine
 allocates only through torch's caching allocator and (in eval mode) never synchronises with the host, so the whole
 chain can be captured ONCE into a HIP graph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm) and replayed per tick with
-new inputs copied into the captured input buffers.  Parameters are read through the captured packed-weight buffers:
-call :meth:`GraphedMixture.refresh` after loading new weights.
+new inputs copied into the captured input buffers.  Parameters are read through the captured packed-weight buffers; every
+replay first compares the engine's build / pointer-table / version keys with those taken at capture and re-captures
+(:meth:`GraphedMixture.refresh`) when a weight, a BatchNorm buffer, the compute dtype or the device has changed since.
 """
 import torch
 
 from . import hip
 from .model.moe import MixtureDistribution
+
+
+def _plan_key(model):
+    """Everything a captured / recorded chain holds raw pointers into, beyond its private activation pool: the engine's
+    packed weight banks and pointer tables (rebuilt when the compute dtype, the fp8 switch or the device changes, or when a
+    parameter's storage moves), their contents (parameter versions) and the eval-mode BatchNorm folds (buffer versions).
+    A replay whose key differs from the one taken at capture would read freed or stale memory."""
+    eng = model._engine()
+    bufs = [b for l in eng.all_bns for m in l.mods for b in (m.running_mean, m.running_var)]
+    return (eng._built_for, eng._ptr_key, eng._packed_version, sum(p._version for p in eng.flat_params),
+            sum(b._version for b in bufs), tuple(b.data_ptr() for b in bufs[:4]))
 
 
 class GraphedMixture:
@@ -36,12 +48,15 @@ class GraphedMixture:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.static_out = model.mixture_params(*self.static_in)
+        self.key = _plan_key(model)
 
     def __call__(self, images, speed, command):
         for dst, src in zip(self.static_in, (images, speed, command)):
             if dst.shape != src.shape:
                 raise ValueError(f"GraphedMixture was captured for input shape {tuple(dst.shape)}, got {tuple(src.shape)}")
             dst.copy_(src)
+        if _plan_key(self.model) != self.key:            # weights / buffers / dtype / device changed since the capture
+            self.refresh()
         self.graph.replay()
         return self.static_out
 
@@ -78,12 +93,15 @@ class PlannedMixture:
             with torch.cuda.use_mem_pool(self.pool), hip.LaunchRecorder() as plan:
                 self.static_out = model.mixture_params(*self.static_in)
         self.plan = plan
+        self.key = _plan_key(model)
 
     def __call__(self, images, speed, command):
         for dst, src in zip(self.static_in, (images, speed, command)):
             if dst.shape != src.shape:
                 raise ValueError(f"PlannedMixture was recorded for input shape {tuple(dst.shape)}, got {tuple(src.shape)}")
             dst.copy_(src)
+        if _plan_key(self.model) != self.key:            # an eager call in between re-packed or re-allocated what the plan points to
+            self.refresh()
         self.plan.replay()
         return self.static_out
 

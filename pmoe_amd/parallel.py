@@ -18,21 +18,73 @@ import torch.distributed as dist
 
 
 class BucketedAllReduce:
-    last_issued = 0          # collectives launched by the most recent backward of this process (bench.py / tests report it)
+    """Mean of the gradient arena over the data-parallel group, bucket by bucket, launched from inside backward.
 
-    def __init__(self, group=None, n_buckets=6, always=False):
+    mode "rs_ag" (default when the group has more than one rank): every bucket is a reduce-scatter into the rank's own
+    1/world slice followed by an all-gather of the slices, both IN PLACE on the arena.  On the xGMI mesh (7 point-to-point
+    links per GPU) both halves run over all links at once -- each rank exchanges 1/world of the bucket with every peer --
+    where one ring all-reduce is bound by a single link (443 MB at E=8, ~5 ms on a ring vs ~0.7 ms
+    over the mesh).  mode "ring": one `all_reduce` per bucket (the round-1/2 path; PMOE_DP_COLLECTIVE=ring).
+    Buckets whose length is not a multiple of the world size (an unpadded tail) fall back to `all_reduce`.
+
+    `cuts`: bucket END offsets chosen by the engine (backward TIME, not bytes: the last bucket -- whatever finishes when
+    backward ends and therefore cannot be hidden -- is kept small); default: n_buckets equal slices."""
+    last_issued = 0          # collectives launched by the most recent backward of this process (bench.py / tests report it)
+    last_mode = None
+
+    def __init__(self, group=None, n_buckets=6, always=False, mode=None):
+        import os
         self.group = group
         self.n_buckets = max(1, int(n_buckets))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.single = self.world == 1 and not (always and dist.is_initialized())    # nothing to exchange
-        self._avg_native = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.mode = mode or os.environ.get("PMOE_DP_COLLECTIVE", "rs_ag")
+        if self.mode not in ("rs_ag", "ring"):
+            raise ValueError(f"PMOE_DP_COLLECTIVE: 'rs_ag' or 'ring', got {self.mode!r}")
 
-    def begin(self, arena):
+    def begin(self, arena, cuts=None):
         self.arena = arena
         n = arena.numel()
-        self.bucket = (n + self.n_buckets - 1) // self.n_buckets
+        if cuts is None:
+            b = (n + self.n_buckets - 1) // self.n_buckets
+            cuts = [min(n, (i + 1) * b) for i in range(self.n_buckets)]
+        cuts = sorted({int(c) for c in cuts if 0 < c < n} | {n})
+        self.cuts = cuts
+        self.next = 0            # index of the first bucket not yet launched
         self.sent = 0
         self.works = []
+
+    def _launch(self, lo, hi):
+        chunk = self.arena[lo:hi]
+        n, w = hi - lo, self.world
+        # (gloo moves device tensors through host staging and implements only part of the collectives for them: the
+        #  two-ranks-on-one-GPU rehearsal keeps the plain all-reduce)
+        if self.mode == "rs_ag" and n % w == 0 and n > 0 and (self._nccl or not chunk.is_cuda):
+            per = n // w
+            mine = chunk[self.rank * per:(self.rank + 1) * per]
+            if self._nccl:
+                # in place: the output is the rank's own slice of the input (NCCL/RCCL's in-place reduce-scatter layout)
+                w1 = dist.reduce_scatter_tensor(mine, chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                w2 = dist.all_gather_into_tensor(chunk, mine, group=self.group, async_op=True)
+                self.works += [(w1, None), (w2, None)]
+            else:
+                # gloo has no reduce-scatter: one reduce per slice to its owner, then the same all-gather (CPU tests and
+                # the shared-GPU rehearsal run the slice arithmetic of the RCCL path)
+                for r in range(w):
+                    dist.reduce(chunk[r * per:(r + 1) * per], dst=dist.get_global_rank(self.group, r) if self.group else r,
+                                op=dist.ReduceOp.SUM, group=self.group)
+                mine.mul_(1.0 / w)
+                wk = dist.all_gather_into_tensor(chunk, mine.clone(), group=self.group, async_op=True)
+                self.works.append((wk, None))
+            return
+        if self._nccl:
+            wk = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            self.works.append((wk, None))
+        else:
+            wk = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.works.append((wk, chunk))
 
     def ready(self, upto, final=False):
         """Elements [0, upto) of the arena are final: every kernel that writes them is enqueued on the CURRENT stream or on
@@ -42,27 +94,24 @@ class BucketedAllReduce:
         if self.single:
             return
         n = self.arena.numel()
-        limit = n if final else (min(upto, n) // self.bucket) * self.bucket
-        while self.sent < limit:
-            hi = min(n, self.sent + self.bucket)
-            chunk = self.arena[self.sent:hi]
-            if self._avg_native:
-                w = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            else:
-                w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.works.append((w, chunk))
+        upto = n if final else min(upto, n)
+        while self.next < len(self.cuts) and self.cuts[self.next] <= upto:
+            hi = self.cuts[self.next]
+            self._launch(self.sent, hi)
             self.sent = hi
+            self.next += 1
 
     def finish(self):
         """Flush the tail and make the current stream wait for every bucket."""
         if self.single:
             return
         self.ready(self.arena.numel(), final=True)
-        for w, chunk in self.works:
+        for w, scale_chunk in self.works:
             w.wait()
-            if not self._avg_native:
-                chunk.mul_(1.0 / self.world)
-        BucketedAllReduce.last_issued = len(self.works)
+            if scale_chunk is not None:
+                scale_chunk.mul_(1.0 / self.world)
+        BucketedAllReduce.last_issued = self.next          # buckets (an "rs_ag" bucket is two collectives)
+        BucketedAllReduce.last_mode = self.mode
         self.works = []
 
 

@@ -122,3 +122,26 @@ def test_rccl_branch_runs_on_one_gpu():
     assert out["allreduce_model"]["gradient_bytes"] == 4 * 55373360          # E=4 MixtureOfExperts
     # the collectives really ran: bench logs the backend and the bucket count it issued
     assert out.get("dp", {}).get("backend") == "nccl" and out["dp"]["buckets_issued_per_backward"] == 6, out.get("dp")
+
+
+def test_bench_launches_itself(tmp_path):
+    """`python bench.py --gpus N` (no launcher, the way the driver invokes `--gpus 1`) starts its own
+    one-rank-per-GPU job as a child BEFORE touching the GPU and relays rank 0's line.  Rehearsed with two ranks sharing this
+    box's GPU over gloo (PMOE_BENCH_SHARE_GPU=1); without that switch the same command must refuse with the device count."""
+    import json
+    import subprocess
+    import sys
+    repo = Path(__file__).resolve().parents[1]
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--size", "64",
+            "--no-cpu-baseline", "--no-stage1", "--no-sub-configs", "--no-kernel-profile"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(args, cwd=repo, env=dict(base, PMOE_BENCH_SHARE_GPU="0"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "needs 2 devices" in r.stderr, r.stderr[-2000:]
+    r = subprocess.run(args, cwd=repo, env=dict(base, PMOE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["dp"]["rccl_ranks"] == 2 and out["dp"]["rank_devices"] == [0, 0] and out["dp"]["backend"] == "gloo"
+    assert out["dp"]["buckets_issued_per_backward"] == 6

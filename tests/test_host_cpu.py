@@ -127,3 +127,41 @@ def test_stage1_entry_points_have_no_cpu_path(tmp_path):
         AutoregressiveCriterion(1, "dice")
     m2 = copy.deepcopy(m)
     assert list(m2.state_dict().keys()) == list(m.state_dict().keys()) and "_eng" not in m2.__dict__
+
+
+def test_dp_bucket_cuts_follow_backward_time():
+    """pmoe_amd.engine._bucket_cuts: the arena is in backward order; the LAST bucket (never hidden: it completes when
+    backward ends) holds only stem + layer1, the others split the parameter-heavy head of the arena evenly; every cut is a
+    multiple of 256 elements so that reduce-scatter slices divide for any world size up to 256."""
+    m = get_model(stage2_model_cfg("moe", 4, dropout=0.0))
+    eng = m._engine()
+    eng._layout_arena()
+    cuts = eng._bucket_cuts(6)
+    assert len(cuts) == 6 and cuts[-1] == eng._arena_numel and cuts == sorted(cuts)
+    assert all(c % 256 == 0 for c in cuts) and eng._arena_numel - eng._arena_used < 256
+    total = sum(p.numel() for p in m.parameters())
+    assert eng._arena_used == total == 55373360
+    tail = eng._arena_numel - cuts[-2]
+    assert 0 < tail < 0.06 * total                       # layer1 + stem + the two measurement encoders: ~5 % of the bytes
+    first = cuts[0]
+    assert all(abs((cuts[i + 1] - cuts[i]) - first) <= 256 for i in range(3))     # even split of the rest
+    # the slot of layer1.0.conv1 lies in the last bucket, layer2's in an earlier one
+    def off(name):
+        key = next(eng._key(k, l) for k, l, _ in eng.params if getattr(l, "name", "") == name and k == "w")
+        return eng._slots[key][0]
+    assert off("layer1.0.conv1") >= cuts[-2] > off("layer2.0.conv1")
+
+
+def test_bench_self_launch_refuses_missing_devices():
+    """`python bench.py --gpus N` starts its own one-rank-per-GPU job; on a node with fewer devices it
+    must say so -- before any GPU call -- instead of printing a launcher hint.  (This container has no GPU: 0 < 2.)"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PMOE_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("node has the devices")
+    assert r.returncode == 2 and "needs 2 devices" in r.stderr, (r.returncode, r.stderr[-500:])

@@ -448,7 +448,15 @@ def test_planned_inference_replays_the_recorded_launches():
         for p_ in model.parameters():
             p_.mul_(1.01)
         ref3 = [t.clone() for t in model.mixture_params(img2, dev["speed"], dev["command"])]
-    pm.refresh()
+    # (no explicit refresh() -- the replay compares the engine's build / pointer / version keys with the recorded
+    #  ones and re-records by itself; the eager call above re-packed the weight banks the old plan pointed into)
+    for a, b in zip(ref3, pm(img2, dev["speed"], dev["command"])):
+        assert torch.equal(a, b)
+    # an eager call in ANOTHER compute dtype re-allocates every packed bank (engine._ensure_built): the plan must notice
+    model.compute_dtype = torch.float32
+    with torch.no_grad():
+        model.mixture_params(img2, dev["speed"], dev["command"])
+    model.compute_dtype = torch.bfloat16
     for a, b in zip(ref3, pm(img2, dev["speed"], dev["command"])):
         assert torch.equal(a, b)
     model.train()

@@ -19,15 +19,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, n_buckets, q):
+def _worker(rank, world, port, n, n_buckets, q, mode="rs_ag", cuts=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = torch.Generator().manual_seed(100 + rank)
         arena = torch.randn(n, generator=g)
         mine = arena.clone()
-        red = BucketedAllReduce(None, n_buckets)
-        red.begin(arena)
+        red = BucketedAllReduce(None, n_buckets, mode=mode)
+        red.begin(arena, cuts)
         # backward fills the arena front to back; buckets fly as soon as the prefix passes them
         sent_before_finish = 0
         for upto in range(0, n + 1, max(1, n // 7)):
@@ -49,13 +49,19 @@ def _worker(rank, world, port, n, n_buckets, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,n_buckets", [(1000, 6), (17, 3), (64, 1)])
-def test_bucketed_allreduce_world2(n, n_buckets):
+@pytest.mark.parametrize("n,n_buckets,mode,cuts", [
+    (1000, 6, "rs_ag", None),                  # reduce-scatter + all-gather per bucket, equal buckets (the last one odd-sized: ring fallback)
+    (1024, 4, "rs_ag", [512, 768, 1000]),      # engine-chosen cuts: small last bucket
+    (17, 3, "rs_ag", None),                    # ragged buckets: all-reduce fallback where length % world != 0
+    (1000, 6, "ring", None), (64, 1, "ring", None)])
+def test_bucketed_allreduce_world2(n, n_buckets, mode, cuts):
+    """the mean of the arena over 2 gloo ranks through both collective shapes (RCCL's in-place reduce-scatter is emulated
+    by per-slice reduces on gloo: same slice arithmetic, same all-gather)"""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, n_buckets, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, n_buckets, q, mode, cuts)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
