@@ -174,6 +174,11 @@ class ExpertGroupEngine:
         self.fp8_min_cin = int(os.environ.get("PMOE_FP8_MIN_CIN", "64"))
         self.raw_alpha = False        # lone BaseExpert.forward: the gate kernel returns alpha itself instead of softmax(alpha)
         self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tests/experiments/probe_layers.py)
+        # dict -> forward keeps a reference to every tensor that carries a DISCRETE decision of the network: the outputs of
+        # ReLU layers (BatchNorm+ReLU passes and ReLU GEMM epilogues, by layer name) and the max-pool's winning taps
+        # ("maxpool").  tests/forced_masks.py hands them to the float64 oracle so that both sides differentiate the SAME
+        # piecewise-linear function (two f32 evaluations disagree on the sign of pre-activations within ~1e-7 of zero)
+        self.debug_acts = None
         self._collect()
 
     # ------------------------------------------------------------------ structure
@@ -407,6 +412,8 @@ class ExpertGroupEngine:
                    out_coff=o.coff, bias=layer.bias_packed if bias else None, act=act, drop_p=drop_p, seed=seed,
                    stats=stats, out_scale=layer.oscale if f8 else None, in_scale=self.fp8_in_scale)
         o.act, o.drop_p = act, drop_p
+        if self.debug_acts is not None and act == hip.ACT_RELU:
+            self.debug_acts[layer.name] = (o.t, o.coff, layer.cout)
         o.needs_grad = x.needs_grad or layer.trainable
         if out is not None and o.needs_grad:
             out.needs_grad = True
@@ -565,6 +572,8 @@ class ExpertGroupEngine:
             y.gap_part = (part, nparts)
         else:
             ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, mean, rpe, E, C_, relu, y_coff=y.coff)
+        if self.debug_acts is not None and relu:
+            self.debug_acts[layer.name] = (y.t, y.coff, C_)
         y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
         if out is not None and y.needs_grad:
             out.needs_grad = True
@@ -652,6 +661,8 @@ class ExpertGroupEngine:
         y = Var(self._new(n, ho, wo, C_))
         am = torch.empty(n, ho, wo, C_, dtype=torch.uint8, device=self.dev)
         ops.stem_tail_pool(z2.t, y.t, am, sc2, sh2, sc1, sh1, mu2, mu1, self.B)
+        if self.debug_acts is not None:
+            self.debug_acts["stem_tail"] = (am, y.t)      # winning tap | 0x80 if the winner's a2 > 0; a3 > 0 <=> y > 0
         y.needs_grad = z2.needs_grad or self.bn_c2.trainable or self.bn1.trainable
         if self.taping and y.needs_grad:
             train = self.training
@@ -703,6 +714,8 @@ class ExpertGroupEngine:
         y = Var(self._new(n, ho, wo, c))
         am = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=self.dev)
         ops.maxpool_fwd(x.t, y.t, am)
+        if self.debug_acts is not None:
+            self.debug_acts["maxpool"] = (am, 0, c)
         y.needs_grad = x.needs_grad
         if self.taping and y.needs_grad:
             def bwd():

@@ -331,7 +331,19 @@ class PUNetEngine(ExpertGroupEngine):
         top_training = training
         spd, cmd = self._measurement_inputs(speed, command)
         taping_saved, self.taping = self.taping, False          # nothing inside the frozen PU-Net is taped
-        x0, inter = self._punet_fwd(images)
+        if getattr(self, "debug_x0", None) is not None and not self.return_inter:
+            # tests/punet_parity.py (teacher forcing): the predicted masks [B,F,classes,H,W] are GIVEN, the frozen PU-Net is
+            # skipped -- the trainable half (138-channel stem, ResNet, heads) is then compared on identical inputs, without
+            # the chained train-mode U-Nets' sensitivity in the loop
+            mk = self.debug_x0
+            Hm, Wm = mk.shape[-2:]
+            x0 = Var(self._new(Bsz, Hm, Wm, r16(mk.shape[1] * mk.shape[2])))
+            ops.nchw_to_nhwc(mk.reshape(Bsz, -1, Hm, Wm).contiguous().float(), x0.t)
+            inter = None
+        else:
+            x0, inter = self._punet_fwd(images)
+        if getattr(self, "debug_keep_x0", False):
+            self.debug_x0_kept = x0.t if x0 is not None else None
         self.taping = taping_saved
         self.training = top_training
         feat = Var(self._new(self.N, 1, 1, 1536))

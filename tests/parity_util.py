@@ -19,14 +19,13 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 #         tiny-batch goldens (measured up to 2.8e-2); the same CPU oracle with bf16-rounded layer outputs is
 #         off by the same amount (tests/experiments/bf16_conditioning.py), i.e. it is the storage format, not the kernels:
 #         every bf16 kernel meets 1e-2 on its own (tests/test_ops_gpu.py).
-# Gradients -- the random-weight 20-layer ReLU/BN network is chaotic for gradients: tests/experiments/bf16_conditioning.py
-# shows the CPU oracle in f32 vs f64 differs by up to 2e-2 rel-L2 on some tensors, and the oracle with
-# bf16-rounded activations differs from f64 by a MEDIAN of 0.4 rel-L2 (DESIGN.md "numerics").  So:
-#   f32 : every parameter gradient within max(5e-3, 4x the f32-oracle's own drift from the f64 oracle) of the
-#         float64 oracle (conditioning-aware), median rel-L2 vs the f32 oracle <= 5e-3, and the reference's golden
-#         gradient slices / norms; this is what proves the backward algorithm.
-#   bf16: statistical agreement only (median cosine >= 0.85, total norm within 20%); the bf16 KERNELS are
-#         held to 1e-2 per op in tests/test_ops_gpu.py.
+# Gradients:
+#   f32 : run_forced_case (below): the float64 oracle differentiates the same piecewise-linear function as the HIP path
+#         (ReLU / max-pool decisions forced, tests/forced_masks.py); EVERY tensor of EVERY expert within FORCED_GRAD_TOL,
+#         every decision disagreement a near-tie.  This is what proves the backward algorithm.
+#   bf16: statistical agreement only (median cosine >= 0.85, total norm within 20%: the bf16-storage-emulating oracle has a
+#         median rel-L2 of 0.4 against f64, DESIGN.md "numerics"); the bf16 KERNELS are held to 1e-2 per op in
+#         tests/test_ops_gpu.py.
 TOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
 # bf16 forward bound, measured instead of flat: tests/golden/bf16_bounds.pt (oracle/make_bounds.py)
 # holds, per golden case and output, the float64 oracle's value and the error of the bf16-STORAGE-emulating oracle
@@ -47,11 +46,6 @@ def bf16_bounds(name):
     return _BOUNDS["forward"].get(name)
 
 
-def grad_bounds(name):
-    bf16_bounds(name)
-    return _BOUNDS["grad"].get(name)
-
-
 def bf16_fwd_report(name, outs):
     """{output: (HIP error vs float64, emulating-oracle error vs float64)} for the outputs of golden case ``name``."""
     b = bf16_bounds(name)
@@ -66,8 +60,6 @@ def bf16_fwd_report(name, outs):
 def emul_worst(draws, k):
     """largest max-metric error of output ``k`` over all variants and draws of an emulation record."""
     return max(d[k][0] for v in draws for d in draws[v])
-GRAD_TOL = {torch.float32: 2e-2, torch.bfloat16: None}
-GRAD_MEDIAN_TOL = 5e-3
 
 
 def fwd_err(got, ref, dtype):
@@ -103,8 +95,10 @@ def build_pair(g, dtype, dropout=0.0):
     return ocfg, oracle, model, inp
 
 
-def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, fwd_tol_mult=1.0, f64_oracle=True):
+def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, fwd_tol_mult=1.0):
     g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
+    if dtype == torch.float32 and g["meta"]["train"] and check_grads:
+        return run_forced_case(name, verbose)            # flat bounds, every expert, every tensor (tests/forced_masks.py)
     ocfg, oracle, model, inp = build_pair(g, dtype)
     dev = {k: v.to("cuda") for k, v in inp.items()}
     tol = TOL[dtype]
@@ -156,73 +150,7 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
         errs.sort()
         report["grad_median_rel_l2"], report["grad_worst"] = errs[len(errs) // 2][0], errs[-1]
         if dtype == torch.float32:
-            # conditioning-aware bound: the same oracle in float64 tells how far two exact-f32 evaluations of this
-            # tensor can drift apart; the HIP f32 path must stay within 4x that (floor 5e-3) of the f64 truth
-            import copy
-            if f64_oracle:
-                o64 = copy.deepcopy(oracle).double()
-                o64.zero_grad()
-                d64, s64 = o64(inp["images"].double(), inp["speed"].double(), inp["command"].double())
-                O.moe_loss(d64, s64, inp["control"].double(), inp["target_speed"].double(), ocfg.loss_coefs).backward()
-                g64 = {k: p.grad.float() for k, p in o64.named_parameters()}
-            else:
-                # the largest cases take the float64 evaluation from the fixture (oracle/make_bounds.py): per tensor the
-                # norm of the float64 gradient and the f32 oracle's own relative drift from it.  The full float64
-                # tensors are not stored (220 MB), so the distance to them is bounded by the triangle inequality:
-                # |hip - g64| <= |hip - o32| + |o32 - g64|, all relative to |g64| -- a SUFFICIENT condition, stricter
-                # than the live comparison the smaller cases get
-                gb = grad_bounds(name)
-                assert gb is not None, f"{name}: no float64 gradient fixture (oracle/make_bounds.py)"
-                g64 = None
-            # Isolated ReLU-mask flips: any two f32 implementations disagree on the sign of a few pre-activations
-            # that sit within ~1e-7 of zero (expected 0.2-2 per pass here).  At the 4x4 / 8x8 layers of these B=2
-            # goldens one flip moves ONE channel's BatchNorm gradient by ~25 % and every upstream tensor of THAT
-            # expert by ~1 % (tests/experiments/probe_layers.py pinpoints the channel; DESIGN.md "numerics").  All experts run
-            # through the same launches of the same kernels, so the algorithm is proven by the experts that are
-            # flip-free: at least half of the experts must meet the tight conditioning-aware bound on EVERY
-            # tensor; the others may only deviate by what a flip explains (<= 0.15, median <= 3e-2).
-            import re, statistics
-
-            def expert_of(k):       # "moe.<e>.…" for MixtureOfExperts; the shared-trunk model is one group
-                mt = re.match(r"moe\.(\d+)\.", k)
-                return int(mt.group(1)) if mt else 0
-            per_expert = {}
-            for k, p in named.items():
-                if g64 is None:
-                    n64, e_ref = gb[k]
-                    if n64 < 1e-6 * total_ref:
-                        continue
-                    e_hip = (p.grad.detach().float().cpu() - onamed[k].grad).norm().item() / n64 + e_ref
-                else:
-                    if g64[k].norm().item() < 1e-6 * total_ref:
-                        continue
-                    e_ref = rel_l2(onamed[k].grad, g64[k])
-                    e_hip = rel_l2(p.grad, g64[k])
-                ex = expert_of(k)
-                per_expert.setdefault(ex, []).append((e_hip, e_hip <= max(5e-3, 4 * e_ref), k))
-            tight = [ex for ex, rows in per_expert.items() if all(ok for _, ok, _ in rows)]
-            report["experts_tight"] = f"{len(tight)}/{len(per_expert)}"
-            if len(per_expert) > 1:
-                assert 2 * len(tight) >= len(per_expert), {ex: max(r for r, _, _ in rows) for ex, rows in per_expert.items()}
-            # (a shared-trunk model is ONE group: the caller applies the same "at least half are flip-free" rule
-            #  over several golden cases instead -- tests/test_model_gpu.py::test_train_parity_f32_shared_trunk)
-            for ex, rows in per_expert.items():
-                if ex in tight:
-                    continue
-                assert max(r for r, _, _ in rows) <= 0.15, (ex, max(rows))
-                assert statistics.median(r for r, _, _ in rows) <= 3e-2, ex
-            assert errs[len(errs) // 2][0] <= GRAD_MEDIAN_TOL, errs[len(errs) // 2]
-            assert abs(total - total_ref) <= 1e-2 * total_ref
-            # golden slices produced by the reference itself (not just the oracle)
-            for k, sl in g["grad_slices"].items():
-                if expert_of(k) not in tight:
-                    continue
-                scale = max(sl.abs().max().item(), g["grad_norms"][k] / max(1, named[k].numel()) ** 0.5)
-                e = (named[k].grad.flatten()[:64].cpu() - sl).abs().max().item() / (scale + 1e-20)
-                assert e <= 4 * GRAD_TOL[dtype], f"{name} grad slice {k}: {e:.3e}"
-            for k, nrm in g["grad_norms"].items():
-                if nrm > 1e-6 * total_ref and named[k].numel() >= 16 and expert_of(k) in tight:
-                    assert abs(named[k].grad.norm().item() - nrm) <= GRAD_TOL[dtype] * nrm, k
+            raise AssertionError("f32 gradient parity runs through run_forced_case")
         else:
             cosines.sort()
             report["grad_median_cos"] = cosines[len(cosines) // 2]
@@ -238,4 +166,84 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
                 assert rel_err(sd[k], v) <= (1e-4 if dtype == torch.float32 else 3e-2), k
     if verbose:
         print(name, dtype, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in report.items()})
+    return report
+
+
+# ---- gradient parity with the discrete decisions forced (tests/forced_masks.py): flat bounds, every expert, every tensor
+FORCED_GRAD_TOL = 1e-3        # rel-L2 of a gradient tensor against the float64 oracle run on the HIP path's ReLU / max-pool decisions
+FLIP_ZONE = 1e-4              # a disagreement between the float64 oracle's own decision and the HIP one must sit this close to the tie
+
+
+def run_forced_case(name, verbose=True, tol=FORCED_GRAD_TOL):
+    """f32 HIP path vs (a) the reference's golden forward vectors at north_star's 1e-4 and (b) the float64 oracle
+    differentiating the same piecewise-linear function (forced_masks.py): EVERY parameter gradient of EVERY expert within
+    ``tol``, every decision disagreement a near-tie, and -- for the experts without any disagreement, where the forced
+    oracle IS the reference network -- the reference's own golden gradient slices and norms."""
+    import re
+    from tests import forced_masks as FM
+    g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
+    m = g["meta"]
+    ocfg, oracle, model, inp = build_pair(g, torch.float32)
+    eng = model._engine()
+    eng.debug_acts = {}
+    dev = {k: v.to("cuda") for k, v in inp.items()}
+    dist, speeds = model(dev["images"], dev["speed"], dev["command"])
+    loss = moe_loss(dist, speeds, dev["control"], dev["target_speed"], ocfg.loss_coefs)
+    loss.backward()
+    probs, mean, std = dist.hip_params
+    report = {k: fwd_err(v, g[k], torch.float32) for k, v in (("probs", probs), ("mean", mean), ("std", std), ("speeds", speeds))}
+    report["loss"] = abs(loss.item() - g["loss"].item()) / max(1.0, abs(g["loss"].item())) / TOL[torch.float32]
+    for k, v in report.items():
+        assert v <= 1.0, f"{name} forward {k}: {v:.3f} x 1e-4"
+
+    def run(m64, cast):
+        d, s = m64(cast(inp["images"]), cast(inp["speed"]), cast(inp["command"]))
+        O.moe_loss(d, s, cast(inp["control"]), cast(inp["target_speed"]).clone(), ocfg.loss_coefs).backward()
+        return dict(mean=d.component_distribution.base_dist.loc.detach(), speeds=s.detach())
+    out64, g64, log = FM.forced_float64(oracle, eng, inp, m["batch"], run, alt=m["type"] == "moe_alt",
+                                        shared=m["type"] == "moe_shared")
+    eng.debug_acts = None
+    # the forced function coincides with the network at the HIP path's operating point: its float64 outputs are the HIP outputs
+    assert rel_err(mean, out64["mean"]) <= 1e-4 and rel_err(speeds, out64["speeds"]) <= 1e-4
+    report["flips"] = [(e, nm, n, f"{z:.1e}") for e, nm, n, z, _ in log]
+    for e, nm, n, z, numel in log:
+        assert z <= FLIP_ZONE, f"{name}: expert {e} {nm}: {n} decisions differ from the float64 oracle's, |pre-activation| up to {z:.2e}"
+        assert n <= max(4, numel // 100000), f"{name}: expert {e} {nm}: {n} of {numel} decisions differ"
+    named = dict(model.named_parameters())
+    total = sum(v.norm().item() ** 2 for v in g64.values()) ** 0.5
+    errs = []
+    for k, p in named.items():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        ref = g64[k].float()
+        if ref.norm().item() < 1e-6 * total:
+            assert p.grad.norm().item() < 1e-4 * total, k
+            continue
+        errs.append((rel_l2(p.grad, ref), k))
+    errs.sort()
+    report["grad_median_rel_l2"], report["grad_worst"] = errs[len(errs) // 2][0], errs[-1]
+    bad = [(f"{e:.2e}", k) for e, k in errs if e > tol]
+    assert not bad, f"{name}: {len(bad)} gradient tensors beyond {tol:g} of the float64 oracle on the same decisions: {bad[-6:]}"
+    # golden slices / norms of the REFERENCE: valid yardstick for the experts whose decisions all agree
+    flipped = {e for e, *_ in log}
+
+    def expert_of(k):
+        mt = re.match(r"moe\.(\d+)\.", k)
+        return int(mt.group(1)) if mt else 0
+    checked = 0
+    for k, sl in g["grad_slices"].items():
+        if expert_of(k) in flipped:
+            continue
+        scale = max(sl.abs().max().item(), g["grad_norms"][k] / max(1, named[k].numel()) ** 0.5)
+        e = (named[k].grad.flatten()[:64].cpu() - sl).abs().max().item() / (scale + 1e-20)
+        assert e <= 2e-2, f"{name} reference gradient slice {k}: {e:.3e}"      # the f32 reference's own noise (flips on ITS side)
+        checked += 1
+    report["golden_slices_checked"] = checked
+    sd = model.state_dict()
+    for k, v in g["bn_after_1"].items():
+        if v.dtype == torch.long:
+            assert int(sd[k].item()) == int(v.item()), k
+        else:
+            assert rel_err(sd[k], v) <= 1e-4, k
+    if verbose:
+        print(name, "forced", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in report.items()})
     return report

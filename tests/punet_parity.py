@@ -209,3 +209,107 @@ def run_pmoe_case(tmp, name, dtype=torch.float32, verbose=True, fwd_tol_mult=1.0
     if verbose:
         print(name, dtype, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in report.items()})
     return report
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: the trainable half of a PUNetExpert compared WITHOUT the two sources of noise the
+# bounds above had to allow for -- the chained train-mode U-Nets' sensitivity (forward) and the ReLU / max-pool lottery
+# (gradients, tests/forced_masks.py).
+FORCED_TOL = 1e-3
+
+
+def run_punet_forced(tmp, name, verbose=True, tol=FORCED_TOL):
+    """f32: the float64 oracle receives the HIP path's OWN predicted masks (its frozen PU-Net forward is replaced by them)
+    and the HIP path's own ReLU / max-pool decisions; then actions / speeds must agree to 1e-4 and EVERY trainable gradient
+    tensor to ``tol``.  The masks themselves are compared with the f32 oracle's (informative: the train-mode U-Net chain on
+    a tiny batch is where f32 and float64 oracles already part; eval-mode case p2 holds the PU-Net kernels to 1e-4)."""
+    from tests import forced_masks as FM
+    g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
+    m = g["meta"]
+    ocfg, oracle, model, inp = build_pair(tmp, g, torch.float32)
+    eng = model._engine()
+    eng.debug_acts, eng.debug_keep_x0 = {}, True
+    dev = {k: v.to("cuda") for k, v in inp.items()}
+    actions, speeds = model(dev["images"], dev["speed"], dev["command"])
+    punet_loss(actions, speeds, dev["control"], dev["target_speed"], ocfg.loss_coefs).backward()
+    F_, nc = m["future_frames"], 23
+    x0 = eng.debug_x0_kept[..., :F_ * nc].permute(0, 3, 1, 2).contiguous().cpu()
+    masks = x0.view(x0.shape[0], F_, nc, *x0.shape[-2:])
+    with torch.no_grad():
+        ref_masks = copy.deepcopy(oracle).punet(inp["images"])
+    report = {"masks_vs_f32_oracle": rel_err(masks, ref_masks)}
+    o64 = copy.deepcopy(oracle).double()
+    o64.zero_grad()
+    m64 = masks.double()
+    o64.punet.forward = lambda images: m64
+    log = []
+    q, holder = FM.expert_queue(eng, 0, m["batch"])
+    holder["H"], holder["W"] = inp["images"].shape[-2:]
+    FM.install(o64, q, holder, log)
+    a64, s64 = o64(inp["images"].double(), inp["speed"].double(), inp["command"].double())
+    O.punet_loss(a64, s64, inp["control"].double(), inp["target_speed"].double(), ocfg.loss_coefs).backward()
+    assert not q, f"{len(q)} forced decisions were never consumed"
+    eng.debug_acts, eng.debug_keep_x0 = None, False
+    report["actions"], report["speeds"] = fwd_err(actions, a64, torch.float32), fwd_err(speeds, s64, torch.float32)
+    assert report["actions"] <= 1.0 and report["speeds"] <= 1.0, report
+    report["flips"] = [(nm, n, f"{z:.1e}") for _, nm, n, z, _ in log]
+    for _, nm, n, z, numel in log:
+        assert z <= 1e-4 and n <= max(4, numel // 100000), (name, nm, n, z)
+    named = dict(model.named_parameters())
+    g64 = {k: p.grad for k, p in o64.named_parameters() if p.grad is not None}
+    total = sum(v.norm().item() ** 2 for v in g64.values()) ** 0.5
+    errs = []
+    for k, p in named.items():
+        if not g["requires_grad"][k]:
+            assert p.grad is None, f"frozen parameter {k} received a gradient"
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        ref = g64[k].float()
+        if ref.norm().item() < 1e-6 * total:
+            assert p.grad.norm().item() < 1e-4 * total, k
+            continue
+        errs.append((rel_l2(p.grad, ref), k))
+    errs.sort()
+    report["grad_median_rel_l2"], report["grad_worst"] = errs[len(errs) // 2][0], errs[-1]
+    bad = [(f"{e:.2e}", k) for e, k in errs if e > tol]
+    assert not bad, f"{name}: {len(bad)} gradient tensors beyond {tol:g}: {bad[-6:]}"
+    if verbose:
+        print(name, "forced", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in report.items()})
+    return report
+
+
+def run_punet_teacher_forced_bf16(tmp, name, verbose=True):
+    """bf16: the HIP backbone is fed the ORACLE's predicted masks (engine.debug_x0), so both sides see identical inputs and the
+    comparison is about the bf16 ResNet / head kernels alone: actions / speeds against the f32 oracle, gradient directions
+    (cosine per tensor), total gradient norm."""
+    g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
+    ocfg, oracle, model, inp = build_pair(tmp, g, torch.bfloat16)
+    oa, os_ = oracle(inp["images"], inp["speed"], inp["command"])
+    O.punet_loss(oa, os_, inp["control"], inp["target_speed"], ocfg.loss_coefs).backward()
+    with torch.no_grad():
+        ref_masks = copy.deepcopy(oracle).punet(inp["images"])          # same train-mode batch statistics as the call above
+    eng = model._engine()
+    eng.debug_x0 = ref_masks.cuda()
+    dev = {k: v.to("cuda") for k, v in inp.items()}
+    actions, speeds = model(dev["images"], dev["speed"], dev["command"])
+    punet_loss(actions, speeds, dev["control"], dev["target_speed"], ocfg.loss_coefs).backward()
+    eng.debug_x0 = None
+    report = {"actions": ((actions.detach().cpu() - oa.detach()).abs() / (1 + oa.detach().abs())).max().item(),
+              "speeds": ((speeds.detach().cpu() - os_.detach()).abs() / (1 + os_.detach().abs())).max().item()}
+    named, onamed = dict(model.named_parameters()), dict(oracle.named_parameters())
+    cos, tot, tot_ref = [], 0.0, 0.0
+    for k, p in named.items():
+        if not g["requires_grad"][k]:
+            assert p.grad is None, k
+            continue
+        ref = onamed[k].grad
+        tot += p.grad.float().norm().item() ** 2
+        tot_ref += ref.norm().item() ** 2
+        if p.numel() >= 1024:
+            cos.append((torch.nn.functional.cosine_similarity(p.grad.flatten().cpu().float(), ref.flatten(), dim=0).item(), k))
+    cos.sort()
+    report["grad_median_cos"], report["grad_min_cos"] = cos[len(cos) // 2][0], cos[0]
+    report["grad_total_rel"] = abs(tot ** 0.5 - tot_ref ** 0.5) / tot_ref ** 0.5
+    if verbose:
+        print(name, "teacher-forced bf16", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in report.items()})
+    return report

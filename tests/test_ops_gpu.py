@@ -29,6 +29,13 @@ def close(got, ref, dtype, what=""):
     err = (got - ref).abs().max().item() / scale
     tol = 1e-4 if dtype == torch.float32 else 1e-2
     assert err <= tol, f"{what}: rel-to-max err {err:.3e} > {tol} (scale {scale:.3e})"
+    # ... and elementwise (rel-to-max alone is blind to errors on small elements): every element within
+    # tol of ITS OWN magnitude plus a floor of 1/16 of the tensor's scale
+    bad = (got - ref).abs() > tol * (ref.abs() + scale * 2.0 ** -4)
+    if bad.any():
+        i = ((got - ref).abs() / (ref.abs() + scale * 2.0 ** -4)).argmax()
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} elements beyond {tol} x (|ref| + scale/16); worst "
+                             f"got {got.flatten()[i].item():.6e} ref {ref.flatten()[i].item():.6e} (scale {scale:.3e})")
 
 
 def r16(c):

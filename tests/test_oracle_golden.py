@@ -23,7 +23,7 @@ def _run(g):
 
 
 CASES = ["g1_moe_e4_b2_128", "g3_moe_e8_b2_128", "g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g10_moe_e4_b32_64", "g6_moeshared_k4_b6_96",
-         "g8_moeshared_k3_b4_128", "g9_moeshared_k5_b8_64"]
+         "g8_moeshared_k3_b4_128", "g9_moeshared_k5_b8_64", "g11_moe_e4_b8_128"]
 
 
 @pytest.mark.parametrize("name", CASES + ["g2_moe_e4_b1_224_eval", "g7_moeshared_k6_b1_224_eval"])
@@ -113,7 +113,7 @@ def test_micro_cases(golden_dir):
     torch.testing.assert_close(O.moe_loss(dist, ls["speeds"], ls["act"], ls["tgt"], [0.7, 0.3]), ls["loss"])
 
 
-PUNET_CASES = ["p1_punet_b2_64_f2", "p3_punetinter_b2_64_f2"]
+PUNET_CASES = ["p1_punet_b2_64_f2", "p3_punetinter_b2_64_f2", "p6_punet_b8_96_f2"]
 
 
 def _punet_oracle(g):
