@@ -41,6 +41,13 @@ extern "C" {
 #define PMOE_RES_DELU 3    /* out = acc * elu'(res),  res = saved layer output                        */
 #define PMOE_RES_DTANH 4   /* out = acc * (1 - res^2)                                                  */
 #define PMOE_RES_DSIGMOID 5 /* out = acc * res (1 - res)                                               */
+/* round 3: data gradient of a conv whose input was a = relu(BatchNorm(z)) (train mode, no residual) -- `res` = z, the
+ * BatchNorm's pre-activation input; `bn_coef` = its [4][n/bn_ipe][cout] f32 coefficients (mean, invstd, gamma*invstd,
+ * beta).  out = g = acc * [ (z - mean) * gamma*invstd + beta > 0 ], and `stats` receives the two reductions of that
+ * BatchNorm's backward -- sum g and sum g * (z - mean) * invstd per channel, in the row layout of the forward statistics --
+ * so the separate reduce pass over (dy, z) disappears (autograd of nn.BatchNorm2d + nn.ReLU in torchvision's BasicBlock
+ * and model/blocks/basics.py:93-100).  bf16, 3x3 stride-1 layers on the LDS-DMA kernels only (pmoe_conv2d_plan says). */
+#define PMOE_RES_DBN 6
 
 /* ABI revision of this header: bumped whenever a descriptor struct, an argument list or a buffer contract changes
  * (100: round 1; 200: round 2 -- pmoe_conv_desc 160 -> 176 bytes, pmoe_wgrad_desc.part_ws, pmoe_bn_bwd_reduce's gmask_out,
@@ -83,6 +90,8 @@ typedef struct pmoe_conv_desc {
     int32_t w_fp8;
     float in_scale;
     const float* out_scale;
+    const float* bn_coef; /* PMOE_RES_DBN: [4][n / bn_ipe][cout] f32 = mean, invstd, gamma*invstd, beta of the BatchNorm  */
+    int32_t bn_ipe;       /* PMOE_RES_DBN: images per BatchNorm parameter set (= ipe unless the conv runs per image)     */
 } pmoe_conv_desc;
 
 int pmoe_conv2d_igemm(const pmoe_conv_desc* d, void* stream);

@@ -14,6 +14,7 @@ static ConvArgs to_args(const pmoe_conv_desc* d) {
     a.act = d->act; a.res_mode = d->res ? d->res_mode : PMOE_RES_NONE;
     a.drop_p = d->drop_p; a.seed = d->seed;
     a.oscale = d->out_scale; a.in_scale = d->in_scale; a.w_fp8 = d->w_fp8;
+    a.bn = d->bn_coef; a.bn_ipe = d->bn_ipe > 0 ? d->bn_ipe : d->ipe;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = 0;
     a.kh = a.kw = d->ks; a.use_tapmap = 0; a.tapmap[0] = a.tapmap[1] = a.tapmap[2] = a.tapmap[3] = 0;
     a.out_step = 1; a.out_offy = a.out_offx = 0; a.OH = d->ho; a.OW = d->wo; a.prefetch = 0; a.stagger = 0;
@@ -28,6 +29,9 @@ static int check_conv(const pmoe_conv_desc* d) {
     if (d->res && (d->res_ld % ve || d->res_coff % ve)) return PMOE_ERR_ARG;
     if (d->cout > d->coutp || d->in_coff + d->cin > d->in_ld || d->out_coff + d->cout > d->out_ld) return PMOE_ERR_ARG;
     if (d->drop_p < 0.f || d->drop_p >= 1.f) return PMOE_ERR_ARG;
+    if (d->res && d->res_mode == PMOE_RES_DBN &&
+        (!d->bn_coef || !d->stats || d->dtype != PMOE_DT_BF16 || (d->bn_ipe > 0 && (d->bn_ipe % d->ipe || d->n % d->bn_ipe))))
+        return PMOE_ERR_ARG;
     // geometry: forward conv / transposed (dilate) relation between (h,w) and (ho,wo)
     if (!d->dilate) {
         if (d->ho != (d->h + 2 * d->pad - d->ks) / d->stride + 1) return PMOE_ERR_ARG;

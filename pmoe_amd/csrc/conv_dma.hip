@@ -228,6 +228,21 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
     const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     bf16* out = (bf16*)a.out;
     const bf16* res = (const bf16*)a.res;
+    // PMOE_RES_DBN: this launch is the data gradient into a = relu(BatchNorm(z)); res = z.  The epilogue masks the gradient with
+    // the recomputed ReLU decision and leaves the BatchNorm backward's two channel reductions in `stats` (s2 = sum g * xhat)
+    const bool dbn = a.res_mode == PMOE_RES_DBN;
+    float bmu[VE], bis[VE], bsc[VE], bsh[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) bmu[i] = bis[i] = bsc[i] = bsh[i] = 0.f;
+    if (dbn && cvalid) {
+        const int nset = a.N / a.bn_ipe;
+        const float* b = a.bn + (size_t)((e * a.ipe) / a.bn_ipe) * a.Cout + cout;
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            bmu[i] = b[i]; bis[i] = b[(size_t)nset * a.Cout + i];
+            bsc[i] = b[(size_t)2 * nset * a.Cout + i]; bsh[i] = b[(size_t)3 * nset * a.Cout + i];
+        }
+    }
     // fused tail of one 8-channel vector v of output pixel p of the tile
     auto finish = [&](int p, float* v) {
         const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
@@ -236,9 +251,18 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
             const size_t opix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
 #pragma unroll
             for (int i = 0; i < VE; ++i) v[i] += bias[i];
+            float xh[VE];
             if (a.res_mode) {
                 float rv[VE];
                 unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cout), rv);
+                if (dbn) {
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) {
+                        const float d = rv[i] - bmu[i];
+                        v[i] = (d * bsc[i] + bsh[i]) > 0.f ? v[i] : 0.f;
+                        xh[i] = d * bis[i];
+                    }
+                } else
                 if (a.res_mode == PMOE_RES_ADD) {
 #pragma unroll
                     for (int i = 0; i < VE; ++i) v[i] += rv[i];
@@ -271,8 +295,13 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
             if (a.stats) {
                 float rr[VE];
                 unpack16<bf16>(pk, rr);
+                if (dbn) {
 #pragma unroll
-                for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
+                    for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * xh[i]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
+                }
             }
 #endif
             stg16(out + opix * a.out_ld + a.out_coff + cout, pk);
@@ -282,7 +311,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
     // (16-byte chunks XOR-swizzled by pixel), one barrier, 8 vectors per thread -- half the LDS bytes and half the
     // barriers of the f32 path below
     const bool fast_epi = !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f &&
-                          (a.res_mode == PMOE_RES_NONE || a.res_mode == PMOE_RES_DRELU);
+                          (a.res_mode == PMOE_RES_NONE || a.res_mode == PMOE_RES_DRELU || a.res_mode == PMOE_RES_DBN);
     if (fast_epi) {
         __syncthreads();
 #pragma unroll

@@ -577,6 +577,15 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
         if (dtype != PMOE_DT_BF16 || a.dilate) return PMOE_ERR_ARG;
         return launch_dtype<bf16, fp8>(a, st, nullptr);
     }
+    if (a.res_mode == PMOE_RES_DBN) {                // BatchNorm-backward reductions in the epilogue: the two LDS-DMA kernels only
+        ResPlan plan;
+        int pb, mpw, mph, mb;
+        size_t sm;
+        if (conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm)) return conv_res_launch(a, plan, st);
+        ConvArgs c = a;
+        if (!gemm_skinny_ok(a, dtype) && conv_dma_plan(c, dtype, &mb, &sm, &pb)) return conv_dma_launch(a, st);
+        return PMOE_ERR_UNSUPPORTED;
+    }
     if (a.dilate && a.ks == 3 && a.pad == 1 && a.kh == 3) return launch_stride2_dgrad(a, dtype, st);
     if (a.dilate && a.ks == 1 && a.pad == 0 && a.res_mode == PMOE_RES_ADD && a.res == a.out && a.res_ld == a.out_ld &&
         a.res_coff == a.out_coff && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f)
@@ -612,6 +621,14 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         int mb = 0, cfg = 0;
         const int rc = dtype == PMOE_DT_BF16 && !a.dilate ? launch_dtype<bf16, fp8>(c, nullptr, &mb, &cfg) : PMOE_ERR_ARG;
         return rc ? rc : cfg;
+    }
+    if (a.res_mode == PMOE_RES_DBN) {
+        ResPlan plan;
+        int pb, mpw, mph, mb;
+        size_t sm;
+        if (conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm)) return 1000 + plan.log_rb + 100;
+        if (!gemm_skinny_ok(a, dtype) && conv_dma_plan(c, dtype, &mb, &sm, &pb)) return 5007;
+        return PMOE_ERR_UNSUPPORTED;
     }
     if (gemm_skinny_ok(a, dtype)) return 3000;           // gemm_skinny_kernel
     if (a.dilate && a.ks == 3 && a.pad == 1 && a.kh == 3) {

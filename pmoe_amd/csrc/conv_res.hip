@@ -324,6 +324,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
     char* pbuf = smem + 9 * 64 * RB;                     // 2 patch buffers
     float* lbias = reinterpret_cast<float*>(pbuf + 2 * pbuf_bytes);
     if (BIAS && tid < 64) lbias[tid] = a.bias[(size_t)e * a.CoutP + tid];
+    // PMOE_RES_DBN (this launch is the data gradient into a = relu(BatchNorm(z)), res = z): the BatchNorm's coefficients
+    // [mean | invstd | gamma*invstd | beta][64] stay in LDS; the read-out masks the gradient with the recomputed ReLU decision
+    // and accumulates the BatchNorm backward's two channel reductions in s1 / s2 (s2 = sum g * xhat)
+    const bool dbn = a.res_mode == PMOE_RES_DBN;
+    float* lbn = lbias + 64;
+    if (dbn && tid < 256) {
+        const int nset = a.N / a.bn_ipe;
+        lbn[tid] = (tid & 63) < a.Cout ? a.bn[((size_t)(tid >> 6) * nset + (e * a.ipe) / a.bn_ipe) * a.Cout + (tid & 63)] : 0.f;
+    }
 
     const bf16* inb = (const bf16*)a.in + (size_t)e * a.ipe * a.H * a.W * a.in_ld + a.in_coff;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
@@ -389,7 +398,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
     const bool cvalid = cc * VE < a.Cout;
     bf16* out = (bf16*)a.out;
     const bf16* res = (const bf16*)a.res;
-    const bool res_pref = a.res_mode == PMOE_RES_ADD && a.prefetch;      // (a.prefetch: launcher, PMOE_RES_PREFETCH=0 = A/B)
+    const bool res_pref = (a.res_mode == PMOE_RES_ADD || dbn) && a.prefetch;      // (a.prefetch: launcher, PMOE_RES_PREFETCH=0 = A/B)
 
     if (ntile > 0) issue_patch(0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // filter bank + first patch (DMA), the bias row (ds_write)
@@ -482,6 +491,29 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
             if (cvalid && nn < a.ipe && oy < a.Ho && ox < a.Wo) {
                 const size_t opix = (((size_t)e * a.ipe + nn) * a.Ho + oy) * a.Wo + ox;
                 v4i pk = raw;
+                if (dbn) {
+                    float v[VE], rv[VE];
+                    unpack16<bf16>(raw, v);
+                    unpack16<bf16>(res_pref ? rpre[u] : ldg16(res + opix * a.res_ld + a.res_coff + cc * VE), rv);
+                    float mu[VE], is[VE], sc[VE], sh[VE];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        *reinterpret_cast<f32x4*>(mu + 4 * q) = *reinterpret_cast<const f32x4*>(lbn + cc * VE + 4 * q);
+                        *reinterpret_cast<f32x4*>(is + 4 * q) = *reinterpret_cast<const f32x4*>(lbn + 64 + cc * VE + 4 * q);
+                        *reinterpret_cast<f32x4*>(sc + 4 * q) = *reinterpret_cast<const f32x4*>(lbn + 128 + cc * VE + 4 * q);
+                        *reinterpret_cast<f32x4*>(sh + 4 * q) = *reinterpret_cast<const f32x4*>(lbn + 192 + cc * VE + 4 * q);
+                    }
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) {
+                        const float d = rv[i] - mu[i];
+                        // the value the apply pass will read is the ROUNDED masked gradient: the sums use it too
+                        const float gq = (d * sc[i] + sh[i]) > 0.f ? v[i] : 0.f;
+                        v[i] = gq;
+                        s1[i] += gq;
+                        s2[i] += gq * (d * is[i]);
+                    }
+                    pk = pack16<bf16>(v);
+                } else {
                 if (a.res_mode == PMOE_RES_ADD) {
                     float v[VE], rv[VE];
                     unpack16<bf16>(raw, v);
@@ -495,6 +527,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
                     unpack16<bf16>(pk, rr);
 #pragma unroll
                     for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
+                }
                 }
                 stg16(out + opix * a.out_ld + a.out_coff + cc * VE, pk);
             }
@@ -540,8 +573,9 @@ bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan) {
     if (dtype != PMOE_DT_BF16 || a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dilate) return false;
     if (a.CoutP != 64 || a.Cout % 8 || (a.Cin != 64 && a.Cin != 16)) return false;
     if (a.act != PMOE_ACT_NONE || a.drop_p > 0.f) return false;
-    if (a.bias && (a.res_mode != PMOE_RES_NONE || a.Cin != 64)) return false;
-    if (a.res_mode != PMOE_RES_NONE && a.res_mode != PMOE_RES_ADD) return false;
+    if (a.bias && ((a.res_mode != PMOE_RES_NONE && a.res_mode != PMOE_RES_DBN) || a.Cin != 64)) return false;
+    if (a.res_mode != PMOE_RES_NONE && a.res_mode != PMOE_RES_ADD && a.res_mode != PMOE_RES_DBN) return false;
+    if (a.res_mode == PMOE_RES_DBN && a.Cin != 64) return false;    // (conv3x3_resdma_kernel only: conv_igemm_launch)
     if (a.N % a.ipe || a.Ho != a.H || a.Wo != a.W) return false;
     auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     int lTW = p2(a.Wo); if (lTW > 5) lTW = 5;
@@ -584,7 +618,7 @@ bool conv_res_dma_ok(const ConvArgs& a, const ResPlan& p, int* pbuf, int* magic_
     const int mpw = 65536 / PW + 1, mph = 65536 / PH + 1;
     for (int pp = 0; pp < npiece * 8; ++pp)
         if (((pp * mpw) >> 16) != pp / PW || ((((pp / PW) * mph) >> 16) != (pp / PW) / PH)) return false;
-    const size_t sm = (size_t)9 * 64 * 128 + 2 * (size_t)pb + 256;
+    const size_t sm = (size_t)9 * 64 * 128 + 2 * (size_t)pb + 256 + 1024;     // + bias row + BatchNorm coefficient rows
     if (npiece > 48 || sm > 163840 || p.lTW < 4 || (long long)a.ipe * a.H * a.W * a.in_ld * 2 >= 0x7ff00000ll) return false;
     *pbuf = pb; *magic_pw = mpw; *magic_ph = mph; *smem = sm;
     return true;

@@ -30,6 +30,8 @@ struct ConvArgs {
     // dy whose taps are `tapmap` entries of the 3x3 filter, written to dx[2a+py][2b+px] (out_step 2).
     int kh, kw, use_tapmap, tapmap[4];
     int out_step, out_offy, out_offx, OH, OW;
+    const float* bn;       // PMOE_RES_DBN: [4][N / bn_ipe][Cout] f32 (mean, invstd, scale, beta)
+    int bn_ipe;
     int stagger;           // launcher: waves 4-7 of the 8-wave tile run one k-substep behind their SIMD partners
     int prefetch;          // launcher: 2 patch buffers, the next channel chunk's halo patch is fetched under the MFMAs
 };

@@ -36,12 +36,14 @@ def r64(c):
 
 class Var:
     """A device activation [N,H,W,ld] (+ channel window) with its gradient slot."""
-    __slots__ = ("t", "coff", "c", "g", "needs_grad", "act", "drop_p", "base", "gap_part")
+    __slots__ = ("t", "coff", "c", "g", "needs_grad", "act", "drop_p", "base", "gap_part", "bn_src", "bn_part")
 
     def __init__(self, t, c=None, coff=0, needs_grad=False, base=None):
         self.t, self.coff, self.c = t, coff, (c if c is not None else t.shape[-1])
         self.g, self.needs_grad, self.act, self.drop_p, self.base = None, needs_grad, hip.ACT_NONE, 0.0, base
         self.gap_part = None                 # (part [N,nparts,C], nparts): channel sums left by the pass that wrote t (_bn, want_gap)
+        self.bn_src = None                   # (z, layer, coef [4,E,C], rpe): t = relu(BatchNorm(z)) in train mode (_bn)
+        self.bn_part = None                  # (part, nparts): that BatchNorm's backward reductions, left by the consumer's dgrad
 
     @property
     def grad(self):
@@ -165,6 +167,9 @@ class ExpertGroupEngine:
         # residual-block BatchNorm backward: the reduce pass stores the ReLU-masked gradient, the apply pass reads it (7 tensor
         # passes per block output instead of 8).  PMOE_BN_MASK_IN_REDUCE=0: A/B switch
         self.bn_mask_in_reduce = os.environ.get("PMOE_BN_MASK_IN_REDUCE", "1") != "0"
+        # round 3: the reductions of a BatchNorm+ReLU's backward come out of the data-gradient epilogue of the convolution that
+        # consumed its output (PMOE_RES_DBN: one extra read of z there instead of a pass over dy and z).  bf16, LDS-DMA kernels
+        self.bn_reduce_in_dgrad = os.environ.get("PMOE_BN_REDUCE_IN_DGRAD", "1") != "0"
         # stem: the BatchNorm+ReLU pass that writes a1 also leaves the ECA block's per-image channel sums (no GAP pass over a1)
         self.fuse_bn_gap = os.environ.get("PMOE_FUSE_BN_GAP", "1") != "0"
         # BASELINE config 5: e4m3 weights + e4m3 activations on the fp8 matrix cores for the layer1-4 forward convolutions
@@ -176,7 +181,7 @@ class ExpertGroupEngine:
         self.debug_grads = None       # dict -> backward stores the gradient entering every BatchNorm (tests/experiments/probe_layers.py)
         # dict -> forward keeps a reference to every tensor that carries a DISCRETE decision of the network: the outputs of
         # ReLU layers (BatchNorm+ReLU passes and ReLU GEMM epilogues, by layer name) and the max-pool's winning taps
-        # ("maxpool").  tests/forced_masks.py hands them to the float64 oracle so that both sides differentiate the SAME
+        # ("maxpool").  tests/forced_masks.py hands them to its float64 checker so that both sides differentiate the SAME
         # piecewise-linear function (two f32 evaluations disagree on the sign of pre-activations within ~1e-7 of zero)
         self.debug_acts = None
         self._collect()
@@ -503,12 +508,39 @@ class ExpertGroupEngine:
             elif prev is not None:
                 res, res_mode = prev, hip.RES_ADD       # second consumer: accumulate in the epilogue
             g = prev if prev is not None else torch.empty_like(x.t)
+            kw = dict(cin=layer.dg_red, cout=layer.cinp, coutp=layer.dg_rows, ipe=self.B, ks=layer.ks, stride=1,
+                      pad=layer.ks - 1 - layer.pad, dilate=(layer.stride == 2), in_coff=o.coff, out_coff=x.coff)
+            if self._dgrad_with_bn_reduce(x, dy, layer.w_dg, g, kw, flop, layer.name):
+                return
             ops.set_meta(flop=flop, name=layer.name + ":dgrad")
-            ops.conv2d(dy, layer.w_dg, g, cin=layer.dg_red, cout=layer.cinp, coutp=layer.dg_rows, ipe=self.B,
-                       ks=layer.ks, stride=1, pad=layer.ks - 1 - layer.pad, dilate=(layer.stride == 2),
-                       in_coff=o.coff, out_coff=x.coff, res=res, res_coff=x.coff, res_mode=res_mode,
-                       drop_p=x.drop_p if res_mode >= hip.RES_DRELU else 0.0)
+            ops.conv2d(dy, layer.w_dg, g, res=res, res_coff=x.coff, res_mode=res_mode,
+                       drop_p=x.drop_p if res_mode >= hip.RES_DRELU else 0.0, **kw)
             x.set_grad(g)
+
+    def _dgrad_with_bn_reduce(self, x, dy, w_dg, g, kw, flop, name, bias=None):
+        """x = relu(BatchNorm(z)) with this conv as its only consumer: run the data gradient with PMOE_RES_DBN -- the epilogue
+        reads z, masks the gradient with the recomputed ReLU decision and leaves sum(g), sum(g * xhat) per channel, i.e. the
+        reduce pass of that BatchNorm's backward (_bn_bwd then only finalizes and applies).  False = not applicable here (other
+        dtype / kernel / geometry): the caller runs the plain data gradient."""
+        src = x.bn_src
+        if (src is None or x.grad is not None or x.act != hip.ACT_NONE or x.base is not None or x.coff != 0
+                or kw["ks"] != 3 or kw["dilate"] or x.t.dtype != torch.bfloat16):
+            return False
+        z, bnl, coef, rpe = src
+        if bnl.C != kw["cout"] or z.t.shape != x.t.shape:
+            return False
+        common = dict(res=z.t, res_mode=hip.RES_DBN, bn_coef=coef, bn_ipe=self.B, bias=bias, **kw)
+        if ops.conv2d(dy, w_dg, g, plan_only=True, **common) not in (1107, 5007):
+            return False
+        n, h, w = dy.shape[0], dy.shape[1], dy.shape[2]
+        rows = ops.conv2d_stat_rows(n, h, w, h, w, kw["cin"], kw["cout"], kw["coutp"], kw["ipe"], 3, 1, 1, self.dtype,
+                                    in_ld=dy.shape[-1], out_ld=g.shape[-1])
+        stats = torch.empty(rows, 2, kw["coutp"], dtype=F32, device=self.dev)
+        ops.set_meta(flop=flop, name=name + ":dgrad+bnred")
+        ops.conv2d(dy, w_dg, g, stats=stats, **common)
+        x.set_grad(g)
+        x.bn_part = (stats, rows // self.E)
+        return True
 
     @staticmethod
     def _nparts(rpe):
@@ -528,7 +560,9 @@ class ExpertGroupEngine:
         """scale/shift/mean/invstd [E,C] of a BatchNorm: batch statistics from partial sums (train) or the
         running buffers (eval); updates the running statistics in train mode (momentum, unbiased var)."""
         E, C_ = self.E, layer.C
-        scale, shift, mean, invstd = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(4))
+        # one block [mean | invstd | scale | shift][E][C]: the layout PMOE_RES_DBN's data-gradient epilogue reads
+        coef = self._last_coef = torch.empty(4, E, C_, dtype=F32, device=self.dev)
+        mean, invstd, scale, shift = coef[0], coef[1], coef[2], coef[3]
         if self.training:
             if part is None:
                 nparts = self._nparts(rpe)
@@ -574,6 +608,9 @@ class ExpertGroupEngine:
             ops.bn_apply(z.t, res.t if res is not None else None, y.t, scale, shift, mean, rpe, E, C_, relu, y_coff=y.coff)
         if self.debug_acts is not None and relu:
             self.debug_acts[layer.name] = (y.t, y.coff, C_)
+        if (relu and res is None and out is None and self.taping and self.training and self.bn_reduce_in_dgrad
+                and self.dtype == torch.bfloat16 and z.needs_grad):
+            y.bn_src = (z, layer, self._last_coef, rpe)
         y.needs_grad = z.needs_grad or layer.trainable or (res is not None and res.needs_grad)
         if out is not None and y.needs_grad:
             out.needs_grad = True
@@ -591,9 +628,28 @@ class ExpertGroupEngine:
         if dy is None:
             return
         E, C_ = self.E, layer.C
+        nb = z.t.numel() * z.t.element_size()
+        if y.bn_part is not None:
+            # the consumer's data gradient (PMOE_RES_DBN) already masked dy and reduced it: finalize + apply only
+            part, nparts = y.bn_part
+            if part.shape[2] != C_:
+                raise RuntimeError("BatchNorm reductions from the data-gradient epilogue: channel count mismatch")
+            part, nparts = self._fold_parts(part.view(E, nparts, 2 * C_), nparts, 2 * C_)
+            c1, c2 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(2))
+            dgamma, dbeta, store = self._bn_grad_views(layer)
+            ops.bn_bwd_finalize(part, nparts, rpe, dgamma, dbeta, c1, c2, E, C_)
+            if store is not None:
+                store()
+            if z.needs_grad:
+                if z.grad is not None:
+                    raise RuntimeError("BN input consumed twice")
+                dz = torch.empty_like(z.t)
+                ops.set_meta(name=layer.name, bytes=nb * 3)
+                ops.bn_bwd_apply(dy, None, z.t, mean, invstd, scale, shift, c1, c2, dz, None, rpe, E, C_, False)
+                z.set_grad(dz)
+            return
         nparts = self._nparts(rpe)
         part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
-        nb = z.t.numel() * z.t.element_size()
         want_res = res is not None and res.needs_grad
         # residual blocks: the reduce pass also stores the masked gradient (the residual branch needs it anyway), and the
         # apply pass then reads that instead of dy AND the saved output: one tensor pass less per block
@@ -827,10 +883,12 @@ class ExpertGroupEngine:
                     if x.grad is not None or x.act != hip.ACT_NONE:
                         raise RuntimeError("gate-folded conv: its input must have this conv as the only consumer")
                     g = torch.empty_like(x.t)
-                    ops.set_meta(flop=flop, name=layer.name + ":dgrad")
-                    ops.conv2d(dy, wd, g, cin=layer.dg_red, cout=layer.cinp, coutp=layer.dg_rows, ipe=1, ks=layer.ks,
-                               stride=1, pad=layer.ks - 1 - layer.pad, bias=dgap)
-                    x.set_grad(g)
+                    kw = dict(cin=layer.dg_red, cout=layer.cinp, coutp=layer.dg_rows, ipe=1, ks=layer.ks, stride=1,
+                              pad=layer.ks - 1 - layer.pad, dilate=False, in_coff=0, out_coff=0)
+                    if not self._dgrad_with_bn_reduce(x, dy, wd, g, kw, flop, layer.name, bias=dgap):
+                        ops.set_meta(flop=flop, name=layer.name + ":dgrad")
+                        ops.conv2d(dy, wd, g, bias=dgap, **kw)
+                        x.set_grad(g)
             self.tape.append(bwd)
         return o, stats
 

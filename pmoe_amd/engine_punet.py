@@ -473,6 +473,6 @@ class PredictiveUnetEngine(PUNetEngine):
 
     def backward(self, tape_state, *douts):
         self._accum_done = False
-        n = sum(p.numel() for p in self.flat_params)
-        self._acc = torch.zeros(n, dtype=F32, device=tape_state["dev"])
+        self._layout_arena()                             # (the accumulator has the arena's padded length)
+        self._acc = torch.zeros(self._arena_numel, dtype=F32, device=tape_state["dev"])
         return super().backward(tape_state, *douts)

@@ -18,7 +18,7 @@ _lib = None
 ABI_VERSION = 300            # include/pmoe_hip.h: PMOE_ABI_VERSION
 DT_BF16, DT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
-RES_NONE, RES_ADD, RES_DRELU, RES_DELU, RES_DTANH, RES_DSIGMOID = 0, 1, 2, 3, 4, 5
+RES_NONE, RES_ADD, RES_DRELU, RES_DELU, RES_DTANH, RES_DSIGMOID, RES_DBN = 0, 1, 2, 3, 4, 5, 6
 # derivative mode that undoes each activation in the data-gradient epilogue (from the layer's saved output)
 RES_OF_ACT = {ACT_RELU: RES_DRELU, ACT_ELU: RES_DELU, ACT_TANH: RES_DTANH, ACT_SIGMOID: RES_DSIGMOID}
 ACT_BY_NAME = {"relu": ACT_RELU, "elu": ACT_ELU, "tanh": ACT_TANH, "sigmoid": ACT_SIGMOID}
@@ -43,6 +43,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("res_mode", C.c_int32),
         ("drop_p", C.c_float), ("seed", C.c_uint64), ("dtype", C.c_int32),
         ("w_fp8", C.c_int32), ("in_scale", C.c_float), ("out_scale", C.c_void_p),
+        ("bn_coef", C.c_void_p), ("bn_ipe", C.c_int32),
     ]
 
 

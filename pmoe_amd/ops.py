@@ -28,7 +28,7 @@ def _nhwc(t, name):
 
 def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=False, in_shared=False,
            in_coff=0, out_coff=0, res=None, res_coff=0, res_mode=hip.RES_NONE, bias=None, act=hip.ACT_NONE,
-           drop_p=0.0, seed=0, stats=None, plan_only=False, out_scale=None, in_scale=1.0):
+           drop_p=0.0, seed=0, stats=None, plan_only=False, out_scale=None, in_scale=1.0, bn_coef=None, bn_ipe=0):
     """out[..., out_coff:out_coff+cout] = epilogue(conv(x[..., in_coff:in_coff+cin], w)).
     ``x`` [Nin,H,W,ldx], ``out`` [N,Ho,Wo,ldo] preallocated; also used for dgrad and grouped GEMM.
     ``plan_only``: launch nothing, return the kernel-instantiation code of ``pmoe_conv2d_plan`` (include/pmoe_hip.h)."""
@@ -55,6 +55,15 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
     d.drop_p, d.seed, d.dtype = float(drop_p), int(seed), dt(x)
     if w_fp8:
         d.w_fp8, d.in_scale, d.out_scale = 1, float(in_scale), ptr(out_scale, "out_scale", torch.float32)
+    if d.res_mode == hip.RES_DBN:
+        # data gradient into relu(BatchNorm(z)): res = z, bn_coef = [4][n / bn_ipe][cout] (mean, invstd, gamma*invstd, beta);
+        # the launch masks the gradient and leaves the BatchNorm backward's channel reductions in `stats`
+        nset = n // (bn_ipe or ipe)
+        if bn_coef is None or bn_coef.dtype != torch.float32 or tuple(bn_coef.shape) != (4, nset, cout):
+            raise ValueError(f"conv2d: RES_DBN needs bn_coef [4, {nset}, {cout}] f32")
+        if stats is None and not plan_only:
+            raise ValueError("conv2d: RES_DBN writes the BatchNorm-backward reductions to `stats`")
+        d.bn_coef, d.bn_ipe = ptr(bn_coef, "bn_coef", torch.float32), int(bn_ipe or ipe)
     if in_shared and nin != ipe:
         raise ValueError("conv2d: shared input must hold exactly ipe images")
     if not in_shared and nin != n:

@@ -170,7 +170,10 @@ def run_parity_case(name, dtype=torch.float32, check_grads=True, verbose=True, f
 
 
 # ---- gradient parity with the discrete decisions forced (tests/forced_masks.py): flat bounds, every expert, every tensor
-FORCED_GRAD_TOL = 1e-3        # rel-L2 of a gradient tensor against the float64 oracle run on the HIP path's ReLU / max-pool decisions
+# rel-L2 of a gradient tensor against the float64 oracle run on the HIP path's ReLU / max-pool decisions.  Measured on the nine
+# golden cases (profiles/r03_parity_report.log): worst tensor of >= 64 elements 5.4e-5 (a 3-tap ECA filter: heavy
+# cancellation), median 4e-6 .. 2e-5; tensors of a handful of elements (a [1] bias) up to 9e-4 -> 10 x the bound for those.
+FORCED_GRAD_TOL = 2e-4
 FLIP_ZONE = 1e-4              # a disagreement between the float64 oracle's own decision and the HIP one must sit this close to the tie
 
 
@@ -221,7 +224,7 @@ def run_forced_case(name, verbose=True, tol=FORCED_GRAD_TOL):
         errs.append((rel_l2(p.grad, ref), k))
     errs.sort()
     report["grad_median_rel_l2"], report["grad_worst"] = errs[len(errs) // 2][0], errs[-1]
-    bad = [(f"{e:.2e}", k) for e, k in errs if e > tol]
+    bad = [(f"{e:.2e}", k) for e, k in errs if e > (tol if named[k].numel() >= 64 else 10 * tol)]
     assert not bad, f"{name}: {len(bad)} gradient tensors beyond {tol:g} of the float64 oracle on the same decisions: {bad[-6:]}"
     # golden slices / norms of the REFERENCE: valid yardstick for the experts whose decisions all agree
     flipped = {e for e, *_ in log}

@@ -149,9 +149,7 @@ def _run_model(name, fp8):
 def test_model_fp8_forward_within_the_emulated_policy(name):
     """E2E forward of the mixture with the fp8 policy (train-mode BatchNorm: the policy's fixed activation scale assumes
     normalised, O(1) conv inputs): per output, the distance to the float64 oracle is at most 1.25 x that of the CPU oracle
-    with bf16 storage + the same fp8 policy emulated.  (The eval-mode golden g2 runs on SYNTHETIC running statistics that do
-    not normalise anything -- activations reach |8| and beyond the e4m3 range at scale 16 -- and is not a meaningful fp8
-    case: there the 4 `speeds` values were 1.8 x the emulation's worst draw.)"""
+    with bf16 storage + the same fp8 policy emulated.  (The eval-mode golden g2 has its own test below.)"""
     from tests.parity_util import BF16_SLACK, bf16_bounds, emul_worst
     g, ocfg, oracle, model, inp, dev = _run_model(name, True)
     with torch.no_grad():
@@ -172,6 +170,31 @@ def test_model_fp8_forward_within_the_emulated_policy(name):
     with torch.no_grad():
         d2, _ = model(dev["images"], dev["speed"], dev["command"])
     assert not torch.equal(d2.hip_params[1], mean)
+
+
+def test_model_fp8_eval_agent_shape_layer_by_layer():
+    """The eval-mode golden g2 (B=1, 224x224, the agent's shape) under the fp8 policy -- the case that failed its output bound
+    in round 2 and was dropped with the explanation "activations beyond 28 saturate".  That explanation was wrong and is
+    ASSERTED wrong here: no conv input of the HIP path or of the emulated policy exceeds the e4m3 range at the policy's
+    scale (the largest is ~24).  What the HIP kernels must do is implement the policy, and that is checked where the
+    statistic is meaningful -- per BatchNorm output (1e5..1e6 elements each), the HIP path's rel-L2 distance to the float64
+    oracle is the emulated policy's own distance (measured ratio 0.98-1.04 on all 17 layers; bound 1.15).  The four
+    `speeds` values the old check took a maximum over inherit ~10 % of feature noise from either side; two equally faithful
+    implementations of the policy land 0.09 and 0.24 from the float64 value there (and 0.17 from each other), so the
+    outputs are bounded by 3 x the emulation's own error, no tighter."""
+    from tests.fp8_layerwise import layerwise
+    rows, outs = layerwise("g2_moe_e4_b1_224_eval", True)
+    assert len(rows) == 17
+    for name, d_hip, d_emul, d_between, sat_hip, sat_emul, mx in rows:
+        assert sat_hip == 0 and sat_emul == 0 and mx < 28.0, (name, sat_hip, sat_emul, mx)
+        assert d_hip <= 1.15 * d_emul + 1e-3, (name, d_hip, d_emul)
+    print("fp8 eval g2:", {k: "HIP %.2e | emulation %.2e | between %.2e" % v for k, v in outs.items()})
+    for k, (e_hip, e_emul, _) in outs.items():
+        assert e_hip <= 3.0 * e_emul, (k, e_hip, e_emul)
+    # control: the same table without the fp8 policy (bf16 storage only) is ten times closer, layer by layer
+    rows16, _ = layerwise("g2_moe_e4_b1_224_eval", False)
+    for (name, d8, *_), (_, d16, e16, *_) in zip(rows[1:], rows16[1:]):
+        assert d16 <= 1.15 * e16 + 1e-3 and d16 < 0.5 * d8, (name, d16, e16, d8)
 
 
 def test_model_fp8_train_step():

@@ -193,6 +193,63 @@ def test_conv_baseline_layer_shapes_bf16(case, plan):
     _conv_case(case, torch.bfloat16, plan)
 
 
+# (E_bn, images per BN set, channels, H, W, conv runs per image?, bias?) -> kernel code
+DBN_CASES = [
+    ((2, 2, 64, 128, 128, False, False), 1107),        # layer1 conv2 data gradient: conv3x3_resdma_kernel, persistent workgroups
+    ((2, 3, 64, 64, 96, True, True), 1107),            # stem conv2 (ECA gate folded: one "expert" per image, per-image bias)
+    ((1, 4, 128, 64, 64, False, False), 5007),         # layer2: conv3x3_dma_kernel
+    ((2, 16, 512, 16, 16, False, False), 5007),        # layer4: one image per tile row group, 4 output-channel blocks
+    ((1, 5, 256, 40, 24, False, False), 5007),         # ragged tiles
+]
+
+
+@pytest.mark.parametrize("case,plan", DBN_CASES)
+def test_conv_dgrad_with_batchnorm_reductions(case, plan):
+    """PMOE_RES_DBN (round 3): the data gradient into a = relu(BatchNorm(z)) masks itself with the recomputed ReLU decision
+    and leaves the BatchNorm backward's two channel reductions in `stats`.  Against the plain data gradient of the same
+    launch masked on the host (BIT-identical: same accumulators, the mask only selects) and host sums of that."""
+    Ebn, ipb, C, H, W, per_image, with_bias = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    N = Ebn * ipb
+    E = N if per_image else Ebn
+    ipe = 1 if per_image else ipb
+    BF = torch.bfloat16
+    dy = rnd((N, C, H, W), g, BF)
+    z = rnd((N, C, H, W), g, BF, 2.0) + 0.3
+    ws = [rnd((C, C, 3, 3), g, torch.float32, (2.0 / (C * 9)) ** 0.5) for _ in range(E)]
+    _, wd, _keep = pack(ws, 3, BF, want_dgrad=True)
+    coef = torch.empty(4, Ebn, C)
+    coef[0] = torch.randn(Ebn, C, generator=g) * 0.5 + 0.3             # mean
+    coef[1] = torch.rand(Ebn, C, generator=g) + 0.5                     # invstd
+    coef[2] = coef[1] * (torch.randn(Ebn, C, generator=g) * 0.5 + 1.0)  # gamma * invstd (some negative gammas too)
+    coef[3] = torch.randn(Ebn, C, generator=g) * 0.3                    # beta
+    coefd = coef.to(DEV)
+    bias = (torch.randn(E, r64(C), generator=g) * 0.05).to(DEV) if with_bias else None
+    dyd, zd = nhwc(dy, C, BF), nhwc(z, C, BF)
+    kw = dict(cin=C, cout=C, coutp=r64(C), ipe=ipe, ks=3, stride=1, pad=1, bias=bias)
+    plain = torch.empty(N, H, W, C, dtype=BF, device=DEV)
+    ops.conv2d(dyd, wd, plain, **kw)
+    got = torch.full((N, H, W, C), 7.0, dtype=BF, device=DEV)
+    common = dict(res=zd, res_mode=hip.RES_DBN, bn_coef=coefd, bn_ipe=ipb, **kw)
+    assert ops.conv2d(dyd, wd, got, plan_only=True, **common) == plan
+    rows = ops.conv2d_stat_rows(N, H, W, H, W, C, C, r64(C), ipe, 3, 1, 1, BF)
+    stats = torch.full((rows, 2, r64(C)), 5.0, device=DEV)
+    ops.conv2d(dyd, wd, got, stats=stats, **common)
+    cb = coef.repeat_interleave(ipb, dim=1).view(4, N, 1, 1, C)          # per image
+    zf = zd.float().cpu()
+    d = zf - cb[0]
+    mask = (d * cb[2] + cb[3]) > 0
+    assert 0.2 < mask.float().mean() < 0.8
+    want = torch.where(mask, plain.float().cpu(), torch.zeros(()))
+    assert torch.equal(got.float().cpu(), want), "masked data gradient differs from the plain one"
+    st = stats.view(Ebn, rows // Ebn, 2, r64(C)).sum(1).cpu()
+    s1 = want.view(Ebn, -1, C).sum(1)
+    s2 = (want * d * cb[1]).view(Ebn, -1, C).sum(1)
+    for nm, a, b in (("sum g", st[:, 0, :C], s1), ("sum g*xhat", st[:, 1, :C], s2)):
+        scale = b.abs().max().item()
+        assert ((a - b).abs().max().item() <= 2e-4 * scale + 1e-3), (nm, (a - b).abs().max().item(), scale)
+
+
 def test_conv_resident_pingpong_fallback(monkeypatch):
     """PMOE_RES_DMA=0 (read per launch) routes the 64-channel layers back to conv3x3_res_kernel<7>, the kernel that also
     serves shapes the LDS-DMA variant declines: same parity bar, plan code 1007."""
