@@ -434,6 +434,8 @@ def main():
                 return r.replace("<bf16,", "<bf16+e4m3,"), m.replace(f"E{tname}Ev8ConvArgs", "E3fp8Ev8ConvArgs"), n
             if code == 5007:                      # LDS-DMA staged 3x3 kernel (conv_dma.hip)
                 return "conv3x3_dma_kernel", "void (anonymous namespace)::conv3x3_dma_kernel", 1
+            if code == 5207:                      # ... its stride-2 forward sibling
+                return "conv3x3s2_dma_kernel", "void (anonymous namespace)::conv3x3s2_dma_kernel", 1
             four = code >= 4000
             code %= 4000
             if code == 3000:

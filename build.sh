@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p ../../build
 pids=()
 for f in conv_igemm conv_dma conv_c16 conv_c1x1 conv_res conv_wgrad gemm_skinny elementwise stem_tail heads punet stage1 optim preprocess api; do
-  if [ ! -f ../../build/$f.o ] || [ $f.hip -nt ../../build/$f.o ] || [ common.h -nt ../../build/$f.o ] || [ kernels.h -nt ../../build/$f.o ] || [ conv_common.h -nt ../../build/$f.o ] || [ ../../include/pmoe_hip.h -nt ../../build/$f.o ]; then
+  if [ ! -f ../../build/$f.o ] || [ $f.hip -nt ../../build/$f.o ] || [ common.h -nt ../../build/$f.o ] || [ kernels.h -nt ../../build/$f.o ] || [ conv_common.h -nt ../../build/$f.o ] || [ conv_dma_epilogue.inc -nt ../../build/$f.o ] || [ ../../include/pmoe_hip.h -nt ../../build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o ../../build/$f.o &
     pids+=($!)
   fi

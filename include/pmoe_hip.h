@@ -107,6 +107,7 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
  *   1107                     conv3x3_resdma_kernel                 (resident filter bank, halo patches by LDS-DMA, conv_res.hip)
  *   2000 + LOG_RB            conv_igemm_lite_kernel<T, LOG_RB>     (8-wave 256 x 128 tile, two workgroups per CU)
  *   5007                     conv3x3_dma_kernel                    (LDS-DMA staged 3x3 stride-1 kernel, >= 128 channels, conv_dma.hip)
+ *   5207                     conv3x3s2_dma_kernel                  (its stride-2 forward sibling: parity planes gathered by the DMA, conv_dma.hip)
  *   8000 + one of the above  the same tile with e4m3 operands (w_fp8)
  *   LOG_RB*100 + WM*10 + WN  conv_igemm_kernel<T, LOG_RB, WM, WN>  (halo-patch implicit GEMM, conv_igemm.hip)
  *   4000 + the latter        the four parity-class launches of a stride-2 3x3 data gradient */

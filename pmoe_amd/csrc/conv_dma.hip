@@ -152,6 +152,17 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
     const int nchunks = a.Cin / CK;
     const int T = nchunks * 9;
 
+    // PMOE_RES_DBN (data gradient into relu(BatchNorm(z)) with the BatchNorm-backward reductions in the epilogue): the 8 vectors
+    // of z this thread will need in the read-out are requested at the first tap of the LAST chunk and arrive under its MFMAs
+    // (read in the epilogue they cost +1.3 ms per step on the 9 launches: every wave waiting on its own loads between two
+    // barriers).  Plain global loads share the in-order vmcnt counter with the DMA stream: the wait of the next tap lets them
+    // stay in flight (+8); the one after retires them (hipcc may order them before OR after that tap's weight-tile request --
+    // different address spaces -- so only the first wait can count on their position).
+    const bool zpre_on = a.res_mode == PMOE_RES_DBN && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f;
+    v4i zpre[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) zpre[u] = v4i{0, 0, 0, 0};
+
     // ---- prologue: patch of chunk 0, weight tiles of taps 0 and 1
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -170,6 +181,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
             // are outstanding (vmcnt counts in issue order)
             const bool prev_piece = tap >= 2 && tap <= 7 && more && (tap - 2) < my_pieces;
             if (tt + 1 >= T) VMCNT(0);
+            else if (zpre_on && !more && tap == 1) VMCNT(10);      // W(tt) is older than both W(tt+1) and the 8 loads of tap 0
             else if (prev_piece) VMCNT(3);
             else VMCNT(2);
             __builtin_amdgcn_s_barrier();                // every wave's share of tap tt (and of this chunk's patch) is in LDS
@@ -181,6 +193,20 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
                 int ntap = tap + 2, nc0 = c0;
                 if (ntap >= 9) { ntap -= 9; nc0 += CK; }
                 dma_w((tt + 2) & (RING - 1), ntap, nc0);
+            }
+            if (tap == 0 && zpre_on && !more) {
+                const int zc = tid & 15, zr = tid >> 4;      // the read-out's (cc, pr): 16 channel vectors x 32 pixel rows of threads
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = zr + u * 32;
+                    const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+                    const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
+                    // EVERY wave issues all 8 loads (the counted waits below assume exactly 8): lanes without a pixel read the
+                    // tensor's first vector, which the read-out never uses
+                    const bool ok = cout0 + zc * VE < a.Cout && n < n_end && oy < a.Ho && ox < a.Wo;
+                    const size_t off = ok ? (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.res_ld + a.res_coff + cout0 + zc * VE : (size_t)0;
+                    zpre[u] = ldg16((const bf16*)a.res + off);
+                }
             }
             const char* wt = wring + (tt & (RING - 1)) * WSLOT;
             const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RB;
@@ -210,201 +236,241 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
         }
     }
 
-    LAP(1)                                               // main loop
-    // ---- epilogue: D[cout][pixel] -> LDS f32 [128 pixel rows][BN] per half (16-byte units XOR-swizzled by pixel) -> whole
-    // 16-byte channel vectors per pixel, with bias / residual / activation / dropout / BatchNorm partial sums fused
-    constexpr int UPR = BN / 4, BMH = BM / 2;
-    float* stg = reinterpret_cast<float*>(smem);
-    constexpr int CPO = BN / VE, PROWS = NTHR / CPO;
-    const int cc = tid % CPO, pr = tid / CPO;
-    const int cout = cout0 + cc * VE;
-    const bool cvalid = cout < a.Cout;
-    float bias[VE];
-#pragma unroll
-    for (int i = 0; i < VE; ++i) bias[i] = (a.bias && cvalid) ? a.bias[(size_t)e * a.CoutP + cout + i] : 0.f;
-    float s1[VE], s2[VE];
-#pragma unroll
-    for (int i = 0; i < VE; ++i) s1[i] = s2[i] = 0.f;
-    const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    bf16* out = (bf16*)a.out;
-    const bf16* res = (const bf16*)a.res;
-    // PMOE_RES_DBN: this launch is the data gradient into a = relu(BatchNorm(z)); res = z.  The epilogue masks the gradient with
-    // the recomputed ReLU decision and leaves the BatchNorm backward's two channel reductions in `stats` (s2 = sum g * xhat)
-    const bool dbn = a.res_mode == PMOE_RES_DBN;
-    float bmu[VE], bis[VE], bsc[VE], bsh[VE];
-#pragma unroll
-    for (int i = 0; i < VE; ++i) bmu[i] = bis[i] = bsc[i] = bsh[i] = 0.f;
-    if (dbn && cvalid) {
-        const int nset = a.N / a.bn_ipe;
-        const float* b = a.bn + (size_t)((e * a.ipe) / a.bn_ipe) * a.Cout + cout;
-#pragma unroll
-        for (int i = 0; i < VE; ++i) {
-            bmu[i] = b[i]; bis[i] = b[(size_t)nset * a.Cout + i];
-            bsc[i] = b[(size_t)2 * nset * a.Cout + i]; bsh[i] = b[(size_t)3 * nset * a.Cout + i];
-        }
+#define DMA_ZPRE zpre
+#define DMA_ZPRE_ON zpre_on
+#include "conv_dma_epilogue.inc"
+#undef DMA_ZPRE
+#undef DMA_ZPRE_ON
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 3: the three stride-2 3x3 forward convolutions (ResNet layer2-4 `.0.conv1`, torchvision BasicBlock with stride 2:
+// model/blocks/backbone.py:57-70) on the same LDS-DMA structure.  They ran on the generic register-staged kernel at
+// 0.14 of the matrix peak with 1.85x the compulsory HBM traffic.
+//
+// A stride-2 3x3 convolution is four stride-1 convolutions over the input's PARITY PLANES: input row 2b+p is row b of plane
+// p; output row oy reads (plane 1, block oy-1) for ky = 0, (plane 0, block oy) for ky = 1, (plane 1, block oy) for ky = 2,
+// the same along x -- plane (py,px) carries (1+py)(1+px) of the 9 taps.  No plane-split copy of the activation is needed:
+// an LDS-DMA lane reads its 16 bytes from ANY global address, so the patch of a plane is gathered straight out of the
+// NHWC tensor with a pixel step of 2 (whole 128-byte channel rows per pixel; the neighbouring rows belong to the other
+// planes of the same workgroup: L2 hits).  A step = (plane, 64-channel chunk): its halo patch [(TH+1) x (TW+1) blocks]
+// by DMA into one of THREE buffers, then its 4 / 2 / 2 / 1 taps.  Steps are as short as one tap, so the patch of step s+2
+// is requested at the first tap of step s (its buffer was step s-1's), and the weight ring has 3 slots (tile t+2 goes into
+// the slot read at tap t-1, released by the barrier of tap t).  Tiles are 16 x 16 output pixels: 17 x 17 blocks = 37 KiB per
+// patch, 3 patches + 3 weight tiles = 159 KiB.  The in-order `vmcnt` bookkeeping of this irregular schedule is done with
+// scalar sequence numbers: every DMA instruction the wave issues is counted, the count at the last instruction of each weight
+// tile / patch is remembered, and a tap waits until at most (issued - needed) instructions are outstanding.
+__device__ __forceinline__ void vm_wait_upto(int n) {     // s_waitcnt vmcnt(min(n, 16)): the immediate must be a constant
+    switch (n) {
+        case 0: VMCNT(0); break; case 1: VMCNT(1); break; case 2: VMCNT(2); break; case 3: VMCNT(3); break;
+        case 4: VMCNT(4); break; case 5: VMCNT(5); break; case 6: VMCNT(6); break; case 7: VMCNT(7); break;
+        case 8: VMCNT(8); break; case 9: VMCNT(9); break; case 10: VMCNT(10); break; case 11: VMCNT(11); break;
+        case 12: VMCNT(12); break; case 13: VMCNT(13); break; case 14: VMCNT(14); break; case 15: VMCNT(15); break;
+        default: VMCNT(16); break;
     }
-    // fused tail of one 8-channel vector v of output pixel p of the tile
-    auto finish = [&](int p, float* v) {
-        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
-        const int n = n0 + pn, oy = oy0 + my, ox = ox0 + mx;
-        if (!(cvalid && n < n_end && oy < a.Ho && ox < a.Wo)) return;
-            const size_t opix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+}
+
+constexpr int RING3 = 3;
+
+__global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a, const int pbuf_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    STAMP_INIT
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nblk = a.CoutP / BN;
+    const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned mb = flat / nblk;
+    const int nb = (int)(flat % nblk);
+    int t = (int)mb;
+    const int px_t = t % a.tiles_x; t /= a.tiles_x;
+    const int py_t = t % a.tiles_y; t /= a.tiles_y;
+    const int ng = t % a.n_groups;
+    const int e = t / a.n_groups;
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int PW = TW + 1, PH = TH + 1;                  // blocks: one halo row / column on the top / left only
+    const int NPIX = a.TN * PH * PW;
+    const int NPIECE = (NPIX + 7) >> 3;
+    const int n0 = e * a.ipe + ng * a.TN, n_end = (e + 1) * a.ipe;
+    const int oy0 = py_t * TH, ox0 = px_t * TW;
+    const int cout0 = nb * BN;
+
+    char* wring = smem + 3 * pbuf_bytes;
+
+    const bf16* inb = (const bf16*)a.in + (size_t)n0 * a.H * a.W * a.in_ld + a.in_coff;
+    long long in_bytes = ((long long)(n_end - n0) * a.H * a.W * a.in_ld - a.in_coff) * 2;
+    if (in_bytes > 0x7ff00000ll) in_bytes = 0x7ff00000ll;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, (int)in_bytes, 0x00020000);
+    const bf16* wb = (const bf16*)a.w + ((size_t)e * a.CoutP + cout0) * 9 * a.Cin;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, BN * 9 * a.Cin * 2, 0x00020000);
+
+    // ---- per-lane source offsets of this wave's patch pieces: pixel (2 By, 2 Bx) of the block; the plane's (py, px) and the
+    // channel chunk travel in the scalar offset.  4 validity bits per piece: rows 2By / 2By+1 and columns 2Bx / 2Bx+1 inside
+    // the image (odd image sides: the last block has only its plane-0 row / column)
+    constexpr int OOB = 0x7ff80000;
+    int pvoff[6];
+    unsigned vbits = 0;
 #pragma unroll
-            for (int i = 0; i < VE; ++i) v[i] += bias[i];
-            float xh[VE];
-            if (a.res_mode) {
-                float rv[VE];
-                unpack16<bf16>(ldg16(res + opix * a.res_ld + a.res_coff + cout), rv);
-                if (dbn) {
+    for (int i = 0; i < 6; ++i) {
+        const int pp = ((wave + 8 * i) << 3) + (lane >> 3);
+        const int jj = lane & 7;
+        const int bx = pp % PW;
+        const int rowq = pp / PW;
+        const int by = rowq % PH, pn = rowq / PH;
+        const int By = oy0 - 1 + by, Bx = ox0 - 1 + bx;
+        const bool okb = pp < NPIX && n0 + pn < n_end && By >= 0 && Bx >= 0;
+        pvoff[i] = okb ? ((((pn * a.H + 2 * By) * a.W + 2 * Bx) * a.in_ld) << 1) + ((jj ^ cswz(bx)) << 4) : OOB;
+        const unsigned vb = (okb && 2 * By < a.H ? 1u : 0u) | (okb && 2 * By + 1 < a.H ? 2u : 0u) |
+                            (2 * Bx < a.W ? 4u : 0u) | (2 * Bx + 1 < a.W ? 8u : 0u);
+        vbits |= vb << (4 * i);
+    }
+    int wvoff[2];
 #pragma unroll
-                    for (int i = 0; i < VE; ++i) {
-                        const float d = rv[i] - bmu[i];
-                        v[i] = (d * bsc[i] + bsh[i]) > 0.f ? v[i] : 0.f;
-                        xh[i] = d * bis[i];
-                    }
-                } else
-                if (a.res_mode == PMOE_RES_ADD) {
+    for (int i = 0; i < 2; ++i) {
+        const int row = ((wave + 8 * i) << 3) + (lane >> 3);
+        wvoff[i] = ((row * 9 * a.Cin) << 1) + (((lane & 7) ^ cswz(row)) << 4);
+    }
+    const int my_pieces = (NPIECE - wave + 7) >> 3;
+
+    // plane index pl: 0 = (py 1, px 1) 4 taps, 1 = (1, 0) 2 taps, 2 = (0, 1) 2 taps, 3 = (0, 0) 1 tap
+    auto dma_patch = [&](int buf, int pl, int c0) {      // all pieces of this wave for step (pl, c0)
+        const int py = pl < 2, px = (pl & 1) == 0;
+        const int soff = (c0 << 1) + (((py * a.W + px) * a.in_ld) << 1);
 #pragma unroll
-                    for (int i = 0; i < VE; ++i) v[i] += rv[i];
-                } else if (a.res_mode == PMOE_RES_DRELU) {
-#pragma unroll
-                    for (int i = 0; i < VE; ++i) v[i] = rv[i] > 0.f ? v[i] * keep_scale : 0.f;
-                } else if (a.res_mode >= PMOE_RES_DELU) {               // saved output y = act(z) * mask * keep_scale
-#pragma unroll
-                    for (int i = 0; i < VE; ++i) {
-                        const float y = rv[i] * (1.f / keep_scale);
-                        const float d = act_deriv_from_output(a.res_mode, y);
-                        v[i] = (a.drop_p > 0.f && rv[i] == 0.f) ? 0.f : v[i] * d * keep_scale;
-                    }
-                }
+        for (int i = 0; i < 6; ++i)
+            if (i < my_pieces) {
+                const bool ok = ((vbits >> (4 * i + py)) & 1u) && ((vbits >> (4 * i + 2 + px)) & 1u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(smem + buf * pbuf_bytes + ((wave + 8 * i) << 10)), 16,
+                                                         ok ? pvoff[i] : OOB, soff, 0, 0);
             }
-            if (a.act == PMOE_ACT_RELU) {
-#pragma unroll
-                for (int i = 0; i < VE; ++i) v[i] = fmaxf(v[i], 0.f);
-            } else if (a.act != PMOE_ACT_NONE) {                     // elu / tanh / sigmoid
-#pragma unroll
-                for (int i = 0; i < VE; ++i) v[i] = act_apply(a.act, v[i]);
-            }
-            if (a.drop_p > 0.f && a.res_mode < PMOE_RES_DRELU) {
-                const unsigned long long base = (unsigned long long)opix * (unsigned)a.Cout + cout;
-#pragma unroll
-                for (int i = 0; i < VE; ++i) v[i] = hash_uniform(a.seed, base + i) >= a.drop_p ? v[i] * keep_scale : 0.f;
-            }
-            const v4i pk = pack16<bf16>(v);
-#ifndef PMOE_STAMP
-            if (a.stats) {
-                float rr[VE];
-                unpack16<bf16>(pk, rr);
-                if (dbn) {
-#pragma unroll
-                    for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * xh[i]; }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < VE; ++i) { s1[i] += rr[i]; s2[i] += rr[i] * rr[i]; }
-                }
-            }
-#endif
-            stg16(out + opix * a.out_ld + a.out_coff + cout, pk);
     };
-    // bf16 staging is exact when nothing is added to the accumulator before it is rounded (forward + statistics, plain and
-    // ReLU'-masked data gradients): ONE phase, all 8 waves write their 64 x 64 sub-tiles as bf16 rows [256 px][256 B]
-    // (16-byte chunks XOR-swizzled by pixel), one barrier, 8 vectors per thread -- half the LDS bytes and half the
-    // barriers of the f32 path below
-    const bool fast_epi = !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f &&
-                          (a.res_mode == PMOE_RES_NONE || a.res_mode == PMOE_RES_DRELU || a.res_mode == PMOE_RES_DBN);
-    if (fast_epi) {
-        __syncthreads();
+    auto dma_w = [&](int slot, int tap, int c0) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(wring + slot * WSLOT + ((wave + 8 * i) << 10)), 16,
+                                                     wvoff[i], (tap * a.Cin + c0) << 1, 0, 0);
+    };
+    // tap t of plane pl -> filter tap ky * 3 + kx and the block offset (oy, ox) inside the patch
+    auto tap_of = [](int pl, int tp, int& ktap, int& oy, int& ox) {
+        const int py = pl < 2, px = (pl & 1) == 0;
+        const int iy = px ? (tp >> 1) : tp, ix = px ? (tp & 1) : 0;
+        const int ky = py ? 2 * iy : 1, kx = px ? 2 * ix : 1;
+        ktap = ky * 3 + kx;
+        oy = ky != 0; ox = kx != 0;
+    };
+    auto ntaps = [](int pl) { return pl == 0 ? 4 : pl == 3 ? 1 : 2; };
+
+    int pbase[2], pcol[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int p = wm * 64 + mt * 32 + l31;
+        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+        pbase[mt] = ((pn * PH + my) * PW + mx) << LOG_RB;
+        pcol[mt] = mx;
+    }
+    int aoff[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = wn * 64 + nt * 32 + l31;
+            aoff[nt][ks] = row * RB + (((ks * 2 + h) ^ cswz(row)) << 4);
+        }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    const int nch = a.Cin / CK;
+    const int T = nch * 9, NSTEP = nch * 4;
+
+    // ---- scalar bookkeeping of the DMA stream (wave-uniform).  Issue order inside iteration j: weight tile of tap j+2 (2
+    // instructions), then -- at the first tap of a step -- the my_pieces patch pieces of step s+2.  Tap tt needs W(tt), the first
+    // thing iteration tt-2 issued: everything behind it may stay in flight = pieces(tt-2) + all of iteration tt-1.  A step's
+    // patch was issued two steps earlier and is older than W(tt) unless both steps in between were single taps (then it is
+    // the LAST thing iteration tt-2 issued and only iteration tt-1 may stay in flight).  No arrays: scratch accesses would
+    // themselves count in vmcnt.
+    int c1 = 0, p1 = 0, p2 = 0;                          // instructions of iteration tt-1; patch pieces of tt-1 / tt-2
+    int len1 = 0, len2 = 0;                              // taps of steps s-1 / s-2
+    // step s -> (plane, chunk): plane-major, all chunks of a plane in a row
+    auto step_plane = [&](int s) { return s / nch; };
+    auto step_c0 = [&](int s) { return (s % nch) * CK; };
+    // look-ahead iterator two taps ahead of the current one
+    int pl2 = 0, ch2 = 0, tp2 = 0;
+    auto advance2 = [&]() {
+        if (++tp2 == ntaps(pl2)) { tp2 = 0; if (++ch2 == nch) { ch2 = 0; ++pl2; } }
+    };
+
+    // prologue: patches of steps 0 and 1, weight tiles of taps 0 and 1
+    dma_patch(0, step_plane(0), step_c0(0));
+    if (NSTEP > 1) dma_patch(1, step_plane(1), step_c0(1));
+    {
+        int kt, oy, ox;
+        tap_of(pl2, tp2, kt, oy, ox); dma_w(0, kt, ch2 * CK); advance2();
+        if (T > 1) { tap_of(pl2, tp2, kt, oy, ox); dma_w(1, kt, ch2 * CK); advance2(); c1 = 2; }      // W(1) sits behind W(0)
+    }
+
+    int tt = 0, wslot = 0;                               // wslot = tt % 3
+    for (int s = 0, sbuf = 0; s < NSTEP; ++s, sbuf = sbuf == 2 ? 0 : sbuf + 1) {      // sbuf = s % 3
+        const int pl = step_plane(s);
+        const char* patch = smem + sbuf * pbuf_bytes;
+        const int nt_s = ntaps(pl);
+        for (int tp = 0; tp < nt_s; ++tp, ++tt, wslot = wslot == 2 ? 0 : wslot + 1) {
+            const bool patch_last = tp == 0 && s >= 2 && len1 == 1 && len2 == 1;
+            vm_wait_upto(c1 + (patch_last ? 0 : p2));
+            __builtin_amdgcn_s_barrier();                // every wave's share of tap tt (and of this step's patch) is in LDS
+            int cnow = 0, pnow = 0;
+            if (tt + 2 < T) {
+                int kt, oy2, ox2;
+                tap_of(pl2, tp2, kt, oy2, ox2);
+                dma_w(wslot == 0 ? 2 : wslot - 1, kt, ch2 * CK);            // slot (tt + 2) % 3
+                cnow = 2;
+                advance2();
+            }
+            if (tp == 0 && s + 2 < NSTEP) {              // the buffer of step s-1 is free since this barrier
+                dma_patch(sbuf == 0 ? 2 : sbuf - 1, step_plane(s + 2), step_c0(s + 2));      // buffer (s + 2) % 3
+                pnow = my_pieces;
+            }
+            c1 = cnow + pnow; p2 = p1; p1 = pnow;
+            int ktap, oy, ox;
+            tap_of(pl, tp, ktap, oy, ox);
+            const char* wt = wring + wslot * WSLOT;
+            const int tapoff = (oy * PW + ox) << LOG_RB;
+            int bsw[2];
+            const char* bp[2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const int p = wm * 64 + mt * 32 + l31;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = (bf16)acc[nt][mt][4 * g + i];
-                    const int c16 = wn * 8 + nt * 4 + g;
-                    *reinterpret_cast<bf16x4*>(smem + p * 256 + ((c16 ^ (p & 15)) << 4) + 8 * h) = v;
-                }
+                bp[mt] = patch + pbase[mt] + tapoff;
+                bsw[mt] = cswz(pcol[mt] + ox);
             }
-        __syncthreads();
-#pragma unroll 2
-        for (int u = 0; u < BM / PROWS; ++u) {
-            const int ph = pr + u * PROWS;
-            float v[VE];
-            unpack16<bf16>(*reinterpret_cast<const v4i*>(smem + ph * 256 + ((cc ^ (ph & 15)) << 4)), v);
-            finish(ph, v);
-        }
-    } else
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();                                 // main loop reads / the previous half's read-out are done
-        if (wm / 2 == half) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int ks = 0; ks < 4; ++ks) {
+                v4i af[2], bfr[2];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int p = wm * 64 + mt * 32 + l31 - half * BMH;
+                for (int nt = 0; nt < 2; ++nt) af[nt] = *reinterpret_cast<const v4i*>(wt + aoff[nt][ks]);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int u = wn * 16 + nt * 8 + 2 * g + h;
-                        f32x4 v;
+                for (int mt = 0; mt < 2; ++mt)
+                    bfr[mt] = *reinterpret_cast<const v4i*>(bp[mt] + (((ks * 2 + h) ^ bsw[mt]) << 4));
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = acc[nt][mt][4 * g + i];
-                        *reinterpret_cast<f32x4*>(stg + p * BN + ((u ^ (p & (UPR - 1))) << 2)) = v;
-                    }
-                }
-        }
-        __syncthreads();
-        for (int ph = pr; ph < BMH; ph += PROWS) {
-            const int p = ph + half * BMH;
-            float v[VE];
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int u = cc * 2 + k;
-                const f32x4 tt = *reinterpret_cast<const f32x4*>(stg + ph * BN + ((u ^ (ph & (UPR - 1))) << 2));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[4 * k + i] = tt[i];
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[nt]),
+                                                                              __builtin_bit_cast(bf16x8, bfr[mt]),
+                                                                              acc[nt][mt], 0, 0, 0);
             }
-            finish(p, v);
         }
+        len2 = len1; len1 = nt_s;
     }
-#ifdef PMOE_STAMP
-    LAP(2)                                               // epilogue (staging + fused read-out + stores)
-    if (a.stats && lane == 0) {
-        float* o = a.stats + ((size_t)blockIdx.x * 8 + wave) * 8;
-        for (int i = 0; i < 3; ++i) o[i] = (float)st_acc[i];
-        o[3] = (float)(unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
-    }
-    return;
-#endif
-    if (a.stats) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);     // [8 waves][2][BN]
-#pragma unroll
-        for (int i = 0; i < VE; ++i) {
-#pragma unroll
-            for (int off = CPO; off < 64; off <<= 1) {
-                s1[i] += __shfl_xor(s1[i], off);
-                s2[i] += __shfl_xor(s2[i], off);
-            }
-        }
-        if (lane < CPO) {
-#pragma unroll
-            for (int i = 0; i < VE; ++i) {
-                red[(wave * 2 + 0) * BN + cc * VE + i] = s1[i];
-                red[(wave * 2 + 1) * BN + cc * VE + i] = s2[i];
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid % BN;
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) s += red[(w * 2 + which) * BN + c];
-            if (cout0 + c < a.CoutP) a.stats[((size_t)mb * 2 + which) * a.CoutP + cout0 + c] = s;
-        }
-    }
+
+#include "conv_dma_epilogue.inc"
 }
 
 }  // namespace
@@ -449,5 +515,48 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     if (!conv_dma_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
     HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel>(160 * 1024)));
     hipLaunchKernelGGL(conv3x3_dma_kernel, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
+    return (int)hipGetLastError();
+}
+
+
+// Stride-2 3x3 forward convolutions (pad 1) of >= 128 output-channel rows over whole 64-channel chunks, bf16, output maps of
+// >= 4096 pixels per expert that tile into 16 x 16 squares: conv3x3s2_dma_kernel.  PMOE_CONV_S2DMA=0: back to the generic
+// kernel (A/B runs; read per launch).
+bool conv_dma_s2_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf) {
+    const char* ev = getenv("PMOE_CONV_S2DMA");
+    if ((ev && !atoi(ev)) || dtype != PMOE_DT_BF16 || a.w_fp8) return false;
+    if (a.ks != 3 || a.kh != 3 || a.kw != 3 || a.use_tapmap || a.stride != 2 || a.pad != 1 || a.dilate || a.in_shared) return false;
+    if (a.out_step != 1 || a.Ho != (a.H - 1) / 2 + 1 || a.Wo != (a.W - 1) / 2 + 1) return false;
+    if (a.Cin % CK || a.CoutP % BN || a.Cout % 8 || a.N % a.ipe) return false;
+    if (a.res_mode == PMOE_RES_DBN) return false;
+    if ((long long)a.ipe * a.Ho * a.Wo < 4096) return false;
+    auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    int lTW = p2(a.Wo); if (lTW > 4) lTW = 4;
+    if (lTW < 4) return false;
+    int lTH = p2(a.Ho); if (lTH > 8 - lTW) lTH = 8 - lTW;
+    const int TN = BM >> (lTW + lTH);
+    const int NPIX = TN * ((1 << lTH) + 1) * ((1 << lTW) + 1);
+    const int npiece = (NPIX + 7) / 8;
+    if (npiece > 48) return false;
+    const int pb = npiece * 1024;
+    const size_t need = (size_t)3 * pb + RING3 * WSLOT;
+    if (need > 160 * 1024) return false;
+    if ((long long)a.ipe * a.H * a.W * a.in_ld * 2 >= 0x7ff00000ll) return false;
+    a.lTW = lTW; a.lTH = lTH; a.TN = TN;
+    a.n_groups = (a.ipe + TN - 1) / TN;
+    a.tiles_y = (a.Ho + (1 << lTH) - 1) >> lTH;
+    a.tiles_x = (a.Wo + (1 << lTW) - 1) >> lTW;
+    *mblocks = (a.N / a.ipe) * a.n_groups * a.tiles_y * a.tiles_x;
+    *smem = need < (size_t)BM / 2 * BN * 4 ? (size_t)BM / 2 * BN * 4 : need;
+    *pbuf = pb;
+    return true;
+}
+
+int conv_dma_s2_launch(ConvArgs a, hipStream_t st) {
+    int mblocks = 0, pbuf = 0;
+    size_t smem = 0;
+    if (!conv_dma_s2_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
+    HIP_RET((ensure_dyn_lds<conv3x3s2_dma_kernel>(160 * 1024)));
+    hipLaunchKernelGGL(conv3x3s2_dma_kernel, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
     return (int)hipGetLastError();
 }

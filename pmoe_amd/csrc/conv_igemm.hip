@@ -604,6 +604,8 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
         int mb, pb;
         size_t sm;
         if (conv_dma_plan(c, dtype, &mb, &sm, &pb)) return conv_dma_launch(a, st);
+        c = a;
+        if (conv_dma_s2_plan(c, dtype, &mb, &sm, &pb)) return conv_dma_s2_launch(a, st);
     }
     if (dtype == PMOE_DT_BF16) return launch_dtype<bf16>(a, st, nullptr);
     if (dtype == PMOE_DT_F32) return launch_dtype<float>(a, st, nullptr);
@@ -651,6 +653,8 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         int mbd, pb;
         size_t sm;
         if (conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return 5007;          // conv3x3_dma_kernel
+        d = a;
+        if (conv_dma_s2_plan(d, dtype, &mbd, &sm, &pb)) return 5207;       // conv3x3s2_dma_kernel
     }
     int mb = 0, cfg = 0;
     const int rc = dtype == PMOE_DT_BF16 ? launch_dtype<bf16>(c, nullptr, &mb, &cfg)
@@ -681,6 +685,8 @@ int conv_igemm_mblocks(const ConvArgs& a, int dtype) {
         // (no gemm_skinny_ok test: this function sizes the STATISTICS rows, and a launch that asks for statistics never takes
         //  the skinny kernel -- plan and launch must see the same predicate)
         if (conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return mbd;
+        d = a;
+        if (conv_dma_s2_plan(d, dtype, &mbd, &sm, &pb)) return mbd;
     }
     int mb = 0;
     int rc = (dtype == PMOE_DT_BF16) ? launch_dtype<bf16>(a, nullptr, &mb) : launch_dtype<float>(a, nullptr, &mb);

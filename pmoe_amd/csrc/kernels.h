@@ -59,6 +59,9 @@ int gemm_skinny_launch(const ConvArgs& a, hipStream_t st);
 // LDS-DMA 3x3 kernel for the >= 128-channel stride-1 layers (conv_dma.hip)
 bool conv_dma_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
 int conv_dma_launch(ConvArgs a, hipStream_t st);
+// ... and its stride-2 forward sibling (parity planes gathered by the DMA's per-lane source addresses)
+bool conv_dma_s2_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
+int conv_dma_s2_launch(ConvArgs a, hipStream_t st);
 
 struct ResPlan;
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st);

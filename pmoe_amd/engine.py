@@ -527,7 +527,7 @@ class ExpertGroupEngine:
                 or kw["ks"] != 3 or kw["dilate"] or x.t.dtype != torch.bfloat16):
             return False
         z, bnl, coef, rpe = src
-        if bnl.C != kw["cout"] or z.t.shape != x.t.shape:
+        if bnl.C != kw["cout"] or bnl.C != kw["coutp"] or z.t.shape != x.t.shape:      # (the statistics rows are coutp wide)
             return False
         common = dict(res=z.t, res_mode=hip.RES_DBN, bn_coef=coef, bn_ipe=self.B, bias=bias, **kw)
         if ops.conv2d(dy, w_dg, g, plan_only=True, **common) not in (1107, 5007):

@@ -23,7 +23,11 @@ def rnd(shape, g, dtype, scale=1.0):
     return x.to(dtype).float() if dtype == torch.bfloat16 else x
 
 
-def close(got, ref, dtype, what=""):
+def close(got, ref, dtype, what="", floor=2.0 ** -4):
+    """``floor``: share of the tensor's scale added to |ref| in the elementwise bound.  1/16 where the kernel sees exactly the
+    operands of the reference (inputs representable in the storage type: only summation order and the output rounding differ);
+    1/8 where the kernel re-rounds a DERIVED operand to bf16 that the reference keeps in f32 (BatchNorm-scaled / gated weight
+    packs): that noise scales with sum |w x|, not with the element."""
     got = got.float().cpu()
     scale = ref.abs().max().item() + 1e-12
     err = (got - ref).abs().max().item() / scale
@@ -31,10 +35,10 @@ def close(got, ref, dtype, what=""):
     assert err <= tol, f"{what}: rel-to-max err {err:.3e} > {tol} (scale {scale:.3e})"
     # ... and elementwise (rel-to-max alone is blind to errors on small elements): every element within
     # tol of ITS OWN magnitude plus a floor of 1/16 of the tensor's scale
-    bad = (got - ref).abs() > tol * (ref.abs() + scale * 2.0 ** -4)
+    bad = (got - ref).abs() > tol * (ref.abs() + scale * floor)
     if bad.any():
-        i = ((got - ref).abs() / (ref.abs() + scale * 2.0 ** -4)).argmax()
-        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} elements beyond {tol} x (|ref| + scale/16); worst "
+        i = ((got - ref).abs() / (ref.abs() + scale * floor)).argmax()
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} elements beyond {tol} x (|ref| + scale x {floor}); worst "
                              f"got {got.flatten()[i].item():.6e} ref {ref.flatten()[i].item():.6e} (scale {scale:.3e})")
 
 
@@ -180,7 +184,10 @@ BASELINE_CONV_CASES = [
     ((1, 5, 128, 256, 40, 24, 3, 1), (5007, 5007, 200)),       # ragged: 24-wide rows in 32-wide tiles, 40 rows in strips of 8, 5 images
     ((1, 1, 64, 64, 256, 256, 3, 1), (1107, 1107, 256)),       # stem conv2: conv3x3_resdma_kernel, 256 tiles of one image
     ((2, 2, 64, 64, 128, 128, 3, 1), (1107, 1107, 256)),       # layer1: resident kernel, persistent workgroups per expert
-    ((1, 4, 64, 128, 128, 128, 3, 2), (642, 4741, 256)),       # layer2.0.conv1: stride-2 forward, parity-class data gradient
+    ((1, 4, 64, 128, 128, 128, 3, 2), (5207, 4741, 256)),      # layer2.0.conv1: conv3x3s2_dma_kernel (parity planes by LDS-DMA), parity-class data gradient
+    ((1, 8, 128, 256, 64, 64, 3, 2), (5207, None, None)),      # layer3.0.conv1: 2 channel chunks per plane
+    ((2, 16, 256, 512, 32, 32, 3, 2), (5207, None, None)),     # layer4.0.conv1: 4 chunks (single-tap steps back to back), 4 cout blocks, 2 experts
+    ((1, 6, 64, 128, 71, 55, 3, 2), (5207, None, None)),       # odd image sides: the last block row / column has only its plane-0 pixels; ragged tiles
     ((1, 4, 64, 128, 128, 128, 1, 2), (1404, 741, 128)),       # layer2.0.downsample (1x1 stride 2: conv1x1_direct_kernel<4>)
     ((1, 1, 12, 64, 256, 256, 3, 1), (1316, 1107, 256)),       # stem conv1 (12 -> 16 input channels): direct-form conv3x3_c16_kernel
     ((2, 3, 12, 64, 40, 40, 3, 1), (1316, None, None)),        # ... ragged: 40-wide rows = one full + one 8-pixel tile, 2 experts x 3 images
@@ -743,7 +750,7 @@ def test_unet_pool_upconv_concat_kernels(dtype):
     ops.maxpool2_fwd(xh, y)
     close(y.permute(0, 3, 1, 2), F.max_pool2d(x, 2, 2), torch.float32, "maxpool2")
     # transposed conv: weight [cin, cout, 2, 2]
-    wt = rnd((cin, cout, 2, 2), g, dtype) * 0.2
+    wt = rnd((cin, cout, 2, 2), g, dtype) * 0.25          # (a power of two: the weights stay representable in bf16)
     bias = rnd((cout,), g, torch.float32)
     ref = F.conv_transpose2d(x, wt, bias, stride=2)
     w1 = wt.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1).contiguous().to(DEV)
@@ -844,7 +851,7 @@ def test_folded_weight_packs(dtype):
     y = torch.empty(N, H, W, cout, dtype=dtype, device=DEV)
     ops.conv2d(xd, wf, y, cin=cin, cout=cout, coutp=64, ipe=ipe, ks=3, stride=1, pad=1, bias=bf, act=hip.ACT_RELU,
                res=rd, res_mode=hip.RES_ADD)
-    close(from_nhwc(y, cout), ref, dtype, "conv with folded BatchNorm + residual + ReLU")
+    close(from_nhwc(y, cout), ref, dtype, "conv with folded BatchNorm + residual + ReLU", floor=2.0 ** -3)
     # gate fold: conv(x * g[n, c], W[e]) == conv(x, W[e] * g[n, c]) with one weight pack per image
     gate = torch.rand(N, cin, generator=g)
     ref2 = torch.cat([F.conv2d(x[n:n + 1] * gate[n].view(1, -1, 1, 1), ws[n // ipe], padding=1) for n in range(N)])
@@ -967,7 +974,8 @@ def test_bn_apply_with_fused_global_average_pool(dtype):
                 assert torch.equal(y1, y2) and torch.equal(p1, p2)
             else:
                 close(y2, y1.float().cpu(), dtype, "bn_apply_gap y")
-                close(p2, p1.cpu(), torch.float32, "bn_apply_gap sums")
+                # (sums of bf16 activations, a few of which round the other way between the torch expression and the kernel's FMA)
+                close(p2, p1.cpu(), dtype, "bn_apply_gap sums")
 
 
 def test_conv_c16_channel_windows():
