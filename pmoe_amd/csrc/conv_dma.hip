@@ -52,6 +52,10 @@ __device__ __forceinline__ int cswz(int x) { return (x >> 1) & 7; }
 #define LAP(i)
 #endif
 
+// MF16 (PMOE_DMA_MF16=1, A/B: tools/ab_conv.py): the same 64 x 64 wave tile on v_mfma_f32_16x16x32_bf16 -- 16 MFMAs of half the
+// cycles per 32 channels instead of 4 per 16, identical LDS traffic (8 ds_read_b128 per 32 channels either way).  On this part
+// the clock an MFMA-dense loop holds depends on the MFMA shape (MI355X_MICROARCH.md, DVFS give-back item 7).
+template <bool MF16>
 __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, const int pbuf_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     STAMP_INIT
@@ -148,6 +152,30 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+    // MF16: 4 x 4 tiles of 16 x 16; A rows = couts wn*64 + nt*16 + (lane & 15), B columns = pixels wm*64 + mt*16 + (lane & 15),
+    // k = 8 (lane >> 4) + j inside a 32-channel step -> 16-byte chunk ks*4 + (lane >> 4) of the 128-byte row
+    f32x4 acc16[4][4];
+    int pbase16[4], pcol16[4], aoff16[4][2];
+    if constexpr (MF16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int p = wm * 64 + mt * 16 + (lane & 15);
+            const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+            pbase16[mt] = ((pn * PH + my) * PW + mx) << LOG_RB;
+            pcol16[mt] = mx;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = wn * 64 + nt * 16 + (lane & 15);
+                aoff16[nt][ks] = row * RB + (((ks * 4 + (lane >> 4)) ^ cswz(row)) << 4);
+            }
+    }
 
     const int nchunks = a.Cin / CK;
     const int T = nchunks * 9;
@@ -210,6 +238,32 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
             }
             const char* wt = wring + (tt & (RING - 1)) * WSLOT;
             const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RB;
+            if constexpr (MF16) {
+                int bsw16[4];
+                const char* bp16[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    bp16[mt] = patch + pbase16[mt] + tapoff;
+                    bsw16[mt] = cswz(pcol16[mt] + (tap % 3));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    v4i af[4], bfr[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) af[nt] = *reinterpret_cast<const v4i*>(wt + aoff16[nt][ks]);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        bfr[mt] = *reinterpret_cast<const v4i*>(bp16[mt] + (((ks * 4 + (lane >> 4)) ^ bsw16[mt]) << 4));
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc16[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[nt]),
+                                                                                    __builtin_bit_cast(bf16x8, bfr[mt]),
+                                                                                    acc16[nt][mt], 0, 0, 0);
+                }
+                continue;
+            }
             int bsw[2];
             const char* bp[2];
 #pragma unroll
@@ -238,9 +292,11 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
 
 #define DMA_ZPRE zpre
 #define DMA_ZPRE_ON zpre_on
+#define DMA_HAS_MF16
 #include "conv_dma_epilogue.inc"
 #undef DMA_ZPRE
 #undef DMA_ZPRE_ON
+#undef DMA_HAS_MF16
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -513,8 +569,14 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
     if (!conv_dma_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
-    HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel>(160 * 1024)));
-    hipLaunchKernelGGL(conv3x3_dma_kernel, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
+    const char* ev = getenv("PMOE_DMA_MF16");          // A/B switch, read per launch
+    if (ev && atoi(ev)) {
+        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<true>>(160 * 1024)));
+        hipLaunchKernelGGL(conv3x3_dma_kernel<true>, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
+    } else {
+        HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<false>>(160 * 1024)));
+        hipLaunchKernelGGL(conv3x3_dma_kernel<false>, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
+    }
     return (int)hipGetLastError();
 }
 
