@@ -52,7 +52,7 @@ __device__ __forceinline__ int cswz(int x) { return (x >> 1) & 7; }
 #define LAP(i)
 #endif
 
-// MF16 (PMOE_DMA_MF16=1, A/B: tools/ab_conv.py): the same 64 x 64 wave tile on v_mfma_f32_16x16x32_bf16 -- 16 MFMAs of half the
+// MF16 (default for >= 256 input channels, conv_dma_launch): the same 64 x 64 wave tile on v_mfma_f32_16x16x32_bf16 -- 16 MFMAs of half the
 // cycles per 32 channels instead of 4 per 16, identical LDS traffic (8 ds_read_b128 per 32 channels either way).  On this part
 // the clock an MFMA-dense loop holds depends on the MFMA shape (MI355X_MICROARCH.md, DVFS give-back item 7).
 template <bool MF16>
@@ -569,8 +569,11 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
     if (!conv_dma_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
-    const char* ev = getenv("PMOE_DMA_MF16");          // A/B switch, read per launch
-    if (ev && atoi(ev)) {
+    // v_mfma_f32_16x16x32_bf16 for the layers with >= 4 channel chunks (interleaved A/B, profiles/r03_kernel_ab.log: layer3 forward
+    // +0.6 %, data gradient +3.5 %; layer4 +3.5 % / +5 %; layer2 -3 % / +0.7 %: the shorter the main loop, the less the shape's
+    // higher sustained clock buys).  PMOE_DMA_MF16=0 | 1 forces one shape (read per launch).
+    const char* ev = getenv("PMOE_DMA_MF16");
+    if (ev ? atoi(ev) != 0 : a.Cin >= 256) {
         HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<true>>(160 * 1024)));
         hipLaunchKernelGGL(conv3x3_dma_kernel<true>, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
     } else {
