@@ -429,13 +429,16 @@ def main():
             if 6000 <= code < 7000:               # conv_wgrad_kernel<T, taps, MAXV>
                 taps, maxv = (code - 6000) // 100, (code - 6000) % 100
                 return (f"conv_wgrad_kernel<{kdt},{taps},{maxv}>", f"_Z17conv_wgrad_kernelI{tname}Li{taps}ELi{maxv}EEv9WgradArgs", 1)
+            if code == 9207:                      # the four parity classes of a stride-2 3x3 data gradient on the LDS-DMA kernel
+                return ("conv3x3s2_dma_kernel<true> (4 parity-class launches per stride-2 dgrad)",
+                        "void (anonymous namespace)::conv3x3s2_dma_kernel<true>", 4)
             if code >= 8000:                      # e4m3 operands (BASELINE config 5): same tiles, TL = fp8
                 r, m, n = symbol(code - 8000)
                 return r.replace("<bf16,", "<bf16+e4m3,"), m.replace(f"E{tname}Ev8ConvArgs", "E3fp8Ev8ConvArgs"), n
             if code == 5007:                      # LDS-DMA staged 3x3 kernel (conv_dma.hip)
                 return "conv3x3_dma_kernel", "void (anonymous namespace)::conv3x3_dma_kernel", 1
             if code == 5207:                      # ... its stride-2 forward sibling
-                return "conv3x3s2_dma_kernel", "void (anonymous namespace)::conv3x3s2_dma_kernel", 1
+                return "conv3x3s2_dma_kernel<false>", "void (anonymous namespace)::conv3x3s2_dma_kernel<false>", 1
             four = code >= 4000
             code %= 4000
             if code == 3000:

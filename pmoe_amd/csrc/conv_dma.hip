@@ -328,6 +328,12 @@ __device__ __forceinline__ void vm_wait_upto(int n) {     // s_waitcnt vmcnt(min
 
 constexpr int RING3 = 3;
 
+// CLS = true: ONE PARITY CLASS of a stride-2 3x3 DATA GRADIENT on the same schedule (layer2-4 `.0.conv1`, the four launches the
+// generic kernel served at 0.09-0.2 of the matrix peak): dx[2a+py][2b+px] is a stride-1 correlation of dy with the (1+py)(1+px)
+// taps of the flipped filter that reach that parity (a.kh x a.kw taps at block offsets (r, q) in {0,1}^2, filter taps a.tapmap),
+// written to the class's lattice of dx (a.out_step / out_offy / out_offx over [a.OH][a.OW]).  One "plane" (pixel step 1, halo on
+// the bottom / right), a step = a 64-channel chunk of dy with all of the class's taps.
+template <bool CLS>
 __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a, const int pbuf_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     STAMP_INIT
@@ -336,7 +342,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int nblk = a.CoutP / BN;
+    const int nblk = (a.CoutP + BN - 1) / BN;            // (CLS: a 64-row gradient runs half a tile of zero weights)
     const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned mb = flat / nblk;
     const int nb = (int)(flat % nblk);
@@ -361,7 +367,8 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a
     if (in_bytes > 0x7ff00000ll) in_bytes = 0x7ff00000ll;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, (int)in_bytes, 0x00020000);
     const bf16* wb = (const bf16*)a.w + ((size_t)e * a.CoutP + cout0) * 9 * a.Cin;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, BN * 9 * a.Cin * 2, 0x00020000);
+    const int wrows = a.CoutP - cout0 < BN ? a.CoutP - cout0 : BN;      // rows beyond the bank arrive as zeros
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, wrows * 9 * a.Cin * 2, 0x00020000);
 
     // ---- per-lane source offsets of this wave's patch pieces: pixel (2 By, 2 Bx) of the block; the plane's (py, px) and the
     // channel chunk travel in the scalar offset.  4 validity bits per piece: rows 2By / 2By+1 and columns 2Bx / 2Bx+1 inside
@@ -376,12 +383,18 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a
         const int bx = pp % PW;
         const int rowq = pp / PW;
         const int by = rowq % PH, pn = rowq / PH;
+        if constexpr (CLS) {                              // dy pixel (oy0 + by, ox0 + bx): rows / columns beyond dy read as zero
+            const int By = oy0 + by, Bx = ox0 + bx;
+            const bool ok = pp < NPIX && n0 + pn < n_end && By < a.H && Bx < a.W;
+            pvoff[i] = ok ? ((((pn * a.H + By) * a.W + Bx) * a.in_ld) << 1) + ((jj ^ cswz(bx)) << 4) : OOB;
+        } else {
         const int By = oy0 - 1 + by, Bx = ox0 - 1 + bx;
         const bool okb = pp < NPIX && n0 + pn < n_end && By >= 0 && Bx >= 0;
         pvoff[i] = okb ? ((((pn * a.H + 2 * By) * a.W + 2 * Bx) * a.in_ld) << 1) + ((jj ^ cswz(bx)) << 4) : OOB;
         const unsigned vb = (okb && 2 * By < a.H ? 1u : 0u) | (okb && 2 * By + 1 < a.H ? 2u : 0u) |
                             (2 * Bx < a.W ? 4u : 0u) | (2 * Bx + 1 < a.W ? 8u : 0u);
         vbits |= vb << (4 * i);
+        }
     }
     int wvoff[2];
 #pragma unroll
@@ -394,11 +407,11 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a
     // plane index pl: 0 = (py 1, px 1) 4 taps, 1 = (1, 0) 2 taps, 2 = (0, 1) 2 taps, 3 = (0, 0) 1 tap
     auto dma_patch = [&](int buf, int pl, int c0) {      // all pieces of this wave for step (pl, c0)
         const int py = pl < 2, px = (pl & 1) == 0;
-        const int soff = (c0 << 1) + (((py * a.W + px) * a.in_ld) << 1);
+        const int soff = (c0 << 1) + (CLS ? 0 : (((py * a.W + px) * a.in_ld) << 1));
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             if (i < my_pieces) {
-                const bool ok = ((vbits >> (4 * i + py)) & 1u) && ((vbits >> (4 * i + 2 + px)) & 1u);
+                const bool ok = CLS || (((vbits >> (4 * i + py)) & 1u) && ((vbits >> (4 * i + 2 + px)) & 1u));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(smem + buf * pbuf_bytes + ((wave + 8 * i) << 10)), 16,
                                                          ok ? pvoff[i] : OOB, soff, 0, 0);
             }
@@ -410,14 +423,19 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a
                                                      wvoff[i], (tap * a.Cin + c0) << 1, 0, 0);
     };
     // tap t of plane pl -> filter tap ky * 3 + kx and the block offset (oy, ox) inside the patch
-    auto tap_of = [](int pl, int tp, int& ktap, int& oy, int& ox) {
+    auto tap_of = [&](int pl, int tp, int& ktap, int& oy, int& ox) {
+        if constexpr (CLS) {
+            oy = a.kw == 2 ? (tp >> 1) : tp; ox = a.kw == 2 ? (tp & 1) : 0;
+            ktap = tp == 0 ? a.tapmap[0] : tp == 1 ? a.tapmap[1] : tp == 2 ? a.tapmap[2] : a.tapmap[3];
+            return;
+        }
         const int py = pl < 2, px = (pl & 1) == 0;
         const int iy = px ? (tp >> 1) : tp, ix = px ? (tp & 1) : 0;
         const int ky = py ? 2 * iy : 1, kx = px ? 2 * ix : 1;
         ktap = ky * 3 + kx;
         oy = ky != 0; ox = kx != 0;
     };
-    auto ntaps = [](int pl) { return pl == 0 ? 4 : pl == 3 ? 1 : 2; };
+    auto ntaps = [&](int pl) { return CLS ? a.kh * a.kw : pl == 0 ? 4 : pl == 3 ? 1 : 2; };
 
     int pbase[2], pcol[2];
 #pragma unroll
@@ -445,7 +463,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
     const int nch = a.Cin / CK;
-    const int T = nch * 9, NSTEP = nch * 4;
+    const int T = CLS ? nch * a.kh * a.kw : nch * 9, NSTEP = CLS ? nch : nch * 4;
 
     // ---- scalar bookkeeping of the DMA stream (wave-uniform).  Issue order inside iteration j: weight tile of tap j+2 (2
     // instructions), then -- at the first tap of a step -- the my_pieces patch pieces of step s+2.  Tap tt needs W(tt), the first
@@ -456,7 +474,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a
     int c1 = 0, p1 = 0, p2 = 0;                          // instructions of iteration tt-1; patch pieces of tt-1 / tt-2
     int len1 = 0, len2 = 0;                              // taps of steps s-1 / s-2
     // step s -> (plane, chunk): plane-major, all chunks of a plane in a row
-    auto step_plane = [&](int s) { return s / nch; };
+    auto step_plane = [&](int s) { return CLS ? 0 : s / nch; };
     auto step_c0 = [&](int s) { return (s % nch) * CK; };
     // look-ahead iterator two taps ahead of the current one
     int pl2 = 0, ch2 = 0, tp2 = 0;
@@ -526,7 +544,13 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a
         len2 = len1; len1 = nt_s;
     }
 
+    if constexpr (CLS) {
+#define DMA_LATTICE
 #include "conv_dma_epilogue.inc"
+#undef DMA_LATTICE
+    } else {
+#include "conv_dma_epilogue.inc"
+    }
 }
 
 }  // namespace
@@ -621,7 +645,48 @@ int conv_dma_s2_launch(ConvArgs a, hipStream_t st) {
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
     if (!conv_dma_s2_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
-    HIP_RET((ensure_dyn_lds<conv3x3s2_dma_kernel>(160 * 1024)));
-    hipLaunchKernelGGL(conv3x3s2_dma_kernel, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
+    HIP_RET((ensure_dyn_lds<conv3x3s2_dma_kernel<false>>(160 * 1024)));
+    hipLaunchKernelGGL(conv3x3s2_dma_kernel<false>, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
+    return (int)hipGetLastError();
+}
+
+// One parity class of a stride-2 3x3 data gradient (the class fields of ConvArgs set by launch_stride2_dgrad, conv_igemm.hip):
+// bf16, whole 64-channel chunks of dy, gradient rows in multiples of 64, class lattices of >= 4096 pixels per expert that tile
+// into 16 x 16 squares.  PMOE_CONV_S2DMA=0: back to the generic kernel.
+bool conv_dma_s2cls_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf) {
+    const char* ev = getenv("PMOE_CONV_S2DMA");
+    if ((ev && !atoi(ev)) || dtype != PMOE_DT_BF16 || a.w_fp8) return false;
+    if (a.ks != 3 || !a.use_tapmap || a.out_step != 2 || a.stride != 1 || a.pad != 0 || a.dilate || a.in_shared) return false;
+    if (a.kh < 1 || a.kh > 2 || a.kw < 1 || a.kw > 2) return false;
+    if (a.Cin % CK || a.CoutP % 64 || a.Cout % 8 || a.N % a.ipe || a.stats || a.res_mode > PMOE_RES_ADD) return false;
+    if ((long long)a.ipe * a.Ho * a.Wo < 4096) return false;
+    auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    int lTW = p2(a.Wo); if (lTW > 4) lTW = 4;
+    if (lTW < 4) return false;
+    int lTH = p2(a.Ho); if (lTH > 8 - lTW) lTH = 8 - lTW;
+    const int TN = BM >> (lTW + lTH);
+    const int NPIX = TN * ((1 << lTH) + 1) * ((1 << lTW) + 1);
+    const int npiece = (NPIX + 7) / 8;
+    if (npiece > 48) return false;
+    const int pb = npiece * 1024;
+    const size_t need = (size_t)3 * pb + RING3 * WSLOT;
+    if (need > 160 * 1024) return false;
+    if ((long long)a.ipe * a.H * a.W * a.in_ld * 2 >= 0x7ff00000ll) return false;
+    a.lTW = lTW; a.lTH = lTH; a.TN = TN;
+    a.n_groups = (a.ipe + TN - 1) / TN;
+    a.tiles_y = (a.Ho + (1 << lTH) - 1) >> lTH;
+    a.tiles_x = (a.Wo + (1 << lTW) - 1) >> lTW;
+    *mblocks = (a.N / a.ipe) * a.n_groups * a.tiles_y * a.tiles_x;
+    *smem = need < (size_t)BM / 2 * BN * 4 ? (size_t)BM / 2 * BN * 4 : need;
+    *pbuf = pb;
+    return true;
+}
+
+int conv_dma_s2cls_launch(ConvArgs a, hipStream_t st) {
+    int mblocks = 0, pbuf = 0;
+    size_t smem = 0;
+    if (!conv_dma_s2cls_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
+    HIP_RET((ensure_dyn_lds<conv3x3s2_dma_kernel<true>>(160 * 1024)));
+    hipLaunchKernelGGL(conv3x3s2_dma_kernel<true>, dim3(mblocks * ((a.CoutP + BN - 1) / BN)), dim3(NTHR), smem, st, a, pbuf);
     return (int)hipGetLastError();
 }

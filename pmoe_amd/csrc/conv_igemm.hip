@@ -553,6 +553,16 @@ static int launch_stride2_dgrad(const ConvArgs& a, int dtype, hipStream_t st) {
                     const int fy = py ? (r == 0 ? 0 : 2) : 1, fx = px ? (q == 0 ? 0 : 2) : 1;
                     c.tapmap[r * c.kw + q] = fy * 3 + fx;
                 }
+            {
+                ConvArgs d = c;
+                int mb, pb;
+                size_t sm;
+                if (conv_dma_s2cls_plan(d, dtype, &mb, &sm, &pb)) {          // LDS-DMA kernel (conv_dma.hip)
+                    const int rcd = conv_dma_s2cls_launch(c, st);
+                    if (rcd) return rcd;
+                    continue;
+                }
+            }
             const int rc = dtype == PMOE_DT_BF16 ? launch_dtype<bf16>(c, st, nullptr)
                          : dtype == PMOE_DT_F32 ? launch_dtype<float>(c, st, nullptr) : PMOE_ERR_ARG;
             if (rc) return rc;
@@ -638,6 +648,13 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         c.Ho = a.Ho / 2; c.Wo = a.Wo / 2; c.OH = a.Ho; c.OW = a.Wo; c.out_step = 2;
         if (c.Ho <= 0 || c.Wo <= 0) return PMOE_ERR_ARG;
         extra = 4000;
+        {
+            ConvArgs d = c;
+            d.use_tapmap = 1; d.out_offy = d.out_offx = 1;
+            int mb, pb;
+            size_t sm;
+            if (conv_dma_s2cls_plan(d, dtype, &mb, &sm, &pb)) return 4000 + 5207;      // 4 launches of conv3x3s2_dma_kernel<true>
+        }
     } else {
         int wpe, tx, tpe, slabs, mt;
         size_t smx;

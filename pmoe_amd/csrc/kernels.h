@@ -62,6 +62,9 @@ int conv_dma_launch(ConvArgs a, hipStream_t st);
 // ... and its stride-2 forward sibling (parity planes gathered by the DMA's per-lane source addresses)
 bool conv_dma_s2_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
 int conv_dma_s2_launch(ConvArgs a, hipStream_t st);
+// ... and one parity class of a stride-2 3x3 data gradient on the same kernel (ConvArgs with the class fields set)
+bool conv_dma_s2cls_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
+int conv_dma_s2cls_launch(ConvArgs a, hipStream_t st);
 
 struct ResPlan;
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st);
