@@ -186,7 +186,11 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
     // barriers).  Plain global loads share the in-order vmcnt counter with the DMA stream: the wait of the next tap lets them
     // stay in flight (+8); the one after retires them (hipcc may order them before OR after that tap's weight-tile request --
     // different address spaces -- so only the first wait can count on their position).
-    const bool zpre_on = a.res_mode == PMOE_RES_DBN && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f;
+    // The same prefetch serves PMOE_RES_ADD (a data gradient accumulating into the gradient the identity branch left: layer2-4
+    // `.1.conv1`), which then also takes the one-phase bf16 read-out (the sum is formed on the rounded accumulator, as the
+    // resident-filter kernel always did: 0.46 -> 0.37 ms on layer2.1.conv1's data gradient).
+    const bool zpre_on = (a.res_mode == PMOE_RES_DBN || a.res_mode == PMOE_RES_ADD) && !a.bias && a.act == PMOE_ACT_NONE &&
+                         a.drop_p == 0.f;
     v4i zpre[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) zpre[u] = v4i{0, 0, 0, 0};
@@ -658,7 +662,10 @@ bool conv_dma_s2cls_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int
     if ((ev && !atoi(ev)) || dtype != PMOE_DT_BF16 || a.w_fp8) return false;
     if (a.ks != 3 || !a.use_tapmap || a.out_step != 2 || a.stride != 1 || a.pad != 0 || a.dilate || a.in_shared) return false;
     if (a.kh < 1 || a.kh > 2 || a.kw < 1 || a.kw > 2) return false;
-    if (a.Cin % CK || a.CoutP % 64 || a.Cout % 8 || a.N % a.ipe || a.stats || a.res_mode > PMOE_RES_ADD) return false;
+    // (64 gradient rows -- layer2.0.conv1 -- would run half a tile of zero weights: measured 0.77 vs 0.58 ms on the generic kernel;
+    //  PMOE_S2CLS_64=1 admits them for that A/B)
+    const char* e64 = getenv("PMOE_S2CLS_64");
+    if (a.Cin % CK || a.CoutP % ((e64 && atoi(e64)) ? 64 : BN) || a.Cout % 8 || a.N % a.ipe || a.stats || a.res_mode > PMOE_RES_ADD) return false;
     if ((long long)a.ipe * a.Ho * a.Wo < 4096) return false;
     auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     int lTW = p2(a.Wo); if (lTW > 4) lTW = 4;

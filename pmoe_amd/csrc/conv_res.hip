@@ -403,6 +403,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
     if (ntile > 0) issue_patch(0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // filter bank + first patch (DMA), the bias row (ds_write)
     __builtin_amdgcn_s_barrier();
+    // PMOE_RES_DBN: this thread's 8 channels of the BatchNorm coefficients, in registers for all of its tiles
+    float kmu[VE], kis[VE], ksc[VE], ksh[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) kmu[i] = kis[i] = ksc[i] = ksh[i] = 0.f;
+    if (dbn) {
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            kmu[i] = lbn[cc * VE + i]; kis[i] = lbn[64 + cc * VE + i]; ksc[i] = lbn[128 + cc * VE + i]; ksh[i] = lbn[192 + cc * VE + i];
+        }
+    }
 
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
@@ -495,22 +505,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
                     float v[VE], rv[VE];
                     unpack16<bf16>(raw, v);
                     unpack16<bf16>(res_pref ? rpre[u] : ldg16(res + opix * a.res_ld + a.res_coff + cc * VE), rv);
-                    float mu[VE], is[VE], sc[VE], sh[VE];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        *reinterpret_cast<f32x4*>(mu + 4 * q) = *reinterpret_cast<const f32x4*>(lbn + cc * VE + 4 * q);
-                        *reinterpret_cast<f32x4*>(is + 4 * q) = *reinterpret_cast<const f32x4*>(lbn + 64 + cc * VE + 4 * q);
-                        *reinterpret_cast<f32x4*>(sc + 4 * q) = *reinterpret_cast<const f32x4*>(lbn + 128 + cc * VE + 4 * q);
-                        *reinterpret_cast<f32x4*>(sh + 4 * q) = *reinterpret_cast<const f32x4*>(lbn + 192 + cc * VE + 4 * q);
-                    }
 #pragma unroll
                     for (int i = 0; i < VE; ++i) {
-                        const float d = rv[i] - mu[i];
+                        const float d = rv[i] - kmu[i];
                         // the value the apply pass will read is the ROUNDED masked gradient: the sums use it too
-                        const float gq = (d * sc[i] + sh[i]) > 0.f ? v[i] : 0.f;
+                        const float gq = (d * ksc[i] + ksh[i]) > 0.f ? v[i] : 0.f;
                         v[i] = gq;
                         s1[i] += gq;
-                        s2[i] += gq * (d * is[i]);
+                        s2[i] += gq * (d * kis[i]);
                     }
                     pk = pack16<bf16>(v);
                 } else {

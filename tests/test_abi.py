@@ -89,7 +89,8 @@ def test_conv_plan_reports_the_kernel_instantiation():
     assert plan(512, 512, 14, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # B=1 inference layer4: tap-looping skinny kernel
     assert plan(128, 128, 56, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # ... layer2 (3136 pixels per expert <= 3200)
     assert plan(128, 128, 64, 3, 1, torch.bfloat16, B=1, E=3) == 5007      # 4096 pixels per expert: the LDS-DMA tile
-    assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 9207   # stride-2 dgrad: 4 class launches of conv3x3s2_dma_kernel<true>
+    assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 4741   # stride-2 dgrad, 64 gradient rows: 4 class launches <7,4,1>
+    assert plan(256, 128, 32, 3, 1, torch.bfloat16, dilate=True, Hout=64) == 9207   # ... >= 128 rows: 4 class launches of conv3x3s2_dma_kernel<true>
     assert plan(64, 128, 128, 3, 2, torch.bfloat16) == 5207                # stride-2 forward: conv3x3s2_dma_kernel<false>
     assert plan(128, 64, 64, 3, 1, torch.float32, dilate=True, Hout=128) // 1000 == 4   # ... in f32: 4 class launches of the generic kernel
 

@@ -15,7 +15,7 @@ E, B = 4, 64
 SHAPES = {  # name: (cin, cout, H, ks, stride)
     "conv1": (12, 64, 256, 3, 1), "conv2": (64, 64, 256, 3, 1), "l1": (64, 64, 128, 3, 1),
     "l2s2": (64, 128, 128, 3, 2), "l2": (128, 128, 64, 3, 1), "l3": (256, 256, 32, 3, 1), "l4": (512, 512, 16, 3, 1),
-    "l2d": (64, 128, 128, 1, 2),
+    "l2d": (64, 128, 128, 1, 2), "l3s2": (128, 256, 64, 3, 2), "l4s2": (256, 512, 32, 3, 2),
 }
 
 
