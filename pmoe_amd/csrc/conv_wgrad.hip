@@ -244,9 +244,13 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
 // pixels, images beyond the expert's last and channels beyond Cin / Cout arrive as zeros from the buffer range check.
 // WCI = 1 (layers with <= 32 input channels: the per-image gradient of the 16-channel stem convolution): the 8 waves are
 // 2 (cout) x 4 (pixel quarters) instead of 2 x 2 x 2 -- with WCI = 2 half of them multiplied the zero-filled channels 32..63.
-template <int PIN, int WCI = 2>
+// PAIRS (WCI = 1, <= 16 input channels: the stem's first convolution, 12 -> 16): the 32 columns of an MFMA hold TWO taps x
+// 16 channels instead of one tap x 16 channels + 16 columns of zero fill -- lanes 16..31 of a fragment read the next tap's
+// pixel (a per-lane tap offset), 5 MFMAs per k-block instead of 9 (round 3: 0.83 -> ~0.5 ms on the per-image stem gradient).
+template <int PIN, int WCI = 2, bool PAIRS = false>
 __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, const int magic_pw, const int magic_ph) {
     constexpr int TAPS = 9, RS = 128, CKW = 64;
+    static_assert(!PAIRS || WCI == 1, "tap pairs: the narrow wave layout only");
     constexpr int WCO = 2, WK = 8 / (WCI * WCO);
     typedef __attribute__((address_space(3))) void lds_void;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -340,6 +344,18 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
     for (int kx = 0; kx < 3; ++kx)
         cb_sw[kx] = (((ci_sub * 4 + (g & 1) * 2 + (pc >> 1)) ^ ((((q + kx) >> 1) & 1) << 2)) << 4) + 8 * (pc & 1);
 
+    // PAIRS: lane-constant byte offset of pair i inside a patch row group: tap 2i for the column block (g & 1) = 0, tap 2i+1 for
+    // block 1 (pair 4's second half repeats tap 8 and is dropped by the flush); channels 0..15 for both
+    int pairoff[5];
+    if constexpr (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int tl = 2 * i + (g & 1) > 8 ? 8 : 2 * i + (g & 1);
+            const int kx = tl % 3;
+            pairoff[i] = ((tl / 3) * PW + kx) * RS + ((((pc >> 1)) ^ ((((q + kx) >> 1) & 1) << 2)) << 4) + 8 * (pc & 1);
+        }
+    }
+
     if (mb_begin < mb_end) issue(mb_begin, 0);
     for (int mbi = mb_begin; mbi < mb_end; ++mbi) {
         const int buf = (mbi - mb_begin) & 1;
@@ -398,6 +414,30 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
                 for (int tap = 0; tap < TAPS; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
                 continue;
             }
+            if constexpr (PAIRS) {
+                const bf16x8 fa = read_a(pA);
+                auto read_pair = [&](int i) {
+                    bf16x8 fb;
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const s16x4 r = tr_read(patch + ppB[tt] * RS + pairoff[i]);
+                        const bf16x4 rb = __builtin_bit_cast(bf16x4, r);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fb[4 * tt + j] = rb[j];
+                    }
+                    return fb;
+                };
+                bf16x8 fbp[2];
+                fbp[0] = read_pair(0);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    if (i + 1 < 5) fbp[(i + 1) & 1] = read_pair(i + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbp[i & 1], acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
             const bf16x8 fa = read_a(pA);
             bf16x8 fbq[2];                                // static double buffer: tap t lives in fbq[t & 1]
             fbq[0] = read_b(ppB, 0);
@@ -418,6 +458,34 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
     const int cin = ci0 + ci_sub * 32 + l31;
     const size_t slab = a.per_image ? (size_t)e * a.ipe + split : (size_t)split * gridDim.z + e;
     float* dst = (a.per_image || nsplit == 1) ? a.dw : a.part;
+    if constexpr (PAIRS) {
+        // accumulator i, column c: tap 2i + (c >> 4), input channel c & 15.  One pair per round through LDS (fixed-order fold of the
+        // 4 pixel quarters); the 48 columns past the 16 channels are written as zeros
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            __syncthreads();
+            if (k_sub > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((k_sub - 1) * TILE_WAVES + tw) * 16 + r) * 64 + lane] = acc[i][r];
+            }
+            __syncthreads();
+            const int tap = 2 * i + (l31 >> 4);
+            if (k_sub == 0 && tap < TAPS) {
+                float* base = dst + ((slab * TAPS + tap) * a.CoutP) * a.CinP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][r];
+#pragma unroll
+                    for (int k = 1; k < WK; ++k) v += red[(((k - 1) * TILE_WAVES + tw) * 16 + r) * 64 + lane];
+                    const int cout = co0 + co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float* row = base + (size_t)cout * a.CinP + ci0 + (l31 & 15);
+                    row[0] = v;
+                    for (int z = 16; ci0 + (l31 & 15) + z < a.CinP; z += 16) row[z] = 0.f;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t0 = 0; t0 < TAPS; t0 += TPR) {
         __syncthreads();
@@ -560,7 +628,12 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                     hipLaunchKernelGGL(conv_wgrad_dma_kernel<3>, grid, block, sm, st, a, mpw, mph);
                 } else
 #endif
-                if (narrow) {
+                const char* evp = getenv("PMOE_WGRAD_PAIRS");            // A/B: 0 = one tap per MFMA column block
+                if (narrow && a.Cin <= 16 && !(evp && !atoi(evp))) {
+                    if (sm < (size_t)3 * 3 * 2 * 4096) sm = (size_t)3 * 3 * 2 * 4096;
+                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<1, 1, true>>(160 * 1024)));
+                    hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 1, true>), grid, block, sm, st, a, mpw, mph);
+                } else if (narrow) {
                     if (sm < (size_t)3 * 3 * 2 * 4096) sm = (size_t)3 * 3 * 2 * 4096;      // fold room: (WK - 1) x 3 taps x 2 tile waves
                     HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<1, 1>>(160 * 1024)));
                     hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 1>), grid, block, sm, st, a, mpw, mph);
