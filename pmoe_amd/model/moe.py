@@ -127,7 +127,9 @@ class BaseExpert(_Grouped):
         self.speed_encoder = B.make_mlp(**params.speed_encoder)
         self.command_encoder = B.make_mlp(**params.command_encoder)
         if params.backbone.type != "rgb":
-            raise NotImplementedError("backbone.type 'segmentation' (get_unet) is not on the HIP path (SURVEY.md section 2 #3)")
+            raise NotImplementedError("backbone.type 'segmentation' (get_unet) is not built: the reference cannot run it either -- "
+                                      "Sequential(entry_block, UNet(inter_repr=True)) returns a TUPLE (blocks/unet.py:92-95) that "
+                                      "BaseExpert.forward's torch.cat rejects (model/moe.py:92-95); SURVEY.md section 2 #3")
         self.backbone = B.get_backbone(**{**params.backbone.rgb, "n_frames": params.backbone.n_frames})
         self.speed_pred = B.make_mlp(**params.speed_prediction)
         self.action_features = B.make_mlp(**params.action_head)
@@ -206,7 +208,9 @@ class MixtureOfExpertsShared(_Grouped):
         self.speed_encoder = B.make_mlp(**params.speed_encoder)
         self.command_encoder = B.make_mlp(**params.command_encoder)
         if params.backbone.type != "rgb":
-            raise NotImplementedError("backbone.type 'segmentation' (get_unet) is not on the HIP path (SURVEY.md section 2 #3)")
+            raise NotImplementedError("backbone.type 'segmentation' (get_unet) is not built: the reference cannot run it either -- "
+                                      "Sequential(entry_block, UNet(inter_repr=True)) returns a TUPLE (blocks/unet.py:92-95) that "
+                                      "BaseExpert.forward's torch.cat rejects (model/moe.py:92-95); SURVEY.md section 2 #3")
         self.backbone = B.get_backbone(**{**params.backbone.rgb, "n_frames": params.backbone.n_frames})
         self.speed_pred = B.make_mlp(**params.speed_prediction)
         self.action_features = B.make_mlp(**params.action_head)
