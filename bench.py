@@ -435,8 +435,9 @@ def main():
             if code >= 8000:                      # e4m3 operands (BASELINE config 5): same tiles, TL = fp8
                 r, m, n = symbol(code - 8000)
                 return r.replace("<bf16,", "<bf16+e4m3,"), m.replace(f"E{tname}Ev8ConvArgs", "E3fp8Ev8ConvArgs"), n
-            if code == 5007:                      # LDS-DMA staged 3x3 kernel (conv_dma.hip)
-                return "conv3x3_dma_kernel", "void (anonymous namespace)::conv3x3_dma_kernel", 1
+            if code in (5007, 5017):              # LDS-DMA staged 3x3 kernel (conv_dma.hip): 32x32x16 | 16x16x32 MFMA instantiation
+                tf = "true" if code == 5017 else "false"
+                return f"conv3x3_dma_kernel<{tf}>", f"void (anonymous namespace)::conv3x3_dma_kernel<{tf}>", 1
             if code == 5207:                      # ... its stride-2 forward sibling
                 return "conv3x3s2_dma_kernel<false>", "void (anonymous namespace)::conv3x3s2_dma_kernel<false>", 1
             four = code >= 4000
@@ -450,8 +451,9 @@ def main():
                 return f"conv1x1_direct_kernel<{code - 1400}>", f"void (anonymous namespace)::conv1x1_direct_kernel<{code - 1400}>", 1
             if code == 1316:                      # 16-channel stem convolution, direct form (conv_c16.hip)
                 return "conv3x3_c16_kernel", "void (anonymous namespace)::conv3x3_c16_kernel", 1
-            if code >= 1100:                      # filter bank resident in LDS, halo patches by LDS-DMA (conv_res.hip)
-                return "conv3x3_resdma_kernel", "void conv3x3_resdma_kernel", 1
+            if code >= 1100:                      # filter bank resident in LDS, halo patches by LDS-DMA (conv_res.hip); <true>: bias row
+                tf = "true" if code == 1117 else "false"
+                return f"conv3x3_resdma_kernel<{tf}>", f"void conv3x3_resdma_kernel<{tf}>", 1
             if code >= 1000:
                 return f"conv3x3_res_kernel<{code - 1000}>", f"void conv3x3_res_kernel<{code - 1000}", 1
             rb, wm, wn = code // 100, code // 10 % 10, code % 10

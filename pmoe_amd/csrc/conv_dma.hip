@@ -593,6 +593,11 @@ bool conv_dma_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf
     return true;
 }
 
+bool conv_dma_uses_mf16(const ConvArgs& a) {
+    const char* ev = getenv("PMOE_DMA_MF16");
+    return ev ? atoi(ev) != 0 : a.Cin >= 256;
+}
+
 int conv_dma_launch(ConvArgs a, hipStream_t st) {
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
@@ -600,8 +605,7 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     // v_mfma_f32_16x16x32_bf16 for the layers with >= 4 channel chunks (interleaved A/B, profiles/r03_kernel_ab.log: layer3 forward
     // +0.6 %, data gradient +3.5 %; layer4 +3.5 % / +5 %; layer2 -3 % / +0.7 %: the shorter the main loop, the less the shape's
     // higher sustained clock buys).  PMOE_DMA_MF16=0 | 1 forces one shape (read per launch).
-    const char* ev = getenv("PMOE_DMA_MF16");
-    if (ev ? atoi(ev) != 0 : a.Cin >= 256) {
+    if (conv_dma_uses_mf16(a)) {
         HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<true>>(160 * 1024)));
         hipLaunchKernelGGL(conv3x3_dma_kernel<true>, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
     } else {

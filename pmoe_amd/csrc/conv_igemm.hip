@@ -638,8 +638,8 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         ResPlan plan;
         int pb, mpw, mph, mb;
         size_t sm;
-        if (conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm)) return 1000 + plan.log_rb + 100;
-        if (!gemm_skinny_ok(a, dtype) && conv_dma_plan(c, dtype, &mb, &sm, &pb)) return 5007;
+        if (conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm)) return 1000 + plan.log_rb + 100 + (a.bias ? 10 : 0);
+        if (!gemm_skinny_ok(a, dtype) && conv_dma_plan(c, dtype, &mb, &sm, &pb)) return conv_dma_uses_mf16(a) ? 5017 : 5007;
         return PMOE_ERR_UNSUPPORTED;
     }
     if (gemm_skinny_ok(a, dtype)) return 3000;           // gemm_skinny_kernel
@@ -664,12 +664,12 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         if (conv_res_plan(a, dtype, &plan)) {
             int pb, mpw, mph;
             size_t sm;
-            return 1000 + plan.log_rb + (conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) ? 100 : 0);
+            return 1000 + plan.log_rb + (conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) ? 100 + (a.bias ? 10 : 0) : 0);
         }
         ConvArgs d = a;
         int mbd, pb;
         size_t sm;
-        if (conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return 5007;          // conv3x3_dma_kernel
+        if (conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return conv_dma_uses_mf16(a) ? 5017 : 5007;          // conv3x3_dma_kernel<MF16>
         d = a;
         if (conv_dma_s2_plan(d, dtype, &mbd, &sm, &pb)) return 5207;       // conv3x3s2_dma_kernel
     }

@@ -619,6 +619,7 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                 const int nsp = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
                 dim3 grid(nsp * pairs / E, 1, E), block(512, 1, 1);
                 const char* evx = getenv("PMOE_WGRAD_PIPE");
+                const char* evp = getenv("PMOE_WGRAD_PAIRS");            // A/B: 0 = one tap per MFMA column block
 #ifdef PMOE_STAMP          // tools build only (tools/stamp_conv.py --build): timing modes with WRONG results, see the kernel's main loop
                 if (evx && atoi(evx) == 2) {
                     HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<2>>(160 * 1024)));
@@ -628,7 +629,6 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                     hipLaunchKernelGGL(conv_wgrad_dma_kernel<3>, grid, block, sm, st, a, mpw, mph);
                 } else
 #endif
-                const char* evp = getenv("PMOE_WGRAD_PAIRS");            // A/B: 0 = one tap per MFMA column block
                 if (narrow && a.Cin <= 16 && !(evp && !atoi(evp))) {
                     if (sm < (size_t)3 * 3 * 2 * 4096) sm = (size_t)3 * 3 * 2 * 4096;
                     HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<1, 1, true>>(160 * 1024)));

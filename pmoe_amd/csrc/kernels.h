@@ -59,6 +59,7 @@ int gemm_skinny_launch(const ConvArgs& a, hipStream_t st);
 // LDS-DMA 3x3 kernel for the >= 128-channel stride-1 layers (conv_dma.hip)
 bool conv_dma_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
 int conv_dma_launch(ConvArgs a, hipStream_t st);
+bool conv_dma_uses_mf16(const ConvArgs& a);      // which instantiation: <true> = v_mfma_f32_16x16x32_bf16
 // ... and its stride-2 forward sibling (parity planes gathered by the DMA's per-lane source addresses)
 bool conv_dma_s2_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
 int conv_dma_s2_launch(ConvArgs a, hipStream_t st);

@@ -80,7 +80,8 @@ def test_conv_plan_reports_the_kernel_instantiation():
         return load().pmoe_conv2d_plan(C.byref(d))
     assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1107                 # conv3x3_resdma_kernel (filter bank resident, LDS-DMA patches)
     assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1316                 # 12(16)-channel stem: conv3x3_c16_kernel (direct form)
-    assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 5007                # conv3x3_dma_kernel (LDS-DMA staged, conv_dma.hip)
+    assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 5017                # conv3x3_dma_kernel<true> (LDS-DMA staged, 16x16x32 MFMA shape from 256 input channels)
+    assert plan(128, 128, 64, 3, 1, torch.bfloat16) == 5007                # conv3x3_dma_kernel<false> (32x32x16)
     assert plan(128, 256, 64, 1, 2, torch.bfloat16) == 1404                # 1x1 stride 2 (downsample): conv1x1_direct_kernel<4>
     assert plan(256, 512, 32, 1, 2, torch.bfloat16) == 1402                # ... 64-channel slabs from 256 input channels
     assert plan(256, 256, 32, 3, 1, torch.float32) == 722                  # f32: 4-wave 128x128 tile, 32-channel chunks
