@@ -26,7 +26,11 @@
 // running across tile boundaries (the next tile's operands land under the epilogue) -- 4-8 % slower: the epilogue's
 // stores share the in-order vmcnt counter with the prefetch, the cold next-tile patch stalls the counted waits of the
 // last chunk, and the kernel needs all 256 VGPRs; DMA requests issued between the MFMA groups, staggered between the two
-// waves of a SIMD -- within 1 %.
+// waves of a SIMD -- within 1 %.  Round 3: TWO workgroups per CU (one patch buffer + a 2-slot weight ring = 75 KiB, <= 128 VGPRs,
+// weight-tile lookahead of one tap, the next chunk's patch requested after the current chunk's last tap) so that one
+// workgroup's prologue / epilogue / barrier waits are covered by the other's MFMAs: layer2 -10 %, layer3 -2 % / -9 %, layer4
+// +3 % / 0 % (forward / data gradient) -- the exposed DMA round trip per chunk and the thin weight ring cost what the
+// co-residence buys; dropped.
 #include "conv_common.h"
 #include <stdlib.h>
 #include "kernels.h"
