@@ -131,6 +131,11 @@ typedef struct pmoe_wgrad_desc {
                            * gate gradient of the stem from per-image filter gradients); needs ho*wo >= 256 */
     float* part_ws;       /* K-split scratch, pmoe_conv2d_wgrad_ws_floats() floats (may be null when that is 0) */
     int64_t part_ws_floats;
+    float* grads;         /* optional (round 3): the parameters' own gradient [E][cout_real][cin_real][ks][ks] f32 (what
+                           * autograd leaves in nn.Conv2d.weight.grad / nn.Linear.weight.grad of the E experts, contiguous);
+                           * when set, the K-split fold writes it directly and dw_ws is only scratch: no
+                           * pmoe_unpack_conv_wgrad launch afterwards.  Not with per_image. */
+    int32_t cout_real, cin_real;
 } pmoe_wgrad_desc;
 int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
 /* floats of part_ws the launch needs for this descriptor (0: single K slice or per_image); <0 = error.  Pointers in the

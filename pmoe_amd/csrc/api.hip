@@ -95,6 +95,8 @@ static int to_wgrad_args(const pmoe_wgrad_desc* d, WgradArgs& a) {
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.dy_ld = d->dy_ld; a.dy_coff = d->dy_coff;
     a.ipe = d->ipe; a.x_shared = d->x_shared;
     a.ks = d->ks; a.stride = d->stride; a.pad = d->pad; a.per_image = d->per_image;
+    a.grads = d->grads; a.cout_real = d->cout_real; a.cin_real = d->cin_real;
+    if (a.grads && (a.per_image || a.cout_real <= 0 || a.cin_real <= 0 || a.cout_real > a.CoutP || a.cin_real > a.CinP)) return PMOE_ERR_ARG;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = a.mb_per_wg = 0;
     a.slice_fastest = 0;
     return 0;

@@ -48,6 +48,8 @@ struct WgradArgs {
     int ipe, x_shared;
     int ks, stride, pad;
     int per_image;         // 1: dw is [N][taps][CoutP][CinP] -- one slab per IMAGE (no sum over the expert's images)
+    float* grads;          // optional: the parameter's own gradient [E][cout_real][cin_real][ks][ks] f32, written INSTEAD of dw
+    int cout_real, cin_real;
     int lTW, lTH, TN, n_groups, tiles_y, tiles_x, mb_per_wg;
     int slice_fastest;     // launcher: grid order of round 1 (A/B switch)
 };

@@ -458,16 +458,19 @@ class ExpertGroupEngine:
         cpw = (layer.cinp + ckw - 1) // ckw * ckw
         cow = (layer.cout_st + ckw - 1) // ckw * ckw
         ws = self._wgrad_ws(E * layer.taps * cow * cpw)      # overwritten by the launch (no atomics, nothing to zero)
+        parts = getattr(layer, "parts", None)
+        # plain layers: the launch's own fold writes the parameter-layout gradient (no separate unpack launch)
+        direct = parts is None and not hasattr(layer, "store_grads")
         ops.set_meta(flop=flop, name=layer.name)
         ops.conv2d_wgrad(x.t, dy, ws, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B,
                          ks=layer.ks, stride=layer.stride, pad=layer.pad, x_shared=in_shared, x_coff=x.coff,
-                         dy_coff=o.coff)
-        parts = getattr(layer, "parts", None)
+                         dy_coff=o.coff, grads=self._grad_slot("w", layer) if direct else None, grads_cout=layer.cout,
+                         grads_cin=layer.cin)
         if hasattr(layer, "store_grads"):       # derived layouts (ConvTranspose2d as a 4*Cout-row 1x1 layer, engine_punet)
             layer.store_grads(self, ws, cow, cpw)
             return
         if parts is None:
-            ops.unpack_conv_wgrad(ws, self._grad_slot("w", layer), E, layer.cout, layer.cin, layer.ks, cow, cpw)
+            pass                                           # written by the launch (direct)
         else:
             full = torch.empty(E, layer.cout, layer.cin, dtype=F32, device=self.dev)
             ops.unpack_conv_wgrad(ws, full, E, layer.cout, layer.cin, 1, cow, cpw)

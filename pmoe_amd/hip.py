@@ -57,6 +57,7 @@ class WgradDesc(C.Structure):
         ("ks", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dtype", C.c_int32),
         ("per_image", C.c_int32),
         ("part_ws", C.c_void_p), ("part_ws_floats", C.c_int64),
+        ("grads", C.c_void_p), ("cout_real", C.c_int32), ("cin_real", C.c_int32),
     ]
 
 

@@ -113,9 +113,10 @@ def _wgrad_part_ws(device, floats):
 
 
 def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, x_shared=False, x_coff=0, dy_coff=0,
-                 per_image=False, plan_only=False):
+                 per_image=False, plan_only=False, grads=None, grads_cout=0, grads_cin=0):
     """dw_ws [E | N][ks*ks][coutp][cinp] f32 is OVERWRITTEN with the weight gradient (deterministic: fixed-order folds
-    of the pixel split, no atomics; csrc/conv_wgrad.hip)."""
+    of the pixel split, no atomics; csrc/conv_wgrad.hip).  ``grads`` (flat f32, E * grads_cout * grads_cin * ks * ks): the
+    parameters' own gradient layout, written by the fold instead of dw_ws (which then is scratch only)."""
     nin, h, w_, ldx = _nhwc(x, "x")
     n, ho, wo, ldy = _nhwc(dy, "dy")
     d = WgradDesc()
@@ -126,6 +127,10 @@ def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, 
     d.ipe, d.x_shared = ipe, int(x_shared)
     d.ks, d.stride, d.pad, d.dtype = ks, stride, pad, dt(x)
     d.per_image = int(per_image)
+    if grads is not None:
+        if per_image or grads.dtype != torch.float32 or grads.numel() != (n // ipe) * grads_cout * grads_cin * ks * ks:
+            raise ValueError("conv2d_wgrad: grads must hold E * cout * cin * ks * ks float32 values (not with per_image)")
+        d.grads, d.cout_real, d.cin_real = ptr(grads, "grads", torch.float32), int(grads_cout), int(grads_cin)
     if dw_ws.numel() < (n if per_image else n // ipe) * ks * ks * coutp * cinp:
         raise ValueError("conv2d_wgrad: workspace too small")
     need = load().pmoe_conv2d_wgrad_ws_floats(C.byref(d))

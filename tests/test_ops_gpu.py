@@ -172,6 +172,12 @@ def _conv_case(case, dtype, plan=None):
     ops.unpack_conv_wgrad(ws_buf, grads, E, cout, cin, ks, cow, cpw)
     for e in range(E):
         close(grads[e], wr[e].grad, dtype, f"conv wgrad e{e}")
+    # round 3: the launch's own K-split fold writes the parameter-layout gradient (WgradDesc.grads): bit-identical to the
+    # workspace + pmoe_unpack_conv_wgrad pair (same fixed-order fold)
+    direct = torch.full((E, cout, cin, ks, ks), 9.0, device=DEV)
+    ops.conv2d_wgrad(xd, dyd, ws_buf, cin=cinp, cout=r16(cout), cinp=cpw, coutp=cow, ipe=ipe, ks=ks, stride=stride, pad=pad,
+                     grads=direct.view(-1), grads_cout=cout, grads_cin=cin)
+    assert torch.equal(direct, grads), "fold + unpack in the weight-gradient launch differs from the two-launch path"
 
 
 
