@@ -136,8 +136,12 @@ typedef struct pmoe_wgrad_desc {
                            * when set, the K-split fold writes it directly and dw_ws is only scratch: no
                            * pmoe_unpack_conv_wgrad launch afterwards.  Not with per_image. */
     int32_t cout_real, cin_real;
+    int32_t defer_fold;   /* 1: pmoe_conv2d_wgrad runs the MFMA launch only; the caller runs pmoe_conv2d_wgrad_fold(d) afterwards
+                           * (so that a profiler / per-launch events see the two kernels apart) */
 } pmoe_wgrad_desc;
 int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
+/* the tail of pmoe_conv2d_wgrad for the same descriptor: K-split slabs -> dw_ws, or -> `grads` when set */
+int pmoe_conv2d_wgrad_fold(const pmoe_wgrad_desc* d, void* stream);
 /* floats of part_ws the launch needs for this descriptor (0: single K slice or per_image); <0 = error.  Pointers in the
  * descriptor are not read. */
 int64_t pmoe_conv2d_wgrad_ws_floats(const pmoe_wgrad_desc* d);

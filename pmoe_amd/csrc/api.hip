@@ -95,7 +95,7 @@ static int to_wgrad_args(const pmoe_wgrad_desc* d, WgradArgs& a) {
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.dy_ld = d->dy_ld; a.dy_coff = d->dy_coff;
     a.ipe = d->ipe; a.x_shared = d->x_shared;
     a.ks = d->ks; a.stride = d->stride; a.pad = d->pad; a.per_image = d->per_image;
-    a.grads = d->grads; a.cout_real = d->cout_real; a.cin_real = d->cin_real;
+    a.grads = d->grads; a.cout_real = d->cout_real; a.cin_real = d->cin_real; a.defer_fold = d->defer_fold;
     if (a.grads && (a.per_image || a.cout_real <= 0 || a.cin_real <= 0 || a.cout_real > a.CoutP || a.cin_real > a.CinP)) return PMOE_ERR_ARG;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = a.mb_per_wg = 0;
     a.slice_fastest = 0;
@@ -108,6 +108,14 @@ int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream) {
     if (rc) return rc;
     if (!d->x || !d->dy || !d->dw_ws) return PMOE_ERR_ARG;
     return conv_wgrad_launch(a, d->dtype, (hipStream_t)stream);
+}
+
+int pmoe_conv2d_wgrad_fold(const pmoe_wgrad_desc* d, void* stream) {
+    WgradArgs a;
+    const int rc = to_wgrad_args(d, a);
+    if (rc) return rc;
+    if (!d->dw_ws) return PMOE_ERR_ARG;
+    return conv_wgrad_fold(a, d->dtype, (hipStream_t)stream);
 }
 
 int pmoe_conv2d_wgrad_plan(const pmoe_wgrad_desc* d) {

@@ -556,8 +556,8 @@ __global__ void __launch_bounds__(256) wgrad_fold_unpack_kernel(const float* __r
 }
 
 // the tail of a weight-gradient launch: slabs -> a.dw (wgrad_reduce_kernel) or, with a.grads, straight into the parameter layout
-static int wgrad_finish(const WgradArgs& a, int E, int taps, int nsplit, hipStream_t st) {
-    if (a.per_image) return 0;
+static int wgrad_finish(const WgradArgs& a, int E, int taps, int nsplit, hipStream_t st, bool force = false) {
+    if (a.per_image || (a.defer_fold && !force)) return 0;
     const long long total = (long long)E * taps * a.CoutP * a.CinP;
     if (a.grads) {
         const float* src = nsplit > 1 ? a.part : a.dw;
@@ -698,6 +698,20 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
         return a.ks == 3 ? launch_wg<T, 9, M2>(a, E, smem, st) : launch_wg<T, 1, M2>(a, E, smem, st);
     }
     return PMOE_ERR_UNSUPPORTED;
+}
+
+// the deferred tail (WgradArgs.defer_fold): the K-split count is the one the launch used (same planning code)
+int conv_wgrad_fold(const WgradArgs& a, int dtype, hipStream_t st) {
+    if (a.per_image) return 0;
+    long long ws = 0;
+    const int rc = dtype == PMOE_DT_BF16 ? wgrad_dtype<bf16>(a, nullptr, true, &ws)
+                 : dtype == PMOE_DT_F32 ? wgrad_dtype<float>(a, nullptr, true, &ws) : PMOE_ERR_ARG;
+    if (rc) return rc;
+    const int E = a.N / a.ipe, taps = a.ks * a.ks;
+    const long long total = (long long)E * taps * a.CoutP * a.CinP;
+    const int nsplit = ws > 0 ? (int)(ws / total) : 1;
+    if (nsplit > 1 && (!a.part || a.part_floats < ws)) return PMOE_ERR_ARG;
+    return wgrad_finish(a, E, taps, nsplit, st, true);
 }
 
 int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {

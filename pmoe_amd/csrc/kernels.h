@@ -50,6 +50,7 @@ struct WgradArgs {
     int per_image;         // 1: dw is [N][taps][CoutP][CinP] -- one slab per IMAGE (no sum over the expert's images)
     float* grads;          // optional: the parameter's own gradient [E][cout_real][cin_real][ks][ks] f32, written INSTEAD of dw
     int cout_real, cin_real;
+    int defer_fold;        // 1: conv_wgrad_launch stops after the MFMA kernel (conv_wgrad_fold runs the tail)
     int lTW, lTH, TN, n_groups, tiles_y, tiles_x, mb_per_wg;
     int slice_fastest;     // launcher: grid order of round 1 (A/B switch)
 };
@@ -74,5 +75,6 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st);
 int conv_igemm_mblocks(const ConvArgs& a, int dtype);
 int conv_igemm_plan(const ConvArgs& a, int dtype);
 int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);
+int conv_wgrad_fold(const WgradArgs& a, int dtype, hipStream_t st);
 long long conv_wgrad_ws_floats(const WgradArgs& a, int dtype);
 int conv_wgrad_plan(const WgradArgs& a, int dtype);

@@ -462,10 +462,12 @@ class ExpertGroupEngine:
         # plain layers: the launch's own fold writes the parameter-layout gradient (no separate unpack launch)
         direct = parts is None and not hasattr(layer, "store_grads")
         ops.set_meta(flop=flop, name=layer.name)
-        ops.conv2d_wgrad(x.t, dy, ws, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B,
-                         ks=layer.ks, stride=layer.stride, pad=layer.pad, x_shared=in_shared, x_coff=x.coff,
-                         dy_coff=o.coff, grads=self._grad_slot("w", layer) if direct else None, grads_cout=layer.cout,
-                         grads_cin=layer.cin)
+        d = ops.conv2d_wgrad(x.t, dy, ws, cin=layer.cinp, cout=layer.cout_st, cinp=cpw, coutp=cow, ipe=self.B,
+                             ks=layer.ks, stride=layer.stride, pad=layer.pad, x_shared=in_shared, x_coff=x.coff,
+                             dy_coff=o.coff, grads=self._grad_slot("w", layer) if direct else None, grads_cout=layer.cout,
+                             grads_cin=layer.cin, defer_fold=direct)
+        if direct:
+            ops.conv2d_wgrad_fold(d)
         if hasattr(layer, "store_grads"):       # derived layouts (ConvTranspose2d as a 4*Cout-row 1x1 layer, engine_punet)
             layer.store_grads(self, ws, cow, cpw)
             return

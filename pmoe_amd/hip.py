@@ -57,7 +57,7 @@ class WgradDesc(C.Structure):
         ("ks", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dtype", C.c_int32),
         ("per_image", C.c_int32),
         ("part_ws", C.c_void_p), ("part_ws_floats", C.c_int64),
-        ("grads", C.c_void_p), ("cout_real", C.c_int32), ("cin_real", C.c_int32),
+        ("grads", C.c_void_p), ("cout_real", C.c_int32), ("cin_real", C.c_int32), ("defer_fold", C.c_int32),
     ]
 
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "pmoe_conv2d_stat_rows": [C.POINTER(ConvDesc)],
     "pmoe_conv2d_plan": [C.POINTER(ConvDesc)],
     "pmoe_conv2d_wgrad": [C.POINTER(WgradDesc), _P],
+    "pmoe_conv2d_wgrad_fold": [C.POINTER(WgradDesc), _P],
     "pmoe_conv2d_wgrad_ws_floats": [C.POINTER(WgradDesc)],
     "pmoe_conv2d_wgrad_plan": [C.POINTER(WgradDesc)],
     "pmoe_pack_conv_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

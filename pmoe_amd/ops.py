@@ -113,10 +113,11 @@ def _wgrad_part_ws(device, floats):
 
 
 def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, x_shared=False, x_coff=0, dy_coff=0,
-                 per_image=False, plan_only=False, grads=None, grads_cout=0, grads_cin=0):
+                 per_image=False, plan_only=False, grads=None, grads_cout=0, grads_cin=0, defer_fold=False):
     """dw_ws [E | N][ks*ks][coutp][cinp] f32 is OVERWRITTEN with the weight gradient (deterministic: fixed-order folds
     of the pixel split, no atomics; csrc/conv_wgrad.hip).  ``grads`` (flat f32, E * grads_cout * grads_cin * ks * ks): the
-    parameters' own gradient layout, written by the fold instead of dw_ws (which then is scratch only)."""
+    parameters' own gradient layout, written by the fold instead of dw_ws (which then is scratch only).  ``defer_fold``: run the
+    MFMA launch only and return the descriptor for :func:`conv2d_wgrad_fold` (the two kernels are then timed apart)."""
     nin, h, w_, ldx = _nhwc(x, "x")
     n, ho, wo, ldy = _nhwc(dy, "dy")
     d = WgradDesc()
@@ -143,8 +144,14 @@ def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, 
         d.part_ws, d.part_ws_floats = ptr(part, "part_ws"), part.numel()
     if _prof is not None:            # profiling: remember which kernel instantiation serves this launch
         _launch_info["kernel"] = load().pmoe_conv2d_wgrad_plan(C.byref(d))
+    d.defer_fold = int(defer_fold)
     check(load().pmoe_conv2d_wgrad(C.byref(d), stream_ptr()), "pmoe_conv2d_wgrad")
-    return dw_ws
+    return d if defer_fold else dw_ws
+
+
+def conv2d_wgrad_fold(d):
+    """the deferred tail of :func:`conv2d_wgrad` (``defer_fold``): K-split slabs -> the parameter-layout gradient / dw_ws"""
+    check(load().pmoe_conv2d_wgrad_fold(C.byref(d), stream_ptr()), "pmoe_conv2d_wgrad_fold")
 
 
 def pack_conv_weights(ptr_tab, fwd, dgrd, E, cout, cin, ks, coutp, cinp, cinp2, coutp2, dtype):
@@ -443,7 +450,7 @@ def _timed(fn):
     return wrapper
 
 
-for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "stem_tail_pooled", "stem_tail_combine", "conv2d", "conv2d_wgrad", "pack_conv_weights", "pack_conv_weights_scaled", "pack_conv_weights_gated", "unpack_conv_wgrad", "pack_bias", "colstats",
+for _n in ("stem_tail_stats", "stem_tail_pool", "stem_tail_bwd", "stem_tail_pooled", "stem_tail_combine", "conv2d", "conv2d_wgrad", "conv2d_wgrad_fold", "pack_conv_weights", "pack_conv_weights_scaled", "pack_conv_weights_gated", "unpack_conv_wgrad", "pack_bias", "colstats",
            "reduce_partials", "bn_finalize", "bn_apply", "bn_apply_gap", "bn_bwd_reduce", "bn_bwd_finalize", "bn_bwd_apply",
            "maxpool_fwd", "maxpool_bwd", "gap_partial", "gap_finish", "gap_bwd", "eca_gate", "eca_scale",
            "eca_bwd_small", "eca_bwd_apply", "eca_stem_fold", "nchw_to_nhwc", "pad_rows", "gate_mixture_fwd", "gate_mixture_bwd",

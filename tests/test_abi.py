@@ -51,7 +51,7 @@ def test_struct_layouts_match_c(lib):
     # pad + 2 pointers + int32 + pad
     assert ctypes.sizeof(hip.ConvDesc) == 192 == lib.pmoe_abi_sizeof(0)
     assert ctypes.sizeof(hip.WgradDesc) == lib.pmoe_abi_sizeof(1)
-    assert ctypes.sizeof(hip.WgradDesc) == 3 * 8 + 19 * 4 + 4 + 2 * 8 + 8 + 2 * 4  # int32 block padded to 8, part_ws + its size, grads + 2 int32
+    assert ctypes.sizeof(hip.WgradDesc) == 3 * 8 + 19 * 4 + 4 + 2 * 8 + 8 + 4 * 4  # int32 block padded to 8, part_ws + its size, grads + 3 int32 (+ pad)
     from pmoe_amd import optim
     assert ctypes.sizeof(optim.OptTensor) == 64 == lib.pmoe_abi_sizeof(2)
     assert optim.CHUNK == 16384          # PMOE_OPT_CHUNK

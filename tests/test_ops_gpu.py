@@ -178,6 +178,12 @@ def _conv_case(case, dtype, plan=None):
     ops.conv2d_wgrad(xd, dyd, ws_buf, cin=cinp, cout=r16(cout), cinp=cpw, coutp=cow, ipe=ipe, ks=ks, stride=stride, pad=pad,
                      grads=direct.view(-1), grads_cout=cout, grads_cin=cin)
     assert torch.equal(direct, grads), "fold + unpack in the weight-gradient launch differs from the two-launch path"
+    # ... and as two calls (the engine's form: the MFMA kernel and the fold are then timed apart)
+    direct.fill_(9.0)
+    d = ops.conv2d_wgrad(xd, dyd, ws_buf, cin=cinp, cout=r16(cout), cinp=cpw, coutp=cow, ipe=ipe, ks=ks, stride=stride, pad=pad,
+                         grads=direct.view(-1), grads_cout=cout, grads_cin=cin, defer_fold=True)
+    ops.conv2d_wgrad_fold(d)
+    assert torch.equal(direct, grads)
 
 
 
