@@ -537,21 +537,33 @@ template <int TAPS>
 __global__ void __launch_bounds__(256) wgrad_fold_unpack_kernel(const float* __restrict__ slabs, float* __restrict__ g,
                                                                 const int nsplit, const long long slab_stride, const int cout,
                                                                 const int cin, const int CoutP, const int CinP) {
+    // block = 64 consecutive (cout, cin) pairs x 4 tap groups (a wave = one tap group: its 64 lanes read 64 consecutive input
+    // channels of one slab row, 256 contiguous bytes); the 64 x TAPS results leave through LDS as one contiguous run
     const int e = blockIdx.y;
     const long long n = (long long)cout * cin;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int ci = (int)(i % cin), co = (int)(i / cin);
-        float v[TAPS];
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const float* p = slabs + (((size_t)e * TAPS + t) * CoutP + co) * CinP + ci;
-            float s = p[0];
-            for (int k = 1; k < nsplit; ++k) s += p[(size_t)k * slab_stride];
-            v[t] = s;
+    const int pr = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    __shared__ float sm[64 * TAPS];
+    for (long long i0 = (long long)blockIdx.x * 64; i0 < n; i0 += (long long)gridDim.x * 64) {
+        const long long i = i0 + pr;
+        if (i < n) {
+            const int ci = (int)(i % cin), co = (int)(i / cin);
+            for (int t = tg; t < TAPS; t += 4) {
+                const float* p = slabs + (((size_t)e * TAPS + t) * CoutP + co) * CinP + ci;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // (fixed association: bit-reproducible)
+                int k = 0;
+                for (; k + 4 <= nsplit; k += 4) {
+                    s0 += p[(size_t)k * slab_stride]; s1 += p[(size_t)(k + 1) * slab_stride];
+                    s2 += p[(size_t)(k + 2) * slab_stride]; s3 += p[(size_t)(k + 3) * slab_stride];
+                }
+                for (; k < nsplit; ++k) s0 += p[(size_t)k * slab_stride];
+                sm[pr * TAPS + t] = (s0 + s1) + (s2 + s3);
+            }
         }
-        float* o = g + ((size_t)e * n + i) * TAPS;
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) o[t] = v[t];
+        __syncthreads();
+        const long long cnt = (n - i0 < 64 ? n - i0 : 64) * TAPS;
+        float* o = g + ((size_t)e * n + i0) * TAPS;
+        for (int j = threadIdx.x; j < cnt; j += 256) o[j] = sm[j];
+        __syncthreads();
     }
 }
 
@@ -561,8 +573,8 @@ static int wgrad_finish(const WgradArgs& a, int E, int taps, int nsplit, hipStre
     const long long total = (long long)E * taps * a.CoutP * a.CinP;
     if (a.grads) {
         const float* src = nsplit > 1 ? a.part : a.dw;
-        long long blocks = ((long long)a.cout_real * a.cin_real + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
+        long long blocks = ((long long)a.cout_real * a.cin_real + 63) / 64;
+        if (blocks > 4096) blocks = 4096;
         dim3 grid((unsigned)blocks, E);
         if (taps == 9)
             hipLaunchKernelGGL(wgrad_fold_unpack_kernel<9>, grid, dim3(256), 0, st, src, a.grads, nsplit, total, a.cout_real,

@@ -177,13 +177,16 @@ def _conv_case(case, dtype, plan=None):
     direct = torch.full((E, cout, cin, ks, ks), 9.0, device=DEV)
     ops.conv2d_wgrad(xd, dyd, ws_buf, cin=cinp, cout=r16(cout), cinp=cpw, coutp=cow, ipe=ipe, ks=ks, stride=stride, pad=pad,
                      grads=direct.view(-1), grads_cout=cout, grads_cin=cin)
-    assert torch.equal(direct, grads), "fold + unpack in the weight-gradient launch differs from the two-launch path"
+    # (the fold sums the K-split slabs in four interleaved chains -- a fixed order, but not the sequential one of
+    #  wgrad_reduce_kernel: equal to f32 rounding, bit-identical between its own two call forms below)
+    assert (direct - grads).abs().max().item() <= 1e-5 * grads.abs().max().item() + 1e-7, "fold + unpack differs from the two-launch path"
+    first = direct.clone()
     # ... and as two calls (the engine's form: the MFMA kernel and the fold are then timed apart)
     direct.fill_(9.0)
     d = ops.conv2d_wgrad(xd, dyd, ws_buf, cin=cinp, cout=r16(cout), cinp=cpw, coutp=cow, ipe=ipe, ks=ks, stride=stride, pad=pad,
                          grads=direct.view(-1), grads_cout=cout, grads_cin=cin, defer_fold=True)
     ops.conv2d_wgrad_fold(d)
-    assert torch.equal(direct, grads)
+    assert torch.equal(direct, first)
 
 
 
