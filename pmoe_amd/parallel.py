@@ -31,6 +31,8 @@ class BucketedAllReduce:
     backward ends and therefore cannot be hidden -- is kept small); default: n_buckets equal slices."""
     last_issued = 0          # collectives launched by the most recent backward of this process (bench.py / tests report it)
     last_mode = None
+    _warned = False
+    _forced_mode = None      # set to "ring" for the rest of the process when this torch build refuses the in-place reduce-scatter
 
     def __init__(self, group=None, n_buckets=6, always=False, mode=None):
         import os
@@ -40,7 +42,7 @@ class BucketedAllReduce:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.single = self.world == 1 and not (always and dist.is_initialized())    # nothing to exchange
         self._nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
-        self.mode = mode or os.environ.get("PMOE_DP_COLLECTIVE", "rs_ag")
+        self.mode = mode or BucketedAllReduce._forced_mode or os.environ.get("PMOE_DP_COLLECTIVE", "rs_ag")
         if self.mode not in ("rs_ag", "ring"):
             raise ValueError(f"PMOE_DP_COLLECTIVE: 'rs_ag' or 'ring', got {self.mode!r}")
 
@@ -66,7 +68,16 @@ class BucketedAllReduce:
             mine = chunk[self.rank * per:(self.rank + 1) * per]
             if self._nccl:
                 # in place: the output is the rank's own slice of the input (NCCL/RCCL's in-place reduce-scatter layout)
-                w1 = dist.reduce_scatter_tensor(mine, chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                try:
+                    w1 = dist.reduce_scatter_tensor(mine, chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                except (RuntimeError, ValueError) as err:
+                    # an argument check of this torch build refusing the aliased views (raised on every rank alike, before
+                    # anything is enqueued): keep the job alive on the ring path and say so once
+                    if not BucketedAllReduce._warned:
+                        BucketedAllReduce._warned = True
+                        print(f"pmoe_amd.parallel: in-place reduce-scatter refused ({err}); falling back to all_reduce", flush=True)
+                    self.mode = BucketedAllReduce._forced_mode = "ring"
+                    return self._launch(lo, hi)
                 w2 = dist.all_gather_into_tensor(chunk, mine, group=self.group, async_op=True)
                 self.works += [(w1, None), (w2, None)]
             else:
