@@ -90,6 +90,9 @@ typedef struct pmoe_conv_desc {
     int32_t w_fp8;
     float in_scale;
     const float* out_scale;
+    int32_t in_fp8;       /* round 3 (with w_fp8): `in` holds e4m3 BYTES too -- e4m3(x * in_scale), written by pmoe_bn_apply's fp8
+                           * side output; in_ld / in_coff count bytes.  Dense 3x3 stride 1, cin % 128 == 0: the block-scaled
+                           * matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 (plan code 8507), twice the bf16 rate */
     const float* bn_coef; /* PMOE_RES_DBN: [4][n / bn_ipe][cout] f32 = mean, invstd, gamma*invstd, beta of the BatchNorm  */
     int32_t bn_ipe;       /* PMOE_RES_DBN: images per BatchNorm parameter set (= ipe unless the conv runs per image)     */
 } pmoe_conv_desc;
@@ -109,6 +112,7 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
  *   5007 | 5017              conv3x3_dma_kernel<false | true>      (LDS-DMA staged 3x3 stride-1 kernel, >= 128 channels, conv_dma.hip; <true>: 16x16x32 MFMA shape, >= 256 input channels)
  *   5207                     conv3x3s2_dma_kernel                  (its stride-2 forward sibling: parity planes gathered by the DMA, conv_dma.hip)
  *   8000 + one of the above  the same tile with e4m3 operands (w_fp8)
+ *   8507                     conv3x3_dma_f8_kernel                 (w_fp8 + in_fp8: LDS-DMA kernel on the block-scaled fp8 MFMA, conv_dma.hip)
  *   LOG_RB*100 + WM*10 + WN  conv_igemm_kernel<T, LOG_RB, WM, WN>  (halo-patch implicit GEMM, conv_igemm.hip)
  *   4000 + the latter        the four parity-class launches of a stride-2 3x3 data gradient */
 int pmoe_conv2d_plan(const pmoe_conv_desc* d);
@@ -213,9 +217,11 @@ int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const voi
                      int32_t C, const float* shiftc, void* stream);
 /* y = [relu]( (x - mean)*scale + shift [+ res] ); y is dense (y_ld = 0 or C) or the channel window
  * [y_coff, y_coff + C) of rows y_ld wide -- the skip half of a U-Net concatenation buffer (unet.py:72) */
+/* y_fp8 (optional, bf16 + dense y only; round 3, BASELINE config 5): the same activation once more as e4m3(bf16(y) * in_scale)
+ * bytes [rows][C] -- the input of the block-scaled fp8 convolution that consumes it (pmoe_conv_desc.in_fp8) */
 int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, const float* mean,
                   int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t y_ld, int32_t y_coff,
-                  int32_t dtype, void* stream);
+                  int32_t dtype, void* y_fp8, float in_scale, void* stream);
 /* pmoe_bn_apply (no residual, dense y) that ALSO returns pmoe_gap_partial(y)'s partial sums [N][nparts][C], bit-identical to a
  * separate pmoe_gap_partial pass over the stored y: BatchNorm -> ReLU -> EfficientBlock of the stem (basics.py:113-123) without
  * re-reading the activation for the block's global average pool.  N images, ipe images per expert, HW pixels per image. */

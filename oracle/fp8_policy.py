@@ -13,8 +13,13 @@ Policy (include/pmoe_hip.h ``pmoe_pack_conv_weights_fp8`` / ``pmoe_conv_desc.w_f
   * forward : y = conv(Q(x), Q(W)) accumulated in f32.
   * backward: straight-through -- dx = conv^T(dy, Q(W)) on the bf16 matrix cores with the exactly dequantised weights;
               dW = dy (x) x with the UNQUANTISED bf16 input (the weight-gradient kernel reads the stored activation).
-  * which   : the 3x3 / 1x1 convolutions of ResNet layer1-4 (model/blocks/backbone.py:57-70; 75.5 % of the forward MACs).
-              The stem keeps bf16 (12 input channels; the ECA gate is folded into per-image weight packs).
+  * which   : (round 3) the dense 3x3 stride-1 convolutions with whole 128-channel chunks -- ResNet layer2-4, 9 convolutions,
+              46 % of the forward MACs (model/blocks/backbone.py:57-70) -- i.e. the launches the block-scaled fp8 matrix
+              instruction v_mfma_scale_f32_32x32x64_f8f6f4 serves at twice the bf16 rate.  Round 2 also quantised layer1, the
+              stride-2 and the 1x1 convolutions, on kernels that were SLOWER than bf16; they are bf16 again.  The stem keeps
+              bf16 (12 input channels; the ECA gate is folded into per-image weight packs).
+  * where   : the activation is quantised ONCE, by the BatchNorm pass that produces it (e4m3(bf16(y) * IN_SCALE) written next
+              to the bf16 tensor), not in the consumer's loader; same values either way.
 """
 import torch
 import torch.nn as nn
@@ -70,7 +75,10 @@ class Fp8Conv(torch.autograd.Function):
 
 
 def selected(name, mod):
-    return isinstance(mod, nn.Conv2d) and ".backbone.layer" in "." + name and mod.in_channels % 64 == 0
+    """round 3: the dense 3x3 stride-1 convolutions of ResNet layer2-4 (whole 128-channel chunks) -- the launches the block-scaled
+    fp8 matrix instruction serves; the 64-channel layer1, the stride-2 and the 1x1 convolutions stay bf16"""
+    return (isinstance(mod, nn.Conv2d) and ".backbone.layer" in "." + name and mod.kernel_size == (3, 3)
+            and mod.stride == (1, 1) and mod.in_channels % 128 == 0)
 
 
 def apply_fp8_policy(model, in_scale=IN_SCALE):

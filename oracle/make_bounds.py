@@ -153,6 +153,12 @@ def main():
     torch.manual_seed(0)
     path = GOLDEN / "bf16_bounds.pt"
     keep_grads = "--keep-grads" in sys.argv and path.exists()   # reuse the (slow) float64 gradient records
+    if "--fp8-only" in sys.argv:                                # refresh the fp8-policy records after a policy change (round 3)
+        out = torch.load(path, weights_only=False)
+        for name in FP8_CASES:
+            fp8_bounds(name, out["forward"][name])
+        torch.save(out, path)
+        return
     if "--only" in sys.argv:                                    # add / refresh the forward record of one case
         name = sys.argv[sys.argv.index("--only") + 1]
         out = torch.load(path, weights_only=False)

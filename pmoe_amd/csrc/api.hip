@@ -13,7 +13,7 @@ static ConvArgs to_args(const pmoe_conv_desc* d) {
     a.ks = d->ks; a.stride = d->stride; a.pad = d->pad; a.dilate = d->dilate;
     a.act = d->act; a.res_mode = d->res ? d->res_mode : PMOE_RES_NONE;
     a.drop_p = d->drop_p; a.seed = d->seed;
-    a.oscale = d->out_scale; a.in_scale = d->in_scale; a.w_fp8 = d->w_fp8;
+    a.oscale = d->out_scale; a.in_scale = d->in_scale; a.w_fp8 = d->w_fp8; a.in_fp8 = d->in_fp8;
     a.bn = d->bn_coef; a.bn_ipe = d->bn_ipe > 0 ? d->bn_ipe : d->ipe;
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = 0;
     a.kh = a.kw = d->ks; a.use_tapmap = 0; a.tapmap[0] = a.tapmap[1] = a.tapmap[2] = a.tapmap[3] = 0;
@@ -25,6 +25,7 @@ static int check_conv(const pmoe_conv_desc* d) {
     if (!d || !d->in || !d->w || !d->out) return PMOE_ERR_ARG;
     if (d->n <= 0 || d->h <= 0 || d->w_ <= 0 || d->ho <= 0 || d->wo <= 0 || d->ipe <= 0) return PMOE_ERR_ARG;
     const int ve = d->dtype == PMOE_DT_BF16 ? 8 : 4;
+    if (d->in_fp8 && (!d->w_fp8 || d->dtype != PMOE_DT_BF16 || d->in_ld % 16 || d->in_coff % 16)) return PMOE_ERR_ARG;
     if (d->in_ld % ve || d->in_coff % ve || d->out_ld % ve || d->out_coff % ve) return PMOE_ERR_ARG;
     if (d->res && (d->res_ld % ve || d->res_coff % ve)) return PMOE_ERR_ARG;
     if (d->cout > d->coutp || d->in_coff + d->cin > d->in_ld || d->out_coff + d->cout > d->out_ld) return PMOE_ERR_ARG;

@@ -561,6 +561,178 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3s2_dma_kernel(const ConvArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 3, BASELINE config 5: the dense 3x3 stride-1 forward convolutions with >= 128 input channels on the BLOCK-SCALED fp8
+// matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 -- twice the bf16 rate per clock (MI355X_MICROARCH.md, matrix cores), the
+// one way fp8 operands pay on gfx950 (the non-scaled 32x32x16_fp8_fp8 form of round 2 runs at the bf16 rate).  Both operands are
+// e4m3 BYTES in HBM: the weights from pmoe_pack_conv_weights_fp8 (one power-of-two scale per output channel), the activations
+// written as e4m3(x * in_scale) by the producing BatchNorm pass (pmoe_bn_apply's fp8 side output) -- no conversion in this
+// kernel, and half the activation bytes through L2 and LDS.  Same schedule as conv3x3_dma_kernel with the SAME byte geometry: a
+// 128-byte LDS row now holds 128 channels, so a channel chunk is 128 channels and a tap is two 64-deep MFMA steps (4 + 4
+// instructions of 64 cycles per wave instead of 16 of 32 for 64 bf16 channels).  Lane half h feeds bytes [32 h, 32 h + 32) of a
+// 64-channel step to both operands (any split works as long as A and B agree: tools/probe_mfma_f8.hip); unit block scales
+// (E8M0 0x7f), the real scales are applied per output channel in the epilogue (DMA_OSCALE).
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+__global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_f8_kernel(const ConvArgs a, const int pbuf_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    STAMP_INIT
+    constexpr int CK8 = 128;                             // channels (= bytes) per chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nblk = a.CoutP / BN;
+    const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned mb = flat / nblk;
+    const int nb = (int)(flat % nblk);
+    int t = (int)mb;
+    const int px_t = t % a.tiles_x; t /= a.tiles_x;
+    const int py_t = t % a.tiles_y; t /= a.tiles_y;
+    const int ng = t % a.n_groups;
+    const int e = t / a.n_groups;
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int PW = TW + 2, PH = TH + 2;
+    const int NPIX = a.TN * PH * PW;
+    const int NPIECE = (NPIX + 7) >> 3;
+    const int n0 = e * a.ipe + ng * a.TN, n_end = (e + 1) * a.ipe;
+    const int oy0 = py_t * TH, ox0 = px_t * TW;
+    const int cout0 = nb * BN;
+
+    char* wring = smem + 2 * pbuf_bytes;
+
+    const unsigned char* inb = (const unsigned char*)a.in + (size_t)n0 * a.H * a.W * a.in_ld + a.in_coff;
+    long long in_bytes = (long long)(n_end - n0) * a.H * a.W * a.in_ld - a.in_coff;
+    if (in_bytes > 0x7ff00000ll) in_bytes = 0x7ff00000ll;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, (int)in_bytes, 0x00020000);
+    const unsigned char* wb = (const unsigned char*)a.w + ((size_t)e * a.CoutP + cout0) * 9 * a.Cin;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, BN * 9 * a.Cin, 0x00020000);
+
+    constexpr int OOB = 0x7ff80000;
+    int pvoff[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pp = ((wave + 8 * i) << 3) + (lane >> 3);
+        const int jj = lane & 7;
+        int px = pp % PW;
+        const int rowq = pp / PW;
+        const int prow = rowq % PH, pn = rowq / PH;
+        const int Y = oy0 - 1 + prow, X = ox0 - 1 + px;
+        const bool ok = pp < NPIX && n0 + pn < n_end && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+        pvoff[i] = ok ? (((pn * a.H + Y) * a.W + X) * a.in_ld) + ((jj ^ cswz(px)) << 4) : OOB;
+    }
+    int wvoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = ((wave + 8 * i) << 3) + (lane >> 3);
+        wvoff[i] = (row * 9 * a.Cin) + (((lane & 7) ^ cswz(row)) << 4);
+    }
+    const int my_pieces = (NPIECE - wave + 7) >> 3;
+
+    auto dma_patch = [&](int i, int buf, int c0) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(smem + buf * pbuf_bytes + ((wave + 8 * i) << 10)), 16,
+                                                 pvoff[i], c0, 0, 0);
+    };
+    auto dma_w = [&](int slot, int tap, int c0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(wring + slot * WSLOT + ((wave + 8 * i) << 10)), 16,
+                                                     wvoff[i], tap * a.Cin + c0, 0, 0);
+    };
+
+    int pbase[2], pcol[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int p = wm * 64 + mt * 32 + l31;
+        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+        pbase[mt] = ((pn * PH + my) * PW + mx) << LOG_RB;
+        pcol[mt] = mx;
+    }
+    int arow[2], asw[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int row = wn * 64 + nt * 32 + l31;
+        arow[nt] = row * RB;
+        asw[nt] = cswz(row);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    const int nchunks = a.Cin / CK8;
+    const int T = nchunks * 9;
+
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (i < my_pieces) dma_patch(i, 0, 0);
+    dma_w(0, 0, 0);
+    dma_w(1, 1, 0);
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK8;
+        const char* patch = smem + (ch & 1) * pbuf_bytes;
+        const bool more = ch + 1 < nchunks;
+        // (NOT unrolled over the taps: with 8-register operand tuples hipcc hoists the fragment reads of later taps and spills
+        //  them -- scratch traffic that would also break the vmcnt accounting)
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int tt = ch * 9 + tap;
+            const bool prev_piece = tap >= 2 && tap <= 7 && more && (tap - 2) < my_pieces;
+            if (tt + 1 >= T) VMCNT(0);
+            else if (prev_piece) VMCNT(3);
+            else VMCNT(2);
+            __builtin_amdgcn_s_barrier();
+            if (tap >= 1 && tap <= 6 && more && (tap - 1) < my_pieces) dma_patch(tap - 1, (ch + 1) & 1, c0 + CK8);
+            if (tt + 2 < T) {
+                int ntap = tap + 2, nc0 = c0;
+                if (ntap >= 9) { ntap -= 9; nc0 += CK8; }
+                dma_w((tt + 2) & (RING - 1), ntap, nc0);
+            }
+            const char* wt = wring + (tt & (RING - 1)) * WSLOT;
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RB;
+            int bsw[2];
+            const char* bp[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                bp[mt] = patch + pbase[mt] + tapoff;
+                bsw[mt] = cswz(pcol[mt] + (tap % 3));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                v8i af[2], bfr[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const v4i lo = *reinterpret_cast<const v4i*>(wt + arow[nt] + (((ks * 4 + 2 * h) ^ asw[nt]) << 4));
+                    const v4i hi = *reinterpret_cast<const v4i*>(wt + arow[nt] + (((ks * 4 + 2 * h + 1) ^ asw[nt]) << 4));
+                    af[nt] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const v4i lo = *reinterpret_cast<const v4i*>(bp[mt] + (((ks * 4 + 2 * h) ^ bsw[mt]) << 4));
+                    const v4i hi = *reinterpret_cast<const v4i*>(bp[mt] + (((ks * 4 + 2 * h + 1) ^ bsw[mt]) << 4));
+                    bfr[mt] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0, 0x7f, 0, 0x7f);
+            }
+        }
+    }
+
+#define DMA_OSCALE
+#include "conv_dma_epilogue.inc"
+#undef DMA_OSCALE
+}
+
 }  // namespace
 
 // Which launches take this kernel: bf16, dense 3x3 stride 1 pad 1 (forward, or the flipped-filter data gradient), whole
@@ -703,5 +875,47 @@ int conv_dma_s2cls_launch(ConvArgs a, hipStream_t st) {
     if (!conv_dma_s2cls_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
     HIP_RET((ensure_dyn_lds<conv3x3s2_dma_kernel<true>>(160 * 1024)));
     hipLaunchKernelGGL(conv3x3s2_dma_kernel<true>, dim3(mblocks * ((a.CoutP + BN - 1) / BN)), dim3(NTHR), smem, st, a, pbuf);
+    return (int)hipGetLastError();
+}
+
+
+// BASELINE config 5 on the block-scaled fp8 matrix instruction: e4m3 weights AND e4m3 activations in HBM (ConvArgs.in_fp8), dense
+// 3x3 stride 1, whole 128-channel chunks, >= 128 output-channel rows, maps of >= 4096 pixels per expert.  PMOE_CONV_F8DMA=0: the
+// activations go through the bf16 -> e4m3 converting loaders of round 2 instead.
+bool conv_dma_f8_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf) {
+    const char* ev = getenv("PMOE_CONV_F8DMA");
+    if ((ev && !atoi(ev)) || dtype != PMOE_DT_BF16 || !a.w_fp8 || !a.in_fp8 || !a.oscale) return false;
+    if (a.ks != 3 || a.kh != 3 || a.kw != 3 || a.use_tapmap || a.stride != 1 || a.pad != 1 || a.dilate || a.in_shared) return false;
+    if (a.out_step != 1 || a.Ho != a.H || a.Wo != a.W || a.res_mode != PMOE_RES_NONE) return false;
+    if (a.Cin % 128 || a.CoutP % BN || a.Cout % 8 || a.N % a.ipe || a.in_ld % 16 || a.in_coff % 16) return false;
+    if ((long long)a.ipe * a.Ho * a.Wo < 4096) return false;
+    auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    int lTW = p2(a.Wo); if (lTW > 5) lTW = 5;
+    if (lTW < 4) return false;
+    int lTH = p2(a.Ho); if (lTH > 8 - lTW) lTH = 8 - lTW;
+    const int TN = BM >> (lTW + lTH);
+    const int NPIX = TN * ((1 << lTH) + 2) * ((1 << lTW) + 2);
+    const int npiece = (NPIX + 7) / 8;
+    if (npiece > 48) return false;
+    const int pb = npiece * 1024;
+    const size_t need = (size_t)2 * pb + RING * WSLOT;
+    if (need > 160 * 1024) return false;
+    if ((long long)a.ipe * a.H * a.W * a.in_ld >= 0x7ff00000ll) return false;
+    a.lTW = lTW; a.lTH = lTH; a.TN = TN;
+    a.n_groups = (a.ipe + TN - 1) / TN;
+    a.tiles_y = (a.Ho + (1 << lTH) - 1) >> lTH;
+    a.tiles_x = (a.Wo + (1 << lTW) - 1) >> lTW;
+    *mblocks = (a.N / a.ipe) * a.n_groups * a.tiles_y * a.tiles_x;
+    *smem = need < (size_t)BM / 2 * BN * 4 ? (size_t)BM / 2 * BN * 4 : need;
+    *pbuf = pb;
+    return true;
+}
+
+int conv_dma_f8_launch(ConvArgs a, hipStream_t st) {
+    int mblocks = 0, pbuf = 0;
+    size_t smem = 0;
+    if (!conv_dma_f8_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return PMOE_ERR_UNSUPPORTED;
+    HIP_RET((ensure_dyn_lds<conv3x3_dma_f8_kernel>(160 * 1024)));
+    hipLaunchKernelGGL(conv3x3_dma_f8_kernel, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
     return (int)hipGetLastError();
 }

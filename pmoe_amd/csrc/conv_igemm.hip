@@ -583,8 +583,14 @@ static int launch_stride2_1x1_inplace(const ConvArgs& a, int dtype, hipStream_t 
 }
 
 int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
-    if (a.w_fp8) {                                   // e4m3 weights: forward convs on the halo-patch kernels only
+    if (a.w_fp8) {                                   // e4m3 weights: forward convs
         if (dtype != PMOE_DT_BF16 || a.dilate) return PMOE_ERR_ARG;
+        if (a.in_fp8) {                              // e4m3 activations too: the block-scaled MFMA kernel, or nothing
+            ConvArgs c = a;
+            int mb, pb;
+            size_t sm;
+            return conv_dma_f8_plan(c, dtype, &mb, &sm, &pb) ? conv_dma_f8_launch(a, st) : PMOE_ERR_UNSUPPORTED;
+        }
         return launch_dtype<bf16, fp8>(a, st, nullptr);
     }
     if (a.res_mode == PMOE_RES_DBN) {                // BatchNorm-backward reductions in the epilogue: the two LDS-DMA kernels only
@@ -629,6 +635,12 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
 int conv_igemm_plan(const ConvArgs& a, int dtype) {
     ConvArgs c = a;
     int extra = 0;
+    if (a.w_fp8 && a.in_fp8) {
+        ConvArgs d = a;
+        int mb, pb;
+        size_t sm;
+        return conv_dma_f8_plan(d, dtype, &mb, &sm, &pb) ? 8507 : PMOE_ERR_UNSUPPORTED;      // conv3x3_dma_f8_kernel
+    }
     if (a.w_fp8) {                                   // 8000 + the bf16 code of the same tile
         int mb = 0, cfg = 0;
         const int rc = dtype == PMOE_DT_BF16 && !a.dilate ? launch_dtype<bf16, fp8>(c, nullptr, &mb, &cfg) : PMOE_ERR_ARG;
@@ -680,6 +692,12 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
 }
 
 int conv_igemm_mblocks(const ConvArgs& a, int dtype) {
+    if (a.w_fp8 && a.in_fp8) {
+        ConvArgs d = a;
+        int mb, pb;
+        size_t sm;
+        return conv_dma_f8_plan(d, dtype, &mb, &sm, &pb) ? mb : PMOE_ERR_UNSUPPORTED;
+    }
     if (a.w_fp8) {
         int mb = 0;
         const int rc = dtype == PMOE_DT_BF16 ? launch_dtype<bf16, fp8>(a, nullptr, &mb) : PMOE_ERR_ARG;

@@ -198,7 +198,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                       T* __restrict__ y, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const float* __restrict__ mean,
-                                                      long long rpe, int C, int relu, int y_ld, int y_coff, int log_cv) {
+                                                      long long rpe, int C, int relu, int y_ld, int y_coff, int log_cv,
+                                                      unsigned char* __restrict__ y8, float in_scale) {
     constexpr int VE = 16 / (int)sizeof(T);
     const int CV = C / VE;                       // power of two <= 256*gridDim.x: a thread keeps ONE channel vector
     const int e = blockIdx.y;
@@ -229,7 +230,24 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
         }
         // dense output, or a channel window [y_coff, y_coff + C) of rows y_ld wide (skip-concatenation buffers)
         const size_t yoff = y_ld == C ? off : ((size_t)e * rpe + (size_t)(i >> log_cv)) * y_ld + y_coff + (size_t)cv * VE;
-        stg16(y + yoff, pack16<T>(xv));
+        const v4i pk = pack16<T>(xv);
+        stg16(y + yoff, pk);
+        if constexpr (sizeof(T) == 2) {
+            // BASELINE config 5: the same activation as e4m3(bf16(y) * in_scale) bytes, dense [rows][C], for the block-scaled fp8
+            // convolution that consumes it (the quantiser of conv_common.h: clamp to +-448, round to nearest even)
+            if (y8) {
+                float q[VE];
+                unpack16<T>(pk, q);                      // the STORED (bf16-rounded) value is what the policy quantises
+                int w0 = 0, w1 = 0;
+#pragma unroll
+                for (int k = 0; k < VE; ++k) q[k] = fminf(fmaxf(q[k] * in_scale, -PMOE_FP8_MAX), PMOE_FP8_MAX);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+                *reinterpret_cast<int2*>(y8 + ebase + (size_t)i * VE) = int2{w0, w1};
+            }
+        }
     }
 }
 
@@ -740,18 +758,19 @@ int pmoe_bn_bwd_finalize(const float* part, int32_t nparts, int64_t count, float
 
 int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, const float* mean,
                   int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t y_ld, int32_t y_coff, int32_t dtype,
-                  void* stream) {
+                  void* y_fp8, float in_scale, void* stream) {
     DISPATCH_DT(dtype, {
         constexpr int VE = 16 / (int)sizeof(T);
         if (C % VE || !pow2(C / VE) || C / VE > 256) return PMOE_ERR_ARG;   // kernels keep one channel vector per thread
         if (y_ld <= 0) { y_ld = C; y_coff = 0; }
+        if (y_fp8 && (dtype != PMOE_DT_BF16 || y_ld != C)) return PMOE_ERR_ARG;
         if (y_ld % VE || y_coff % VE || y_coff + C > y_ld) return PMOE_ERR_ARG;
         int log_cv = 0;
         while ((1 << log_cv) < C / VE) ++log_cv;
         const long long nvec = rows_per_expert * (C / VE);
         hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(nvec, 2048), E), dim3(256), 0, (hipStream_t)stream,
                            (const T*)x, (const T*)res, (T*)y, scale, shift, mean, (long long)rows_per_expert, C, relu,
-                           y_ld, y_coff, log_cv);
+                           y_ld, y_coff, log_cv, (unsigned char*)y_fp8, in_scale);
         return (int)hipGetLastError();
     });
 }

@@ -14,6 +14,7 @@ struct ConvArgs {
     const float* oscale;   // w_fp8: [E][CoutP] f32, accumulator scale = weight scale / in_scale
     float in_scale;        // w_fp8: activations are stored in LDS as e4m3(x * in_scale)
     int w_fp8;             // 1: `w` holds e4m3 bytes [E][CoutP][ks*ks][Cin]
+    int in_fp8;            // 1: `in` holds e4m3 bytes too (e4m3(x * in_scale), written by pmoe_bn_apply's fp8 side output)
     int N, H, W, Cin;
     int Ho, Wo, Cout, CoutP;
     int in_ld, in_coff, out_ld, out_coff, res_ld, res_coff;
@@ -62,7 +63,10 @@ int gemm_skinny_launch(const ConvArgs& a, hipStream_t st);
 // LDS-DMA 3x3 kernel for the >= 128-channel stride-1 layers (conv_dma.hip)
 bool conv_dma_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
 int conv_dma_launch(ConvArgs a, hipStream_t st);
-bool conv_dma_uses_mf16(const ConvArgs& a);      // which instantiation: <true> = v_mfma_f32_16x16x32_bf16
+bool conv_dma_uses_mf16(const ConvArgs& a);
+// ... on the block-scaled fp8 matrix instruction (e4m3 weights and activations)
+bool conv_dma_f8_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
+int conv_dma_f8_launch(ConvArgs a, hipStream_t st);      // which instantiation: <true> = v_mfma_f32_16x16x32_bf16
 // ... and its stride-2 forward sibling (parity planes gathered by the DMA's per-lane source addresses)
 bool conv_dma_s2_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
 int conv_dma_s2_launch(ConvArgs a, hipStream_t st);

@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("res_mode", C.c_int32),
         ("drop_p", C.c_float), ("seed", C.c_uint64), ("dtype", C.c_int32),
         ("w_fp8", C.c_int32), ("in_scale", C.c_float), ("out_scale", C.c_void_p),
-        ("bn_coef", C.c_void_p), ("bn_ipe", C.c_int32),
+        ("in_fp8", C.c_int32), ("bn_coef", C.c_void_p), ("bn_ipe", C.c_int32),
     ]
 
 
@@ -86,7 +86,7 @@ SIGNATURES = {
     "pmoe_colstats": [_P, _L, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "pmoe_reduce_partials": [_P, _P, _I, _I, _I, _I, _P],
     "pmoe_bn_finalize": [_P, _I, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P],
-    "pmoe_bn_apply": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_bn_apply": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _F, _P],
     "pmoe_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P],
     "pmoe_bn_bwd_finalize": [_P, _I, _L, _P, _P, _P, _P, _I, _I, _P],
     "pmoe_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],

@@ -35,13 +35,14 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
     nin, h, w_, ldx = _nhwc(x, "x")
     n, ho, wo, ldo = _nhwc(out, "out")
     w_fp8 = w_packed.dtype == torch.uint8          # e4m3 bytes (pack_conv_weights_fp8): BASELINE config 5
-    if x.dtype != out.dtype or (w_packed.dtype != x.dtype and not w_fp8):
+    in_fp8 = w_fp8 and x.dtype == torch.uint8      # ... and e4m3 activations (bn_apply's fp8 side output): the block-scaled MFMA kernel
+    if (x.dtype != out.dtype and not in_fp8) or (w_packed.dtype != out.dtype and not w_fp8):
         raise ValueError("conv2d: x, w and out must share one dtype")
-    if w_fp8 and (out_scale is None or x.dtype != torch.bfloat16):
+    if w_fp8 and (out_scale is None or out.dtype != torch.bfloat16):
         raise ValueError("conv2d: e4m3 weights need bf16 activations and the per-channel out_scale of the pack")
     d = ConvDesc()
     d.in_, d.w, d.out = ptr(x, "x"), ptr(w_packed, "w"), ptr(out, "out")
-    d.res = ptr(res, "res", x.dtype) if res is not None else None
+    d.res = ptr(res, "res", out.dtype) if res is not None else None
     d.bias = ptr(bias, "bias", torch.float32) if bias is not None else None
     d.stats = ptr(stats, "stats", torch.float32) if stats is not None else None
     d.n, d.h, d.w_, d.cin = n, h, w_, cin
@@ -52,9 +53,10 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
     d.ipe, d.in_shared = ipe, int(in_shared)
     d.ks, d.stride, d.pad, d.dilate = ks, stride, pad, int(dilate)
     d.act, d.res_mode = act, res_mode if res is not None else hip.RES_NONE
-    d.drop_p, d.seed, d.dtype = float(drop_p), int(seed), dt(x)
+    d.drop_p, d.seed, d.dtype = float(drop_p), int(seed), dt(out)
     if w_fp8:
         d.w_fp8, d.in_scale, d.out_scale = 1, float(in_scale), ptr(out_scale, "out_scale", torch.float32)
+        d.in_fp8 = int(in_fp8)
     if d.res_mode == hip.RES_DBN:
         # data gradient into relu(BatchNorm(z)): res = z, bn_coef = [4][n / bn_ipe][cout] (mean, invstd, gamma*invstd, beta);
         # the launch masks the gradient and leaves the BatchNorm backward's channel reductions in `stats`
@@ -85,11 +87,13 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
 
 
 def conv2d_stat_rows(n, h, w_, ho, wo, cin, cout, coutp, ipe, ks, stride, pad, dtype, w_fp8=False, in_ld=0, out_ld=0,
-                     in_shared=False):
+                     in_shared=False, in_fp8=False):
     """Partial-sum rows the launch will write.  in_ld / out_ld: row lengths (elements) of the tensors the launch will get --
     the kernel choice can depend on them (0 = dense)."""
     d = ConvDesc()
-    d.w_fp8, d.in_scale = int(w_fp8), 1.0
+    d.w_fp8, d.in_scale, d.in_fp8 = int(w_fp8), 1.0, int(in_fp8)
+    if in_fp8:
+        d.out_scale = C.c_void_p(1)          # (planning only: the fp8 kernel's plan asks for a scale pointer, nothing dereferences it)
     d.in_ld, d.out_ld, d.in_shared = in_ld, out_ld, int(in_shared)
     d.n, d.h, d.w_, d.cin, d.ho, d.wo, d.cout, d.coutp = n, h, w_, cin, ho, wo, cout, coutp
     d.ipe, d.ks, d.stride, d.pad, d.dtype = ipe, ks, stride, pad, hip._TORCH_DT[dtype]
@@ -224,11 +228,15 @@ def bn_finalize(part, nparts, count, gamma_tab, beta_tab, rmean_tab, rvar_tab, m
                                   ptr(shiftc, "shiftc", f32), stream_ptr()), "pmoe_bn_finalize")
 
 
-def bn_apply(x, res, y, scale, shift, mean, rpe, E, C_, relu, y_coff=0):
-    """y[..., y_coff:y_coff+C] = [relu]((x - mean)*scale + shift [+ res]); shift is the BN beta (bn_finalize's output)."""
+def bn_apply(x, res, y, scale, shift, mean, rpe, E, C_, relu, y_coff=0, y_fp8=None, in_scale=1.0):
+    """y[..., y_coff:y_coff+C] = [relu]((x - mean)*scale + shift [+ res]); shift is the BN beta (bn_finalize's output).
+    ``y_fp8`` (uint8, same shape as a dense y): also e4m3(bf16(y) * in_scale), the operand of the block-scaled fp8 conv."""
+    if y_fp8 is not None and (y_fp8.dtype != torch.uint8 or y_fp8.shape != y.shape):
+        raise ValueError("bn_apply: y_fp8 must be a uint8 tensor of y's shape")
     check(load().pmoe_bn_apply(ptr(x, "x"), ptr(res, "res", x.dtype), ptr(y, "y", x.dtype), ptr(scale), ptr(shift),
                                ptr(mean, "mean", torch.float32), rpe,
-                               E, C_, int(relu), y.shape[-1], y_coff, dt(x), stream_ptr()), "pmoe_bn_apply")
+                               E, C_, int(relu), y.shape[-1], y_coff, dt(x), ptr(y_fp8, "y_fp8", torch.uint8),
+                               float(in_scale), stream_ptr()), "pmoe_bn_apply")
 
 
 def bn_bwd_reduce(dy, y, x, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts, gmask=None):

@@ -48,8 +48,8 @@ def test_library_exports_every_symbol(lib):
 
 def test_struct_layouts_match_c(lib):
     # sizes computed by hand from include/pmoe_hip.h (LP64): 6 pointers + 22 int32 + float + pad + u64 + 2 int32 + float +
-    # pad + 2 pointers + int32 + pad
-    assert ctypes.sizeof(hip.ConvDesc) == 192 == lib.pmoe_abi_sizeof(0)
+    # pad + pointer + int32 + pad + pointer + int32 + pad
+    assert ctypes.sizeof(hip.ConvDesc) == 200 == lib.pmoe_abi_sizeof(0)
     assert ctypes.sizeof(hip.WgradDesc) == lib.pmoe_abi_sizeof(1)
     assert ctypes.sizeof(hip.WgradDesc) == 3 * 8 + 19 * 4 + 4 + 2 * 8 + 8 + 4 * 4  # int32 block padded to 8, part_ws + its size, grads + 3 int32 (+ pad)
     from pmoe_amd import optim

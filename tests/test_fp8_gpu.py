@@ -136,6 +136,57 @@ def test_conv_fp8_forward(case, plan):
     assert ((st[:, 0, :cout] - yo.sum(1)).abs().max() / yo.sum(1).abs().max()).item() <= 1e-3
 
 
+@pytest.mark.parametrize("case", [(1, 4, 128, 128, 64, 64), (2, 8, 256, 256, 32, 32), (2, 16, 512, 512, 16, 16), (1, 5, 128, 256, 40, 24)])
+def test_conv_fp8_scaled_mfma_kernel(case):
+    """conv3x3_dma_f8_kernel (round 3): e4m3 weights AND e4m3 activations in HBM on v_mfma_scale_f32_32x32x64_f8f6f4.  The
+    products of two e4m3 factors are exact in f32, so against F.conv2d on the policy's dequantised operands only the summation
+    order and the bf16 output rounding differ; the fused BatchNorm partial sums are the column sums of the stored output."""
+    E, ipe, cin, cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    N = E * ipe
+    x = (torch.relu(rnd((N, cin, H, W), g, BF)) * 1.5).to(BF).float()
+    ws = [rnd((cout, cin, 3, 3), g, torch.float32, (2.0 / (cin * 9)) ** 0.5) for _ in range(E)]
+    ref = torch.cat([F.conv2d(P.qdq_act(x[e * ipe:(e + 1) * ipe]), P.qdq_weight(ws[e]), padding=1) for e in range(E)])
+    f8, _, _, oscale, _ = _pack8(ws, 3)
+    x8 = P.e4m3_bytes(x.permute(0, 2, 3, 1).contiguous() * P.IN_SCALE).to(DEV)          # [N,H,W,cin] e4m3 bytes
+    out = torch.full((N, H, W, r16(cout)), 7.0, dtype=BF, device=DEV)
+    kw = dict(cin=cin, cout=cout, coutp=r64(cout), ipe=ipe, ks=3, stride=1, pad=1, out_scale=oscale, in_scale=P.IN_SCALE)
+    assert ops.conv2d(x8, f8, out, plan_only=True, **kw) == 8507
+    rows = ops.conv2d_stat_rows(N, H, W, H, W, cin, cout, r64(cout), ipe, 3, 1, 1, BF, w_fp8=True, in_fp8=True, in_ld=cin)
+    stats = torch.zeros(rows, 2, r64(cout), device=DEV)
+    ops.conv2d(x8, f8, out, stats=stats, **kw)
+    y = from_nhwc(out, cout)
+    err = (y - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3 * ref.abs().max()).all(), (err.max().item(), ref.abs().max().item())
+    st = stats.view(E, rows // E, 2, r64(cout)).sum(1).cpu()
+    yo = out.float().cpu()[..., :cout].reshape(E, -1, cout)
+    assert ((st[:, 0, :cout] - yo.sum(1)).abs().max() / yo.sum(1).abs().max()).item() <= 1e-3
+    assert ((st[:, 1, :cout] - (yo * yo).sum(1)).abs().max() / (yo * yo).sum(1).abs().max()).item() <= 1e-3
+
+
+def test_bn_apply_fp8_side_output_is_the_policy_quantiser():
+    """pmoe_bn_apply's e4m3 side output (round 3: the activation is quantised once, by the pass that produces it) equals
+    e4m3(bf16(y) * IN_SCALE) of the policy bit for bit -- ties, subnormals and saturation included -- with and without a
+    residual, and the bf16 output is unchanged by asking for it."""
+    g = torch.Generator().manual_seed(5)
+    E, ipe, H, W, C_ = 2, 3, 9, 13, 128
+    x = rnd((E * ipe, H, W, C_), g, BF, 6.0)
+    x.view(-1)[:8] = torch.tensor([448.0, -448.0, 1e4, -1e4, 2 ** -9, 3 * 2 ** -10, 0.0, 27.9])      # saturation / subnormal probes
+    res = rnd((E * ipe, H, W, C_), g, BF)
+    scale = (torch.rand(E, C_, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(E, C_, generator=g) * 0.2).to(DEV)
+    mean = (torch.randn(E, C_, generator=g) * 0.1).to(DEV)
+    xd, rd = x.to(BF).to(DEV), res.to(BF).to(DEV)
+    for r_, relu in ((None, True), (rd, True), (None, False)):
+        y0, y1 = torch.empty_like(xd), torch.empty_like(xd)
+        y8 = torch.full(xd.shape, 0xAB, dtype=torch.uint8, device=DEV)
+        ops.bn_apply(xd, r_, y0, scale, shift, mean, ipe * H * W, E, C_, relu)
+        ops.bn_apply(xd, r_, y1, scale, shift, mean, ipe * H * W, E, C_, relu, y_fp8=y8, in_scale=P.IN_SCALE)
+        assert torch.equal(y0, y1)
+        want = P.e4m3_bytes(y1.float().cpu() * P.IN_SCALE)
+        assert torch.equal(y8.cpu(), want), int((y8.cpu() != want).sum())
+
+
 def _run_model(name, fp8):
     from tests.parity_util import GOLDEN, build_pair
     g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
@@ -178,7 +229,7 @@ def test_model_fp8_eval_agent_shape_layer_by_layer():
     ASSERTED wrong here: no conv input of the HIP path or of the emulated policy exceeds the e4m3 range at the policy's
     scale (the largest is ~24).  What the HIP kernels must do is implement the policy, and that is checked where the
     statistic is meaningful -- per BatchNorm output (1e5..1e6 elements each), the HIP path's rel-L2 distance to the float64
-    oracle is the emulated policy's own distance (measured ratio 0.98-1.04 on all 17 layers; bound 1.15).  The four
+    oracle is the emulated policy's own distance (bound 1.15 on all 17 layers).  The four
     `speeds` values the old check took a maximum over inherit ~10 % of feature noise from either side; two equally faithful
     implementations of the policy land 0.09 and 0.24 from the float64 value there (and 0.17 from each other), so the
     outputs are bounded by 3 x the emulation's own error, no tighter."""
@@ -191,10 +242,16 @@ def test_model_fp8_eval_agent_shape_layer_by_layer():
     print("fp8 eval g2:", {k: "HIP %.2e | emulation %.2e | between %.2e" % v for k, v in outs.items()})
     for k, (e_hip, e_emul, _) in outs.items():
         assert e_hip <= 3.0 * e_emul, (k, e_hip, e_emul)
-    # control: the same table without the fp8 policy (bf16 storage only) is ten times closer, layer by layer
+    # control: the same table without the fp8 policy (bf16 storage only): equal to it up to the first quantised layer (the
+    # policy starts at layer2.0.conv2, so layer2.0.bn2 is the first output it touches), several times closer behind it
     rows16, _ = layerwise("g2_moe_e4_b1_224_eval", False)
-    for (name, d8, *_), (_, d16, e16, *_) in zip(rows[1:], rows16[1:]):
-        assert d16 <= 1.15 * e16 + 1e-3 and d16 < 0.5 * d8, (name, d16, e16, d8)
+    first = [r[0] for r in rows].index("layer2.0.bn2")
+    for i, ((name, d8, *_), (_, d16, e16, *_)) in enumerate(zip(rows, rows16)):
+        assert d16 <= 1.15 * e16 + 1e-3, (name, d16, e16)
+        if i < first:
+            assert abs(d8 - d16) <= 1e-6 + 1e-3 * d16, (name, d8, d16)
+        elif i > first:
+            assert d16 < 0.5 * d8, (name, d16, d8)
 
 
 def test_model_fp8_train_step():
