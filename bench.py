@@ -40,8 +40,8 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--experts", type=int, default=4)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
-                    help="fp8 = BASELINE config 5: e4m3 weights + activations on the fp8 matrix cores for the ResNet layer1-4 "
-                         "forward convolutions, bf16 elsewhere (quote it with --batch 128)")
+                    help="fp8 = BASELINE config 5: e4m3 weights + activations on the block-scaled fp8 matrix instruction for the "
+                         "dense 3x3 stride-1 forward convolutions of ResNet layer2-4, bf16 elsewhere (quote it with --batch 128)")
     ap.add_argument("--dropout", type=float, default=0.3, help="stage_2*.yaml value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage1", action="store_true", help="skip the stage-1 PU-Net training step (section 8f N4)")
@@ -173,8 +173,9 @@ def sub_configs(dev, args):
 
     out["C3_shard_e8_b64"] = dict(moe_case(8, 64, False), what="8-expert MoE, batch 64 (one GPU's shard of the B=512 DP config), bf16")
     gc.collect(); torch.cuda.empty_cache()
-    out["C5_fp8_b128"] = dict(moe_case(args.experts, 128, True), what="4-expert MoE, batch 128, e4m3 weights + activations on "
-                              "the fp8 matrix cores for the layer1-4 forward convolutions (bf16 stem / backward)")
+    out["C5_fp8_b128"] = dict(moe_case(args.experts, 128, True), what="4-expert MoE, batch 128, e4m3 weights + e4m3 activations "
+                              "on the block-scaled fp8 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4) for the dense 3x3 "
+                              "stride-1 forward convolutions of layer2-4 (46 % of the forward MACs); bf16 elsewhere and backward")
     gc.collect(); torch.cuda.empty_cache()
     out["C2_bf16_b128"] = dict(moe_case(args.experts, 128, False), what="same shape as C5 in plain bf16 (the A/B partner)")
     gc.collect(); torch.cuda.empty_cache()
@@ -355,7 +356,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.experts}-expert MoE (PMoE experts), {args.size}x{args.size}x3 x4 frames, "
                                f"batch {args.batch}/GPU, fwd+moe_loss+bwd, dropout {args.dropout}"
-                               + (", fp8 policy (e4m3 weights + activations, layer1-4 forward convolutions)" if args.dtype == "fp8" else ""),
+                               + (", fp8 policy (e4m3 weights + activations, layer2-4 3x3 stride-1 forward convolutions)" if args.dtype == "fp8" else ""),
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         "loss": round(float(loss.item()), 5),
     }
@@ -432,6 +433,8 @@ def main():
             if code == 9207:                      # the four parity classes of a stride-2 3x3 data gradient on the LDS-DMA kernel
                 return ("conv3x3s2_dma_kernel<true> (4 parity-class launches per stride-2 dgrad)",
                         "void (anonymous namespace)::conv3x3s2_dma_kernel<true>", 4)
+            if code == 8507:                      # block-scaled fp8 MFMA kernel (conv_dma.hip)
+                return "conv3x3_dma_f8_kernel", "void (anonymous namespace)::conv3x3_dma_f8_kernel", 1
             if code >= 8000:                      # e4m3 operands (BASELINE config 5): same tiles, TL = fp8
                 r, m, n = symbol(code - 8000)
                 return r.replace("<bf16,", "<bf16+e4m3,"), m.replace(f"E{tname}Ev8ConvArgs", "E3fp8Ev8ConvArgs"), n
