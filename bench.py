@@ -454,6 +454,9 @@ def main():
                 return f"conv1x1_direct_kernel<{code - 1400}>", f"void (anonymous namespace)::conv1x1_direct_kernel<{code - 1400}>", 1
             if code == 1316:                      # 16-channel stem convolution, direct form (conv_c16.hip)
                 return "conv3x3_c16_kernel", "void (anonymous namespace)::conv3x3_c16_kernel", 1
+            if 1200 <= code < 1300:               # ... with the read-out of tile t under the MFMAs of tile t+1: <bias, mode>
+                tf, mode = ("true" if (code - 1207) // 10 % 2 else "false"), (code - 1207) // 20
+                return f"conv3x3_respipe_kernel<{tf}, {mode}>", f"void conv3x3_respipe_kernel<{tf}, {mode}>", 1
             if code >= 1100:                      # filter bank resident in LDS, halo patches by LDS-DMA (conv_res.hip); <true>: bias row
                 tf = "true" if code == 1117 else "false"
                 return f"conv3x3_resdma_kernel<{tf}>", f"void conv3x3_resdma_kernel<{tf}>", 1

@@ -107,7 +107,9 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
  *   1000 + LOG_RB            conv3x3_res_kernel<LOG_RB>            (resident-filter kernel, conv_res.hip)
  *   1400 + MT                conv1x1_direct_kernel<MT>             (1x1, stride 1 | 2, >= 8192 pixels per expert, 64..512 input channels, conv_c1x1.hip)
  *   1316                     conv3x3_c16_kernel                    (16 input channels: direct MFMA form, no LDS staging, conv_c16.hip)
- *   1107 | 1117              conv3x3_resdma_kernel<false | true>   (resident filter bank, halo patches by LDS-DMA, conv_res.hip; <true>: per-expert bias row)
+ *   1207 + 10 b + 20 m       conv3x3_respipe_kernel<b, m>          (resident filter bank, halo patches by LDS-DMA, read-out of tile t in registers under the MFMAs
+ *                                                                   of tile t+1, conv_res.hip; b: per-expert bias row, m: 0 plain | 1 PMOE_RES_ADD | 2 PMOE_RES_DBN)
+ *   1107 | 1117              conv3x3_resdma_kernel<false | true>   (its LDS-staged predecessor, PMOE_RES_PIPE=0)
  *   2000 + LOG_RB            conv_igemm_lite_kernel<T, LOG_RB>     (8-wave 256 x 128 tile, two workgroups per CU)
  *   5007 | 5017              conv3x3_dma_kernel<false | true>      (LDS-DMA staged 3x3 stride-1 kernel, >= 128 channels, conv_dma.hip; <true>: 16x16x32 MFMA shape, >= 256 input channels)
  *   5207                     conv3x3s2_dma_kernel                  (its stride-2 forward sibling: parity planes gathered by the DMA, conv_dma.hip)

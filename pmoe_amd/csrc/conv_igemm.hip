@@ -527,6 +527,7 @@ struct ResPlan {
     size_t smem;
 };
 bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan);
+bool conv_res_pipe_ok(const ConvArgs& a);
 bool conv_res_dma_ok(const ConvArgs& a, const ResPlan& p, int* pbuf, int* magic_pw, int* magic_ph, size_t* smem);
 bool conv_c16_plan(const ConvArgs& a, int dtype, int* wgs_per_expert, int* tiles_x, int* tiles_per_expert);
 int conv_c16_launch(const ConvArgs& a, hipStream_t st);
@@ -628,8 +629,8 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
     return PMOE_ERR_ARG;
 }
 
-// which kernel a descriptor runs on (no launch): 3000 = gemm_skinny_kernel; 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; 1107 =
-// conv3x3_resdma_kernel; 1316 = conv3x3_c16_kernel; 1400 + MT = conv1x1_direct_kernel<MT>; 5007 = conv3x3_dma_kernel; 2000 + LOG_RB =
+// which kernel a descriptor runs on (no launch): 3000 = gemm_skinny_kernel; 1000 + LOG_RB = conv3x3_res_kernel<LOG_RB>; 1207 + 10 bias + 20 mode =
+// conv3x3_respipe_kernel<bias, mode> (1107 | 1117 = conv3x3_resdma_kernel with PMOE_RES_PIPE=0); 1316 = conv3x3_c16_kernel; 1400 + MT = conv1x1_direct_kernel<MT>; 5007 = conv3x3_dma_kernel; 2000 + LOG_RB =
 // conv_igemm_lite_kernel<T, LOG_RB>; LOG_RB*100 + WM*10 + WN = conv_igemm_kernel<T, LOG_RB, WM, WN>; + 4000 = the four
 // parity-class launches of a stride-2 data gradient
 int conv_igemm_plan(const ConvArgs& a, int dtype) {
@@ -650,7 +651,8 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         ResPlan plan;
         int pb, mpw, mph, mb;
         size_t sm;
-        if (conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm)) return 1000 + plan.log_rb + 100 + (a.bias ? 10 : 0);
+        if (conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm))
+            return 1000 + plan.log_rb + (conv_res_pipe_ok(a) ? 240 : 100) + (a.bias ? 10 : 0);
         if (!gemm_skinny_ok(a, dtype) && conv_dma_plan(c, dtype, &mb, &sm, &pb)) return conv_dma_uses_mf16(a) ? 5017 : 5007;
         return PMOE_ERR_UNSUPPORTED;
     }
@@ -676,7 +678,8 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         if (conv_res_plan(a, dtype, &plan)) {
             int pb, mpw, mph;
             size_t sm;
-            return 1000 + plan.log_rb + (conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) ? 100 + (a.bias ? 10 : 0) : 0);
+            const int mode = a.res_mode == PMOE_RES_ADD ? 1 : 0;      // (PMOE_RES_DBN returned above)
+            return 1000 + plan.log_rb + (conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) ? (conv_res_pipe_ok(a) ? 200 + 20 * mode : 100) + (a.bias ? 10 : 0) : 0);
         }
         ConvArgs d = a;
         int mbd, pb;

@@ -297,6 +297,16 @@ __global__ void __launch_bounds__(512) conv3x3_res_kernel(const ConvArgs a, cons
 // accumulator), waits for the prefetched patch BEFORE issuing its stores (one in-order vmcnt counter), and carries the
 // BatchNorm partial sums in registers across tiles.
 // Wave tile = 64 pixels x 32 output channels (4 x 2 waves): 3 ds_read_b128 per 2 MFMAs, ~75 % LDS-array load.
+// -DPMOE_STAMP (tools/stamp_conv.py only, never the product build): s_memtime laps of the five phases of a tile + the workgroup's
+// wall time (s_memrealtime, 100 MHz) land in a.stats instead of the BatchNorm partial sums.
+#ifdef PMOE_STAMP
+#define RSTAMP_INIT unsigned long long st_prev = __builtin_amdgcn_s_memtime(); const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime(); unsigned st_acc[5] = {0, 0, 0, 0, 0};
+#define RLAP(i) { const unsigned long long st_t = __builtin_amdgcn_s_memtime(); st_acc[i] += (unsigned)(st_t - st_prev); st_prev = st_t; }
+#else
+#define RSTAMP_INIT
+#define RLAP(i)
+#endif
+
 template <bool BIAS>
 __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a, const int tiles_per_expert,
                                                                 const int wgs_per_expert, const int pbuf_bytes,
@@ -414,6 +424,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
         }
     }
 
+    RSTAMP_INIT
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntile) issue_patch(t + 1, buf ^ 1);  // its buffer was released by the barrier that ended tile t-1
@@ -452,6 +463,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[mt][k] = 0.f;
         }
+        RLAP(0)                                          // patch requests, residual prefetch, accumulator init
         auto read_step = [&](int st, v4i& af, v4i* bfr) {     // fragments of step st = tap * 4 + ks
             const int tap = st >> 2, ks = st & 3;
             const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RBK;
@@ -475,8 +487,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
         }
         // ---- epilogue: bf16 rows [256 px][128 B] (16-byte chunks XOR-swizzled by pixel) in this tile's patch buffer
         char* stage = pbuf + buf * pbuf_bytes;
+        RLAP(1)                                          // 36 steps of fragment reads + MFMAs
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // every wave is done reading the patch
+        RLAP(2)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int p = wm * 64 + mt * 32 + l31;
@@ -490,6 +504,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // + the next tile's patch, AHEAD of this tile's stores
         __builtin_amdgcn_s_barrier();
+        RLAP(3)                                          // staging writes, wait for the prefetched patch / earlier stores, barrier
         int n0, oy0, ox0;
         tile_geo(t, n0, oy0, ox0);
 #pragma unroll
@@ -536,7 +551,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // staging read out: the buffer may receive the patch of tile t+2
+        RLAP(4)                                          // read-out (+ residual / BatchNorm reductions), stores, barrier
     }
+#ifdef PMOE_STAMP
+    if (a.stats && lane == 0) {
+        float* o = a.stats + (((size_t)e * wgs_per_expert + wg) * 8 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = (float)st_acc[i];
+        o[5] = (float)(unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+        o[6] = (float)ntile;
+    }
+    return;
+#endif
 
     if (a.stats) {
         __syncthreads();
@@ -562,6 +587,341 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) s += red[(w * 2 + which) * 64 + c];
+            a.stats[(((size_t)e * wgs_per_expert + wg) * 2 + which) * a.CoutP + c] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round-3 variant of conv3x3_resdma_kernel: the same resident filter bank, LDS-DMA halo patches and 36-step MFMA loop, but the
+// epilogue of tile t no longer stops the matrix pipe.  Cycle stamps of the kernel above (tools/stamp_conv.py, profiles/
+// r03_resdma_stamps.log): 9450 cycles per tile of which 4460 in the MFMA loop -- 1690 in the next patch's address arithmetic,
+// 860 + 770 + 1670 in the three barriers, the LDS staging and the read-out, all of it VALU / LDS work during which no wave of
+// the workgroup issues an MFMA.  Here
+//   * the accumulators of tile t are rounded to bf16 IN REGISTERS, two v_permlane32_swap per 8-byte piece turn the MFMA layout
+//     (4 consecutive channels per lane half) into whole 16-byte channel vectors, and the stores + BatchNorm sums / residual add /
+//     masked BatchNorm-backward reductions of tile t are issued BETWEEN THE MFMAs OF TILE t+1 (straight-line code: invalid
+//     pixels park their buffer offset out of range instead of branching, so the scheduler may interleave freely);
+//   * no LDS staging, ONE barrier per tile (patch t is free for the request of tile t+2);
+//   * the per-lane geometry of the 6 patch pieces and 2 output pixels is tile-invariant and computed once; the tile walk is
+//     incremental (no divisions in the loop).
+// MODE: 0 = plain (+ BatchNorm partial sums of the stored values when a.stats), 1 = PMOE_RES_ADD, 2 = PMOE_RES_DBN.
+template <bool BIAS, int MODE>
+__global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs a, const int tiles_per_expert,
+                                                                 const int wgs_per_expert, const int pbuf_bytes,
+                                                                 const int magic_pw, const int magic_ph) {
+    constexpr int RB = 128, LOG_RBK = 7;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int e = blockIdx.y, wg = blockIdx.x;
+    const int t0 = (int)((long long)wg * tiles_per_expert / wgs_per_expert);
+    const int t1 = (int)((long long)(wg + 1) * tiles_per_expert / wgs_per_expert);
+    const int ntile = t1 - t0;
+
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int PW = TW + 2, PH = TH + 2;
+    const int NPIX = a.TN * PH * PW;
+    const int NPIECE = (NPIX + 7) >> 3;
+    const int my_pieces = (NPIECE - wave + 7) >> 3;
+
+    char* Wl = smem;                                     // [9][64][128 B], chunks swizzled by row
+    char* pbuf = smem + 9 * 64 * RB;                     // 2 patch buffers
+    float* lbias = reinterpret_cast<float*>(pbuf + 2 * pbuf_bytes);
+    if (BIAS && tid < 64) lbias[tid] = a.bias[(size_t)e * a.CoutP + tid];
+    float* lbn = lbias + 64;                             // MODE 2: [mean | invstd | gamma*invstd | beta][64]
+    if (MODE == 2 && tid < 256) {
+        const int nset = a.N / a.bn_ipe;
+        lbn[tid] = (tid & 63) < a.Cout ? a.bn[((size_t)(tid >> 6) * nset + (e * a.ipe) / a.bn_ipe) * a.Cout + (tid & 63)] : 0.f;
+    }
+
+    constexpr int OOB = 0x7ff80000;
+    const bf16* inb = (const bf16*)a.in + (size_t)e * a.ipe * a.H * a.W * a.in_ld + a.in_coff;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)inb, (short)0, (int)(((long long)a.ipe * a.H * a.W * a.in_ld - a.in_coff) * 2), 0x00020000);
+    const bf16* wsrc = (const bf16*)a.w + (size_t)e * a.CoutP * 9 * a.Cin;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, (short)0, 64 * 9 * 64 * 2, 0x00020000);
+    bf16* outb = (bf16*)a.out + (size_t)e * a.ipe * a.Ho * a.Wo * a.out_ld + a.out_coff;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)outb, (short)0, (int)(((long long)a.ipe * a.Ho * a.Wo * a.out_ld - a.out_coff) * 2), 0x00020000);
+    const bf16* resb = MODE ? (const bf16*)a.res + (size_t)e * a.ipe * a.Ho * a.Wo * a.res_ld + a.res_coff : (const bf16*)a.in;
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)resb, (short)0, MODE ? (int)(((long long)a.ipe * a.Ho * a.Wo * a.res_ld - a.res_coff) * 2) : 0, 0x00020000);
+
+    // resident filter bank: 72 pieces of 8 rows (piece = tap * 8 + row block), 9 per wave
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int piece = wave + 8 * i;
+        const int tap = piece >> 3, row = ((piece & 7) << 3) + (lane >> 3);
+        const int voff = ((row * 9 + tap) * 64 * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(Wl + (piece << 10)), 16, voff, 0, 0, 0);
+    }
+
+    // ---- tile-invariant geometry of this lane's patch pieces: byte offset relative to the patch origin (+ source swizzle) and
+    // the packed (image, row, column) inside the patch
+    int prel[6], pgeo[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pp = ((wave + 8 * i) << 3) + (lane >> 3);
+        const int rowq = (pp * magic_pw) >> 16, px = pp - rowq * PW;
+        const int pn = (rowq * magic_ph) >> 16, prow = rowq - pn * PH;
+        prel[i] = ((((pn * a.H + prow) * a.W + px) * a.in_ld) << 1) + (((lane & 7) ^ ((px >> 1) & 7)) << 4);
+        pgeo[i] = pp < NPIX ? (pn << 20) | (prow << 10) | px : (0x7ff << 20);        // beyond the patch: never in range
+    }
+    // the tile walk: (column tile, row tile, image group) of the current tile, advanced by one per iteration
+    struct Walk { int px, py, q; };
+    Walk cur;
+    {
+        int qq = t0;
+        cur.px = qq % a.tiles_x; qq /= a.tiles_x;
+        cur.py = qq % a.tiles_y; cur.q = qq / a.tiles_y;
+    }
+    auto advance = [&](Walk w) {
+        if (++w.px == a.tiles_x) { w.px = 0; if (++w.py == a.tiles_y) { w.py = 0; ++w.q; } }
+        return w;
+    };
+    auto issue_patch = [&](const Walk& w, int buf) {
+        const int n0 = w.q * a.TN, Y0 = w.py * TH - 1, X0 = w.px * TW - 1;
+        const int tbase = (((n0 * a.H + Y0) * a.W + X0) * a.in_ld) << 1;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i < my_pieces) {
+                const int n = n0 + (pgeo[i] >> 20), Y = Y0 + ((pgeo[i] >> 10) & 0x3ff), X = X0 + (pgeo[i] & 0x3ff);
+                const bool ok = n < a.ipe && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(pbuf + buf * pbuf_bytes + ((wave + 8 * i) << 10)), 16,
+                                                         ok ? tbase + prel[i] : OOB, 0, 0, 0);
+            }
+        }
+    };
+
+    // fragment addressing: B = pixels wm*64 + mt*32 + l31 (columns of D), A = couts wn*32 + l31 (rows of D)
+    int pbase[2], pcol[2];
+    // read-out: this lane owns, for its two pixels (mt), the channel vectors [c0 + 16 k, + 8), k = 0, 1
+    unsigned ovo[2], rvo[2];
+    int ogeo[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int p = wm * 64 + mt * 32 + l31;
+        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+        pbase[mt] = ((pn * PH + my) * PW + mx) << LOG_RBK;
+        pcol[mt] = mx;
+        const int orel = (pn * a.Ho + my) * a.Wo + mx;
+        ogeo[mt] = (pn << 20) | (my << 10) | mx;
+        ovo[mt] = (unsigned)(orel * a.out_ld + wn * 32 + 8 * hh) * 2u;
+        rvo[mt] = (unsigned)(orel * a.res_ld + wn * 32 + 8 * hh) * 2u;
+    }
+    const int c0 = wn * 32 + 8 * hh;
+    const bool cval[2] = {c0 < a.Cout, c0 + 16 < a.Cout};
+    int aoff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int row = wn * 32 + l31;
+        aoff[ks] = row * RB + (((ks * 2 + hh) ^ ((row >> 1) & 7)) << 4);
+    }
+
+    f32x2 s1[2][4], s2[2][4];                            // sums of this lane's 2 x 8 channels, all of its pixels and tiles
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s1[k][q] = s2[k][q] = f32x2{0.f, 0.f};
+
+    if (ntile > 0) issue_patch(cur, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // filter bank + first patch (DMA), bias / coefficient rows
+    __builtin_amdgcn_s_barrier();
+
+    // the tile whose read-out is pending: packed results, its residual / z vectors, validity and store offset
+    v4u prev[2][2], rprev[2][2];
+    bool pval[2] = {false, false};
+    unsigned psoff = 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) prev[mt][k] = rprev[mt][k] = v4u{0u, 0u, 0u, 0u};
+
+    auto unpack2 = [](unsigned w) { return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)}; };
+    auto pack2 = [](f32x2 v) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, bf16x2{(bf16)v[0], (bf16)v[1]});
+    };
+    // read-out of channel vector k of the pending tile (both pixels): straight-line, stores of invalid pixels go out of range
+    auto readout = [&](const int k) {
+        f32x2 mu[4], is[4], sc[4], sh[4];
+        if (MODE == 2) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(lbn + c0 + 16 * k + 4 * q);
+                const f32x4 i4 = *reinterpret_cast<const f32x4*>(lbn + 64 + c0 + 16 * k + 4 * q);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbn + 128 + c0 + 16 * k + 4 * q);
+                const f32x4 h4 = *reinterpret_cast<const f32x4*>(lbn + 192 + c0 + 16 * k + 4 * q);
+                mu[2 * q] = f32x2{m[0], m[1]}; mu[2 * q + 1] = f32x2{m[2], m[3]};
+                is[2 * q] = f32x2{i4[0], i4[1]}; is[2 * q + 1] = f32x2{i4[2], i4[3]};
+                sc[2 * q] = f32x2{s4[0], s4[1]}; sc[2 * q + 1] = f32x2{s4[2], s4[3]};
+                sh[2 * q] = f32x2{h4[0], h4[1]}; sh[2 * q + 1] = f32x2{h4[2], h4[3]};
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const bool ok = pval[mt] && cval[k];
+            v4u pk;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned w = ok ? prev[mt][k][q] : 0u;       // pixels outside the image contribute nothing to the sums
+                f32x2 v = unpack2(w);
+                if (MODE == 2) {
+                    const f32x2 d = unpack2(rprev[mt][k][q]) - mu[q];
+                    const f32x2 y = __builtin_elementwise_fma(d, sc[q], sh[q]);
+                    // the value the apply pass will read is the ROUNDED masked gradient: the sums use it too
+                    v = f32x2{y[0] > 0.f ? v[0] : 0.f, y[1] > 0.f ? v[1] : 0.f};
+                    s1[k][q] += v;
+                    s2[k][q] = __builtin_elementwise_fma(v, d * is[q], s2[k][q]);
+                    pk[q] = pack2(v);
+                } else if (MODE == 1) {
+                    v += unpack2(rprev[mt][k][q]);
+                    pk[q] = pack2(v);
+                    const f32x2 rr = unpack2(pk[q]);
+                    s1[k][q] += rr;
+                    s2[k][q] = __builtin_elementwise_fma(rr, rr, s2[k][q]);
+                } else {
+                    pk[q] = w;
+                    s1[k][q] += v;
+                    s2[k][q] = __builtin_elementwise_fma(v, v, s2[k][q]);
+                }
+            }
+            // (tile base in the VECTOR offset, not in soffset: the registers of `pk` are rewritten by the next pixel's arithmetic
+            //  one instruction later, and hipcc pads the ISA's ">64-bit store data -> VALU write" hazard only for stores WITHOUT an
+            //  SGPR offset -- with one, lanes 12-15 / 44-47 of the first data dword were stored after they had been overwritten)
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, (int)(ok ? ovo[mt] + psoff + 32u * k : (unsigned)OOB), 0, 0);
+        }
+    };
+
+    RSTAMP_INIT
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        const Walk nxt = advance(cur);
+        if (t + 1 < ntile) issue_patch(nxt, buf ^ 1);    // its buffer was released by the barrier that ended tile t-1
+        // this tile's output pixels
+        const int n0 = cur.q * a.TN, oy0 = cur.py * TH, ox0 = cur.px * TW;
+        const unsigned osoff = (unsigned)(((n0 * a.Ho + oy0) * a.Wo + ox0) * a.out_ld) * 2u;
+        bool val[2];
+        v4u rz[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            val[mt] = n0 + (ogeo[mt] >> 20) < a.ipe && oy0 + ((ogeo[mt] >> 10) & 0x3ff) < a.Ho && ox0 + (ogeo[mt] & 0x3ff) < a.Wo;
+            if (MODE) {
+                // residual (a data gradient accumulating into the gradient another consumer left) / z of the BatchNorm whose
+                // backward reductions this launch carries: requested now, consumed one tile later
+                const unsigned rsoff = (unsigned)(((n0 * a.Ho + oy0) * a.Wo + ox0) * a.res_ld) * 2u;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    rz[mt][k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(val[mt] && cval[k] ? rvo[mt] : (unsigned)OOB),
+                                                                      (int)(rsoff + 32u * k), 0);
+            }
+        }
+        const char* patch = pbuf + buf * pbuf_bytes;
+        f32x16 acc[2];
+        if (BIAS) {
+            // accumulators start from the channel bias (acc[mt][4g+i] is cout wn*32 + 8g + 4hh + i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + wn * 32 + g * 8 + hh * 4);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[mt][4 * g + k] = b[k];
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[mt][k] = 0.f;
+        }
+        RLAP(0)                                          // patch requests, residual prefetch, accumulator init
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            const int tap = st >> 2, ks = st & 3;
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RBK;
+            const v4i af = *reinterpret_cast<const v4i*>(Wl + tap * 64 * RB + aoff[ks]);
+            v4i bfr[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                bfr[mt] = *reinterpret_cast<const v4i*>(patch + pbase[mt] + tapoff +
+                                                        (((ks * 2 + hh) ^ (((pcol[mt] + (tap % 3)) >> 1) & 7)) << 4));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr[mt]),
+                                                                  acc[mt], 0, 0, 0);
+            if (st == 7) readout(0);                     // the previous tile leaves under this tile's MFMAs
+            if (st == 21) readout(1);
+        }
+        RLAP(1)                                          // 36 steps of fragment reads + MFMAs (+ the previous tile's read-out)
+        // ---- this tile becomes the pending one: round to bf16, 8-byte pieces -> 16-byte channel vectors across the lane halves
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                unsigned x[2], y[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    x[d] = pack2(f32x2{acc[mt][8 * k + 2 * d], acc[mt][8 * k + 2 * d + 1]});          // piece g = 2k   (couts 16k + 4hh + ..)
+                    y[d] = pack2(f32x2{acc[mt][8 * k + 4 + 2 * d], acc[mt][8 * k + 4 + 2 * d + 1]});  // piece g = 2k+1 (couts 16k + 8 + 4hh + ..)
+                    const auto r = __builtin_amdgcn_permlane32_swap(x[d], y[d], false, false);        // x[32..63] <-> y[0..31]
+                    x[d] = r[0]; y[d] = r[1];
+                }
+                prev[mt][k] = v4u{x[0], x[1], y[0], y[1]};       // channels wn*32 + 16k + 8hh + 0..7 of pixel (mt, l31)
+                if (MODE) rprev[mt][k] = rz[mt][k];
+            }
+            pval[mt] = val[mt];
+        }
+        psoff = osoff;
+        cur = nxt;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next tile's patch has landed (+ residual vectors, earlier stores)
+        __builtin_amdgcn_s_barrier();                    // ... for every wave, and every wave is done reading this tile's patch
+        RLAP(2)
+    }
+    readout(0);
+    readout(1);
+#ifdef PMOE_STAMP
+    if (a.stats && lane == 0) {
+        float* o = a.stats + (((size_t)e * wgs_per_expert + wg) * 8 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = (float)st_acc[i];
+        o[5] = (float)(unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+        o[6] = (float)ntile;
+    }
+    return;
+#endif
+
+    if (a.stats) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [8 waves][2][64]  (the filter bank is dead by now)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float u = s1[k][q][c], v = s2[k][q][c];
+#pragma unroll
+                    for (int off = 1; off < 32; off <<= 1) {
+                        u += __shfl_xor(u, off);
+                        v += __shfl_xor(v, off);
+                    }
+                    if (l31 == 0) {
+                        red[(wave * 2 + 0) * 64 + c0 + 16 * k + 2 * q + c] = u;
+                        red[(wave * 2 + 1) * 64 + c0 + 16 * k + 2 * q + c] = v;
+                    }
+                }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, c = tid & 63;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += red[((w * 2 + (c >> 5)) * 2 + which) * 64 + c];
             a.stats[(((size_t)e * wgs_per_expert + wg) * 2 + which) * a.CoutP + c] = s;
         }
     }
@@ -626,6 +986,24 @@ bool conv_res_dma_ok(const ConvArgs& a, const ResPlan& p, int* pbuf, int* magic_
     return true;
 }
 
+// does the software-pipelined variant (conv3x3_respipe_kernel: register read-out under the next tile's MFMAs) take what
+// conv_res_dma_ok accepted?  PMOE_RES_PIPE=0: A/B switch back to conv3x3_resdma_kernel (read per launch)
+bool conv_res_pipe_ok(const ConvArgs& a) {
+    const char* ev = getenv("PMOE_RES_PIPE");
+    if (ev && !atoi(ev)) return false;
+    if (a.ipe > 2047) return false;
+    if ((long long)a.ipe * a.Ho * a.Wo * a.out_ld * 2 >= 0x7ff00000ll) return false;
+    if (a.res_mode != PMOE_RES_NONE && (long long)a.ipe * a.Ho * a.Wo * a.res_ld * 2 >= 0x7ff00000ll) return false;
+    return true;
+}
+
+template <bool BIAS, int MODE>
+static int launch_respipe(const ConvArgs& a, const ResPlan& p, dim3 grid, size_t sm, int pb, int mpw, int mph, hipStream_t st) {
+    HIP_RET((ensure_dyn_lds<conv3x3_respipe_kernel<BIAS, MODE>>(163840)));
+    hipLaunchKernelGGL((conv3x3_respipe_kernel<BIAS, MODE>), grid, dim3(512), sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb, mpw, mph);
+    return (int)hipGetLastError();
+}
+
 int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
     a.lTW = p.lTW; a.lTH = p.lTH; a.TN = p.TN; a.n_groups = p.n_groups; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
     const int E = a.N / a.ipe;
@@ -634,6 +1012,15 @@ int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
     int pb = 0, mpw = 0, mph = 0;
     size_t sm = 0;
     if (conv_res_dma_ok(a, p, &pb, &mpw, &mph, &sm)) {
+        if (conv_res_pipe_ok(a)) {
+            const int mode = a.res_mode == PMOE_RES_DBN ? 2 : a.res_mode == PMOE_RES_ADD ? 1 : 0;
+            if (a.bias) return mode == 2 ? launch_respipe<true, 2>(a, p, grid, sm, pb, mpw, mph, st)
+                             : mode == 1 ? launch_respipe<true, 1>(a, p, grid, sm, pb, mpw, mph, st)
+                                         : launch_respipe<true, 0>(a, p, grid, sm, pb, mpw, mph, st);
+            return mode == 2 ? launch_respipe<false, 2>(a, p, grid, sm, pb, mpw, mph, st)
+                 : mode == 1 ? launch_respipe<false, 1>(a, p, grid, sm, pb, mpw, mph, st)
+                             : launch_respipe<false, 0>(a, p, grid, sm, pb, mpw, mph, st);
+        }
         const char* evp = getenv("PMOE_RES_PREFETCH");
         a.prefetch = !(evp && !atoi(evp));
         if (a.bias) {

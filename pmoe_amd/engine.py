@@ -547,7 +547,7 @@ class ExpertGroupEngine:
         if bnl.C != kw["cout"] or bnl.C != kw["coutp"] or z.t.shape != x.t.shape:      # (the statistics rows are coutp wide)
             return False
         common = dict(res=z.t, res_mode=hip.RES_DBN, bn_coef=coef, bn_ipe=self.B, bias=bias, **kw)
-        if ops.conv2d(dy, w_dg, g, plan_only=True, **common) not in (1107, 1117, 5007, 5017):
+        if ops.conv2d(dy, w_dg, g, plan_only=True, **common) not in (1107, 1117, 1247, 1257, 5007, 5017):
             return False
         n, h, w = dy.shape[0], dy.shape[1], dy.shape[2]
         rows = ops.conv2d_stat_rows(n, h, w, h, w, kw["cin"], kw["cout"], kw["coutp"], kw["ipe"], 3, 1, 1, self.dtype,

@@ -78,7 +78,7 @@ def test_conv_plan_reports_the_kernel_instantiation():
         d.in_ld, d.out_ld, d.ipe, d.ks, d.stride, d.pad, d.dilate = cin, cout, B, ks, stride, pad, int(dilate)
         d.dtype = 0 if dtype == torch.bfloat16 else 1
         return load().pmoe_conv2d_plan(C.byref(d))
-    assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1107                 # conv3x3_resdma_kernel (filter bank resident, LDS-DMA patches)
+    assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1207                 # conv3x3_respipe_kernel<false, 0> (filter bank resident, LDS-DMA patches)
     assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1316                 # 12(16)-channel stem: conv3x3_c16_kernel (direct form)
     assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 5017                # conv3x3_dma_kernel<true> (LDS-DMA staged, 16x16x32 MFMA shape from 256 input channels)
     assert plan(128, 128, 64, 3, 1, torch.bfloat16) == 5007                # conv3x3_dma_kernel<false> (32x32x16)
@@ -168,3 +168,34 @@ def test_cycle_stamped_tools_build_compiles(tmp_path):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DPMOE_STAMP",
                                "-c", str(src), "-o", str(tmp_path / f"{name}_stamp.o")], stderr=subprocess.DEVNULL)
     assert (tmp_path / "conv_igemm_stamp.o").stat().st_size > 0
+
+
+def test_buffer_stores_with_sgpr_offset_keep_their_data_registers(tmp_path):
+    """gfx950 reads the data registers of a > 64-bit buffer store after the instruction has issued; hipcc pads the ISA's
+    "store data -> VALU write" hazard only for stores WITHOUT an SGPR offset (round 3: with one, conv3x3_respipe_kernel stored
+    lanes 12-15 / 44-47 of a dword that the next instruction had already overwritten).  Static guard over the kernels that use
+    raw buffer stores: no VALU write to a store's data registers within two instructions of a store that carries an SGPR offset."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    for name in ("conv_c16", "conv_c1x1", "conv_res"):
+        out = tmp_path / f"{name}.s"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               str(REPO / "pmoe_amd" / "csrc" / f"{name}.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+        lines = out.read_text().split("\n")
+        for n, l in enumerate(lines):
+            m = re.match(r"\s*buffer_store_dwordx[34] v\[(\d+):(\d+)\], v\d+, s\[\d+:\d+\], (s\d+)", l)
+            if not m:
+                continue
+            lo, hi = int(m.group(1)), int(m.group(2))
+            k, seen = n + 1, 0
+            while seen < 2 and k < len(lines):
+                t = lines[k].strip()
+                k += 1
+                if not t or t[0] in ";.":
+                    continue
+                seen += 1
+                if t.startswith("s_nop"):
+                    break
+                w = re.match(r"v_(?!cmp)\S+ v\[?(\d+)", t)
+                assert not (w and lo <= int(w.group(1)) <= hi), (name, l.strip(), t)

@@ -141,7 +141,7 @@ def _conv_case(case, dtype, plan=None):
     ops.conv2d(dyd, wd, dx, cin=r16(cout), cout=cinp, coutp=r64(cin), ipe=ipe, ks=ks, stride=1,
                pad=ks - 1 - pad, dilate=(stride == 2))
     close(from_nhwc(dx, cin), xr.grad, dtype, "conv dgrad")
-    if stride == 1 and ks == 3 and plan is not None and plan[1] in (5007, 5017, 1107):
+    if stride == 1 and ks == 3 and plan is not None and plan[1] in (5007, 5017, 1207):
         # a data gradient accumulating into the gradient another consumer left (BasicBlock `.1.conv1`: the identity branch's):
         # PMOE_RES_ADD with the residual prefetched under the MFMAs on both LDS-DMA kernels
         prev = rnd((N, cin, H, W), torch.Generator().manual_seed(9), dtype)
@@ -207,14 +207,14 @@ BASELINE_CONV_CASES = [
     ((2, 32, 512, 512, 16, 16, 3, 1), (5017, 5017, 256)),      # layer4: 8 chunks, one 16 x 16 image per tile (two patch rows per
                                                                # 32-lane fragment: the column-keyed swizzle), 2 experts
     ((1, 5, 128, 256, 40, 24, 3, 1), (5007, 5017, 200)),       # ragged: 24-wide rows in 32-wide tiles, 40 rows in strips of 8, 5 images
-    ((1, 1, 64, 64, 256, 256, 3, 1), (1107, 1107, 256)),       # stem conv2: conv3x3_resdma_kernel, 256 tiles of one image
-    ((2, 2, 64, 64, 128, 128, 3, 1), (1107, 1107, 256)),       # layer1: resident kernel, persistent workgroups per expert
+    ((1, 1, 64, 64, 256, 256, 3, 1), (1207, 1207, 256)),       # stem conv2: conv3x3_respipe_kernel, 256 tiles of one image
+    ((2, 2, 64, 64, 128, 128, 3, 1), (1207, 1207, 256)),       # layer1: resident kernel, persistent workgroups per expert
     ((1, 4, 64, 128, 128, 128, 3, 2), (5207, 4741, 256)),      # layer2.0.conv1: conv3x3s2_dma_kernel (parity planes by LDS-DMA); its data gradient (64 gradient rows) stays on the generic kernel's 4 parity-class launches
     ((1, 8, 128, 256, 64, 64, 3, 2), (5207, 9207, None)),      # layer3.0.conv1: 2 channel chunks per plane; 4 chunks of dy per class
     ((2, 16, 256, 512, 32, 32, 3, 2), (5207, 9207, None)),     # layer4.0.conv1: 4 chunks (single-tap steps back to back), 4 cout blocks, 2 experts
     ((1, 6, 64, 128, 71, 55, 3, 2), (5207, None, None)),       # odd image sides: the last block row / column has only its plane-0 pixels; ragged tiles
     ((1, 4, 64, 128, 128, 128, 1, 2), (1404, 741, 128)),       # layer2.0.downsample (1x1 stride 2: conv1x1_direct_kernel<4>)
-    ((1, 1, 12, 64, 256, 256, 3, 1), (1316, 1107, 256)),       # stem conv1 (12 -> 16 input channels): direct-form conv3x3_c16_kernel
+    ((1, 1, 12, 64, 256, 256, 3, 1), (1316, 1207, 256)),       # stem conv1 (12 -> 16 input channels): direct-form conv3x3_c16_kernel
     ((2, 3, 12, 64, 40, 40, 3, 1), (1316, None, None)),        # ... ragged: 40-wide rows = one full + one 8-pixel tile, 2 experts x 3 images
     ((1, 2, 9, 48, 33, 96, 3, 1), (1316, None, None)),         # ... 9 input / 48 output channels (zero-padded filter rows, masked stores)
 ]
@@ -227,8 +227,8 @@ def test_conv_baseline_layer_shapes_bf16(case, plan):
 
 # (E_bn, images per BN set, channels, H, W, conv runs per image?, bias?) -> kernel code
 DBN_CASES = [
-    ((2, 2, 64, 128, 128, False, False), 1107),        # layer1 conv2 data gradient: conv3x3_resdma_kernel, persistent workgroups
-    ((2, 3, 64, 64, 96, True, True), 1117),            # stem conv2 (ECA gate folded: one "expert" per image, per-image bias)
+    ((2, 2, 64, 128, 128, False, False), 1247),        # layer1 conv2 data gradient: conv3x3_respipe_kernel<false, 2>, persistent workgroups
+    ((2, 3, 64, 64, 96, True, True), 1257),            # stem conv2 (ECA gate folded: one "expert" per image, per-image bias)
     ((1, 4, 128, 64, 64, False, False), 5007),         # layer2: conv3x3_dma_kernel
     ((2, 16, 512, 16, 16, False, False), 5017),        # layer4: one image per tile row group, 4 output-channel blocks
     ((1, 5, 256, 40, 24, False, False), 5017),         # ragged tiles
@@ -237,6 +237,19 @@ DBN_CASES = [
 
 @pytest.mark.parametrize("case,plan", DBN_CASES)
 def test_conv_dgrad_with_batchnorm_reductions(case, plan):
+    _dbn_case(case, plan)
+
+
+def test_conv_resident_lds_staged_fallback(monkeypatch):
+    """PMOE_RES_PIPE=0 (read per launch): the 64-channel layers back on conv3x3_resdma_kernel (read-out staged through LDS
+    between the tiles), the A/B partner of conv3x3_respipe_kernel: same parity bar."""
+    monkeypatch.setenv("PMOE_RES_PIPE", "0")
+    _conv_case((2, 2, 64, 64, 128, 128, 3, 1), torch.bfloat16, (1107, 1107, 256))
+    _dbn_case(DBN_CASES[0][0], 1107)
+    _dbn_case(DBN_CASES[1][0], 1117)
+
+
+def _dbn_case(case, plan):
     """PMOE_RES_DBN (round 3): the data gradient into a = relu(BatchNorm(z)) masks itself with the recomputed ReLU decision
     and leaves the BatchNorm backward's two channel reductions in `stats`.  Against the plain data gradient of the same
     launch masked on the host (BIT-identical: same accumulators, the mask only selects) and host sums of that."""
@@ -273,7 +286,9 @@ def test_conv_dgrad_with_batchnorm_reductions(case, plan):
     mask = (d * cb[2] + cb[3]) > 0
     assert 0.2 < mask.float().mean() < 0.8
     want = torch.where(mask, plain.float().cpu(), torch.zeros(()))
-    assert torch.equal(got.float().cpu(), want), "masked data gradient differs from the plain one"
+    bad = (got.float().cpu() != want)
+    assert not bad.any(), ("masked data gradient differs from the plain one", int(bad.sum()), bad.nonzero()[:8].tolist(),
+                           bad.sum((0, 1, 2)).nonzero().flatten().tolist()[:64])
     st = stats.view(Ebn, rows // Ebn, 2, r64(C)).sum(1).cpu()
     s1 = want.view(Ebn, -1, C).sum(1)
     s2 = (want * d * cb[1]).view(Ebn, -1, C).sum(1)

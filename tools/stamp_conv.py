@@ -21,12 +21,13 @@ def build():
     csrc, bld = ROOT / "pmoe_amd" / "csrc", ROOT / "build"
     subprocess.check_call([str(ROOT / "build.sh")])
     objs = []
-    for src in ("conv_igemm", "conv_dma", "conv_wgrad"):
+    for src in ("conv_igemm", "conv_dma", "conv_wgrad", "conv_res"):
         obj = bld / f"{src}_stamp.o"
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                                "-Wno-unused-result", "-DPMOE_STAMP", "-c", str(csrc / f"{src}.hip"), "-o", str(obj)])
         objs.append(str(obj))
-    skip = ("conv_igemm.o", "conv_igemm_stamp.o", "conv_dma.o", "conv_dma_stamp.o", "conv_wgrad.o", "conv_wgrad_stamp.o")
+    skip = ("conv_igemm.o", "conv_igemm_stamp.o", "conv_dma.o", "conv_dma_stamp.o", "conv_wgrad.o", "conv_wgrad_stamp.o",
+            "conv_res.o", "conv_res_stamp.o")
     others = [str(o) for o in sorted(bld.glob("*.o")) if o.name not in skip]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + objs + others)
     print("built", LIB)
@@ -41,7 +42,7 @@ def main():
     from pmoe_amd import hip, ops
     hip.load()
     E, B = 4, 64
-    shapes = {"l2": (128, 128, 64), "l3": (256, 256, 32), "l4": (512, 512, 16)}
+    shapes = {"l2": (128, 128, 64), "l3": (256, 256, 32), "l4": (512, 512, 16), "conv2": (64, 64, 256), "l1": (64, 64, 128)}
     dt = torch.bfloat16
     for name in [a for a in sys.argv[1:] if a in shapes] or ["l3", "l4"]:
         cin, cout, H = shapes[name]
@@ -63,6 +64,18 @@ def main():
                            stride=1, pad=1, stats=stats)
             torch.cuda.synchronize()
             v = stats.flatten().cpu()
+            if cout == 64:                                        # conv3x3_resdma_kernel: 5 laps per tile, summed over the workgroup's tiles
+                rec = v[:rows * 64].view(rows * 8, 8)
+                assert (rec[:, :7] >= 0).all(), "stamped library not loaded or a different kernel ran"
+                cyc, wall, nt = rec[:, :5], rec[:, 5] / 100.0, rec[:, 6]
+                per = (cyc / nt[:, None]).mean(0).tolist()
+                pipe = os.environ.get("PMOE_RES_PIPE", "1") != "0"
+                names = (["requests+init", "36 MFMA steps + the previous tile's read-out", "round/swap + wait + barrier", "-", "-"] if pipe else
+                         ["requests+init", "36 MFMA steps", "barrier (patch read)", "staging+wait+barrier", "read-out+stores+barrier"])
+                print(f"{name} {what} [{'conv3x3_respipe_kernel' if pipe else 'conv3x3_resdma_kernel'}]: {rows} workgroups, {nt.mean():.1f} tiles each; cycles per tile per wave: "
+                      + ", ".join(f"{n} {c:.0f}" for n, c in zip(names, per)) + f" = {sum(per):.0f}; workgroup wall {wall.mean():.1f} us "
+                      f"(=> {cyc.sum(1).mean() / wall.mean() / 1e3:.2f} GHz); slowest wave's main loop {(cyc[:, 1] / nt).max():.0f}")
+                continue
             nwg = rows * (cout // 128)
             if os.environ.get("PMOE_CONV_DMA", "1") != "0":       # conv3x3_dma_kernel: 3 laps + wall time per wave
                 rec = v[:nwg * 8 * 8].view(nwg * 8, 8)[:, :4]
