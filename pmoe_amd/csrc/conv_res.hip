@@ -751,53 +751,45 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
     };
     // read-out of channel vector k of the pending tile (both pixels): straight-line, stores of invalid pixels go out of range
     auto readout = [&](const int k) {
-        f32x2 mu[4], is[4], sc[4], sh[4];
-        if (MODE == 2) {
+        v4u pk[2];
+        const bool ok[2] = {pval[0] && cval[k], pval[1] && cval[k]};
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const f32x4 m = *reinterpret_cast<const f32x4*>(lbn + c0 + 16 * k + 4 * q);
-                const f32x4 i4 = *reinterpret_cast<const f32x4*>(lbn + 64 + c0 + 16 * k + 4 * q);
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(lbn + 128 + c0 + 16 * k + 4 * q);
-                const f32x4 h4 = *reinterpret_cast<const f32x4*>(lbn + 192 + c0 + 16 * k + 4 * q);
-                mu[2 * q] = f32x2{m[0], m[1]}; mu[2 * q + 1] = f32x2{m[2], m[3]};
-                is[2 * q] = f32x2{i4[0], i4[1]}; is[2 * q + 1] = f32x2{i4[2], i4[3]};
-                sc[2 * q] = f32x2{s4[0], s4[1]}; sc[2 * q + 1] = f32x2{s4[2], s4[3]};
-                sh[2 * q] = f32x2{h4[0], h4[1]}; sh[2 * q + 1] = f32x2{h4[2], h4[3]};
+        for (int q = 0; q < 4; ++q) {
+            f32x2 mu, is, sc, sh;                        // MODE 2: the coefficients of this channel pair (LDS broadcast reads)
+            if (MODE == 2) {
+                mu = *reinterpret_cast<const f32x2*>(lbn + c0 + 16 * k + 2 * q);
+                is = *reinterpret_cast<const f32x2*>(lbn + 64 + c0 + 16 * k + 2 * q);
+                sc = *reinterpret_cast<const f32x2*>(lbn + 128 + c0 + 16 * k + 2 * q);
+                sh = *reinterpret_cast<const f32x2*>(lbn + 192 + c0 + 16 * k + 2 * q);
             }
-        }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const bool ok = pval[mt] && cval[k];
-            v4u pk;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned w = ok ? prev[mt][k][q] : 0u;       // pixels outside the image contribute nothing to the sums
+            for (int mt = 0; mt < 2; ++mt) {
+                const unsigned w = ok[mt] ? prev[mt][k][q] : 0u;   // pixels outside the image contribute nothing to the sums
                 f32x2 v = unpack2(w);
                 if (MODE == 2) {
-                    const f32x2 d = unpack2(rprev[mt][k][q]) - mu[q];
-                    const f32x2 y = __builtin_elementwise_fma(d, sc[q], sh[q]);
+                    const f32x2 d = unpack2(rprev[mt][k][q]) - mu;
+                    const f32x2 y = __builtin_elementwise_fma(d, sc, sh);
                     // the value the apply pass will read is the ROUNDED masked gradient: the sums use it too
                     v = f32x2{y[0] > 0.f ? v[0] : 0.f, y[1] > 0.f ? v[1] : 0.f};
                     s1[k][q] += v;
-                    s2[k][q] = __builtin_elementwise_fma(v, d * is[q], s2[k][q]);
-                    pk[q] = pack2(v);
+                    s2[k][q] = __builtin_elementwise_fma(v, d * is, s2[k][q]);
+                    pk[mt][q] = pack2(v);
                 } else if (MODE == 1) {
-                    v += unpack2(rprev[mt][k][q]);
-                    pk[q] = pack2(v);
-                    const f32x2 rr = unpack2(pk[q]);
-                    s1[k][q] += rr;
-                    s2[k][q] = __builtin_elementwise_fma(rr, rr, s2[k][q]);
+                    v += unpack2(rprev[mt][k][q]);         // (no statistics in this mode: conv_res_pipe_ok)
+                    pk[mt][q] = pack2(v);
                 } else {
-                    pk[q] = w;
+                    pk[mt][q] = w;
                     s1[k][q] += v;
                     s2[k][q] = __builtin_elementwise_fma(v, v, s2[k][q]);
                 }
             }
-            // (tile base in the VECTOR offset, not in soffset: the registers of `pk` are rewritten by the next pixel's arithmetic
-            //  one instruction later, and hipcc pads the ISA's ">64-bit store data -> VALU write" hazard only for stores WITHOUT an
-            //  SGPR offset -- with one, lanes 12-15 / 44-47 of the first data dword were stored after they had been overwritten)
-            __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, (int)(ok ? ovo[mt] + psoff + 32u * k : (unsigned)OOB), 0, 0);
         }
+        // (tile base in the VECTOR offset, not in soffset: the registers of `pk` are rewritten by the next arithmetic a few
+        //  instructions later, and hipcc pads the ISA's ">64-bit store data -> VALU write" hazard only for stores WITHOUT an SGPR
+        //  offset -- with one, lanes 12-15 / 44-47 of the first data dword were stored after they had been overwritten)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            __builtin_amdgcn_raw_buffer_store_b128(pk[mt], rs_out, (int)(ok[mt] ? ovo[mt] + psoff + 32u * k : (unsigned)OOB), 0, 0);
     };
 
     RSTAMP_INIT
@@ -856,8 +848,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
             for (int mt = 0; mt < 2; ++mt)
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr[mt]),
                                                                   acc[mt], 0, 0, 0);
-            if (st == 7) readout(0);                     // the previous tile leaves under this tile's MFMAs
-            if (st == 21) readout(1);
+            if (st == 3) readout(0);                     // the previous tile leaves under this tile's MFMAs ...
+            if (st == 11) readout(1);
+            // ... in their first half (nothing is scheduled across this fence): the stores have the second half to be
+            // acknowledged before the vmcnt(0) below has to wait for them
+            if (st == 19) __builtin_amdgcn_sched_barrier(0);
         }
         RLAP(1)                                          // 36 steps of fragment reads + MFMAs (+ the previous tile's read-out)
         // ---- this tile becomes the pending one: round to bf16, 8-byte pieces -> 16-byte channel vectors across the lane halves
@@ -991,7 +986,11 @@ bool conv_res_dma_ok(const ConvArgs& a, const ResPlan& p, int* pbuf, int* magic_
 bool conv_res_pipe_ok(const ConvArgs& a) {
     const char* ev = getenv("PMOE_RES_PIPE");
     if (ev && !atoi(ev)) return false;
-    if (a.ipe > 2047) return false;
+    if (a.ipe > 2047 || (a.res_mode == PMOE_RES_ADD && a.stats)) return false;
+    // (measured and not kept, same box, profiles/r03_kernel_ab.log: the requests for the next patch as straight-line code inside
+    //  the MFMA block -- range checks as one guarded subtraction per bound, a wave without a 6th piece requesting its 5th again --
+    //  and the residual / z vectors loaded into the registers the read-out has just freed: within 1 % on the stem, 3-5 % slower
+    //  on layer1)
     if ((long long)a.ipe * a.Ho * a.Wo * a.out_ld * 2 >= 0x7ff00000ll) return false;
     if (a.res_mode != PMOE_RES_NONE && (long long)a.ipe * a.Ho * a.Wo * a.res_ld * 2 >= 0x7ff00000ll) return false;
     return true;
