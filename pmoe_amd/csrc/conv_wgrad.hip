@@ -247,10 +247,19 @@ __global__ void __launch_bounds__(WgradCfg<T>::NW * 64) conv_wgrad_kernel(const 
 // PAIRS (WCI = 1, <= 16 input channels: the stem's first convolution, 12 -> 16): the 32 columns of an MFMA hold TWO taps x
 // 16 channels instead of one tap x 16 channels + 16 columns of zero fill -- lanes 16..31 of a fragment read the next tap's
 // pixel (a per-lane tap offset), 5 MFMAs per k-block instead of 9 (round 3: 0.83 -> ~0.5 ms on the per-image stem gradient).
-template <int PIN, int WCI = 2, bool PAIRS = false>
+// REQ (round 3; cycle stamps of the forward kernels showed the request phase -- two runtime divisions and ~30 VALU
+// instructions per piece, ten pieces per wave, every wave of the workgroup at once right behind the barrier -- costing a third of
+// an m-block's MFMA time): 1 = the per-lane geometry of the pieces is tile-invariant and computed once, the tile walk is
+// incremental, range checks are one guarded subtraction per bound (~7 VALU per piece); 2 = ... and the requests are issued
+// between the k-blocks of the first half of the m-block instead of all at its top.  0 = the round-2 code (A/B).
+// Measured (profiles/r03_kernel_ab.log, one box, interleaved): 1 = +1.5..4 % on every layer (shipped); 2 = 4-8 % SLOWER than 0 --
+// the requests were never what held this kernel back; its k-loop is (the MFMA of tap t waits for the transposed X fragment
+// requested one MFMA earlier), and the fully unrolled loop that mode 2 needs schedules worse.
+template <int PIN, int WCI = 2, bool PAIRS = false, int REQ = 0>
 __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, const int magic_pw, const int magic_ph) {
     constexpr int TAPS = 9, RS = 128, CKW = 64;
     static_assert(!PAIRS || WCI == 1, "tap pairs: the narrow wave layout only");
+    static_assert(REQ == 0 || (WCI == 2 && !PAIRS && PIN == 1), "precomputed requests: the 2 x 2 x 2 wave layout only");
     constexpr int WCO = 2, WK = 8 / (WCI * WCO);
     typedef __attribute__((address_space(3))) void lds_void;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -335,6 +344,68 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
         }
     };
 
+    // REQ >= 1: (image, row, column) of a piece's pixel inside the tile / patch as three 9-bit fields with a guard bit each: the
+    // guard of a field survives `x | G - lo` iff x >= lo, so one subtraction per bound checks all three.  A wave without a 6th X
+    // piece requests its 5th again (same bytes to the same place): every wave issues the same instruction stream.
+    constexpr int GUARD = (1 << 9) | (1 << 19) | (1 << 29);
+    int drel[4], dgeo[4], xrel[6], xgeo[6], xslot[6];
+    struct Walk { int px, py, ng; };
+    Walk nxtw{0, 0, 0};
+    if constexpr (REQ >= 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = ((wave + 8 * i) << 3) + (lane >> 3);
+            const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+            const int j = (lane & 7) ^ (((p >> 1) & 1) << 2);
+            drel[i] = ((((pn * a.Ho + my) * a.Wo + mx) * a.dy_ld) << 1) + (j << 4);
+            dgeo[i] = (co0 + j * 8 < a.Cout ? (pn << 20) | (my << 10) | mx : (511 << 20)) | GUARD;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            xslot[i] = wave + 8 * (i < my_pieces ? i : my_pieces - 1);
+            const int pp = (xslot[i] << 3) + (lane >> 3);
+            const int rowq = (pp * magic_pw) >> 16, px = pp - rowq * PW;
+            const int pn = (rowq * magic_ph) >> 16, prow = rowq - pn * PH;
+            const int j = (lane & 7) ^ (((px >> 1) & 1) << 2);
+            xrel[i] = ((((pn * a.H + prow) * a.W + px) * a.x_ld) << 1) + (j << 4);
+            xgeo[i] = (pp < NPIX && ci0 + j * 8 < a.Cin ? (pn << 20) | (prow << 10) | px : (511 << 20)) | GUARD;
+        }
+        int t = mb_begin;
+        nxtw.px = t % a.tiles_x; t /= a.tiles_x;
+        nxtw.py = t % a.tiles_y; nxtw.ng = t / a.tiles_y;
+    }
+    auto imin = [](int x, int y) { return x < y ? x : y; };
+    // scalars of the m-block `nxtw` points at (uniform), then one request per call; `live` = false parks the offsets out of range
+    int rq_dbase = 0, rq_dkk = 0, rq_xbase = 0, rq_xlo = 0, rq_xkk = 0, rq_want = 0;
+    auto req_begin = [&](bool live) {
+        const int n0 = nxtw.ng * a.TN, oy0 = nxtw.py * TH, ox0 = nxtw.px * TW, Y0 = oy0 - a.pad, X0 = ox0 - a.pad;
+        const int nmax = imin(a.ipe - n0, 511) - 1;
+        rq_dbase = (((n0 * a.Ho + oy0) * a.Wo + ox0) * a.dy_ld) << 1;
+        rq_dkk = (((nmax << 20) | ((imin(TH, a.Ho - oy0) - 1) << 10) | (imin(TW, a.Wo - ox0) - 1)) | GUARD) + GUARD;
+        rq_xbase = (((n0 * a.H + Y0) * a.W + X0) * a.x_ld) << 1;
+        rq_xlo = ((Y0 < 0 ? -Y0 : 0) << 10) | (X0 < 0 ? -X0 : 0);
+        rq_xkk = (((nmax << 20) | ((imin(PH, a.H - Y0) - 1) << 10) | (imin(PW, a.W - X0) - 1)) | GUARD) + GUARD;
+        rq_want = live ? GUARD : -1;                     // (no branch on `live`: a comparison that cannot hold)
+        if (++nxtw.px == a.tiles_x) { nxtw.px = 0; if (++nxtw.py == a.tiles_y) { nxtw.py = 0; ++nxtw.ng; } }
+    };
+    auto req_dy = [&](int i, int buf) {
+        const bool ok = ((rq_dkk - dgeo[i]) & GUARD) == rq_want;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void*)(smem + buf * pair_bytes + ((wave + 8 * i) << 10)), 16,
+                                                 ok ? rq_dbase + drel[i] : OOB, 0, 0, 0);
+    };
+    auto req_x = [&](int i, int buf) {
+        const bool ok = ((xgeo[i] - rq_xlo) & (rq_xkk - xgeo[i]) & GUARD) == rq_want;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(smem + buf * pair_bytes + (BMP << 7) + (xslot[i] << 10)), 16,
+                                                 ok ? rq_xbase + xrel[i] : OOB, 0, 0, 0);
+    };
+    auto req_all = [&](int buf, bool live) {
+        req_begin(live);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) req_dy(i, buf);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) req_x(i, buf);
+    };
+
     // lane-constant parts of the transposed-fragment addresses (g = lane >> 4: channel block g & 1, k half g >> 1;
     // q = (lane >> 2) & 3: pixel of the 4-row block this lane addresses; pc = lane & 3: 4-channel column group)
     const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
@@ -356,12 +427,15 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
         }
     }
 
-    if (mb_begin < mb_end) issue(mb_begin, 0);
+    if constexpr (REQ >= 1) req_all(0, mb_begin < mb_end);
+    else if (mb_begin < mb_end) issue(mb_begin, 0);
     for (int mbi = mb_begin; mbi < mb_end; ++mbi) {
         const int buf = (mbi - mb_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's pieces of m-block mbi; its reads of mbi-1
         __builtin_amdgcn_s_barrier();                   // every wave's pieces are in LDS; the other buffer pair is free
-        if (mbi + 1 < mb_end) issue(mbi + 1, buf ^ 1);  // lands under this m-block's MFMAs
+        if constexpr (REQ == 1) req_all(buf ^ 1, mbi + 1 < mb_end);
+        else if constexpr (REQ == 2) req_begin(mbi + 1 < mb_end);
+        else if (mbi + 1 < mb_end) issue(mbi + 1, buf ^ 1);  // lands under this m-block's MFMAs
         const char* dyt = smem + buf * pair_bytes;
         const char* patch = dyt + (BMP << 7);
         // k-blocks of 16 pixels; the X fragment of tap t+1 is read BEFORE the MFMA of tap t, order pinned: with one dY fragment
@@ -401,8 +475,16 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
             }
             return fb;
         };
-#pragma unroll 2
+#pragma unroll(REQ == 2 ? 8 : 2)
         for (int kb = k_sub; kb < (BMP >> 4); kb += WK) {
+            if constexpr (REQ == 2) {
+                // k-block it of 8: the ten requests of the next m-block leave in the first four (two to three each), so that the
+                // last of them still has half an m-block to land
+                const int it = (kb - k_sub) / WK;
+                if (it < 4) req_dy(it, buf ^ 1);
+                if (it < 2) { req_x(2 * it, buf ^ 1); req_x(2 * it + 1, buf ^ 1); }
+                else if (it < 4) req_x(it + 2, buf ^ 1);
+            }
             int pA[2], ppB[2];
             frag_addr(kb, pA, ppB);
             if (PIN >= 2) {   // tools build (-DPMOE_STAMP) only, timing, WRONG results: 2 = one X fragment per k-block, 3 = no LDS reads at all
@@ -698,8 +780,18 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                     HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<0>>(160 * 1024)));
                     hipLaunchKernelGGL(conv_wgrad_dma_kernel<0>, grid, block, sm, st, a, mpw, mph);
                 } else {
-                    HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<1>>(160 * 1024)));
-                    hipLaunchKernelGGL(conv_wgrad_dma_kernel<1>, grid, block, sm, st, a, mpw, mph);
+                    const char* evr = getenv("PMOE_WGRAD_REQ");             // A/B: 0 = round-2 request code, 1 = precomputed, at the top
+                    const int req = a.ipe > 511 ? 0 : evr ? atoi(evr) : 1;
+                    if (req == 2) {
+                        HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<1, 2, false, 2>>(160 * 1024)));
+                        hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 2, false, 2>), grid, block, sm, st, a, mpw, mph);
+                    } else if (req == 1) {
+                        HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<1, 2, false, 1>>(160 * 1024)));
+                        hipLaunchKernelGGL((conv_wgrad_dma_kernel<1, 2, false, 1>), grid, block, sm, st, a, mpw, mph);
+                    } else {
+                        HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<1>>(160 * 1024)));
+                        hipLaunchKernelGGL(conv_wgrad_dma_kernel<1>, grid, block, sm, st, a, mpw, mph);
+                    }
                 }
                 HIP_RET(hipGetLastError());
                 return wgrad_finish(a, E, 9, nsp, st);
