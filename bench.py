@@ -561,12 +561,16 @@ def main():
         nbytes = 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
         link = 153e9
         ring = lambda n: 2 * (n - 1) / n * nbytes / link * 1e3           # one ring: per-link bound
+        mesh = lambda n: 2 * nbytes / n / link * 1e3                      # reduce-scatter + all-gather, one slice per peer link
         out["allreduce_model"] = {
             "gradient_bytes": nbytes, "buckets": model._engine().dp_buckets, "backward_ms_measured": round(e0.elapsed_time(e1), 2),
-            "xgmi_link_GBs": 153, "ring_ms": {str(n): round(ring(n), 2) for n in (2, 4, 8)},
-            "note": "RCCL ring all-reduce of the f32 gradient arena, per-link bound (2(N-1)/N x bytes / 153 GB/s); the "
-                    "buckets start as soon as the tape has moved past them (heads -> layer4 -> ... -> stem), and the last "
-                    "bucket (stem + layer1, ~45 % of backward time) is the only one not covered by remaining backward work"}
+            "xgmi_link_GBs": 153, "collective": "reduce_scatter_tensor + all_gather_into_tensor per bucket (pmoe_amd/parallel.py)",
+            "mesh_ms": {str(n): round(mesh(n), 2) for n in (2, 4, 8)}, "ring_ms": {str(n): round(ring(n), 2) for n in (2, 4, 8)},
+            "note": "ARITHMETIC, not a measurement (no multi-GPU node was available to the builder): f32 gradient arena over "
+                    "153 GB/s xGMI links; mesh = every rank exchanges its 1/N slice with each peer over that peer's own link "
+                    "(2 x bytes / N / link), ring = one link per hop (2(N-1)/N x bytes / link).  Buckets are cut by backward "
+                    "TIME (engine._bucket_cuts): each starts as soon as the tape has moved past it (heads -> layer4 -> ... -> "
+                    "stem); the last one (the stem) is small and is the only one not covered by remaining backward work"}
     elif use_dist:
         d, sp = model(images, speed, command)                             # keep the ranks' collectives aligned
         model.zero_grad(set_to_none=True)
