@@ -91,6 +91,8 @@ CONV_CASES = [
     (2, 1, 64, 128, 7, 10, 3, 2),
     (1, 5, 256, 256, 7, 7, 3, 1),
     (2, 3, 512, 512, 4, 4, 3, 1),
+    (2, 3, 64, 64, 40, 24, 3, 1),         # resident-filter kernel (register read-out): ragged tiles on both axes
+    (2, 3, 64, 64, 8, 16, 3, 1),          # ... two images per tile, the expert's last tile half empty
 ]
 
 
@@ -303,6 +305,17 @@ def test_conv_dma_mfma16_variant(monkeypatch, case):
     same tile, same parity bar (forward with fused statistics, data gradient)."""
     monkeypatch.setenv("PMOE_DMA_MF16", "1")
     _conv_case(case, torch.bfloat16, (5017, 5017, None))
+
+
+@pytest.mark.parametrize("req", ["0", "2"])
+def test_conv_wgrad_request_modes(monkeypatch, req):
+    """PMOE_WGRAD_REQ (read per launch): the weight-gradient kernel's round-2 request code (0) and the variant that spreads the
+    requests between the k-blocks (2) -- the A/B partners of the shipped mode 1 (tile-invariant piece geometry, guarded range
+    checks): same parity bar on a layer1 shape and on ragged tiles with an odd image count per expert."""
+    monkeypatch.setenv("PMOE_WGRAD_REQ", req)
+    _conv_case((2, 2, 64, 64, 128, 128, 3, 1), torch.bfloat16)
+    _conv_case((1, 5, 128, 256, 40, 24, 3, 1), torch.bfloat16)
+    _conv_case((2, 3, 256, 128, 16, 16, 3, 1), torch.bfloat16)
 
 
 def test_conv_resident_pingpong_fallback(monkeypatch):
