@@ -122,18 +122,20 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     }
 }
 
-// finalize: block = 64 channels x 4 partial lanes
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ part, int nparts, long long count,
+// finalize: block = 64 channels x 16 partial lanes (round 3: up to 2048 partial rows are folded HERE in fixed order instead of by
+// a reduce_partials launch in front of every finalize: ~250 launches fewer in the stage-1 step, ~200 in the PU-Net expert's)
+constexpr int FIN_LANES = 16;
+__global__ void __launch_bounds__(64 * FIN_LANES) bn_finalize_kernel(const float* __restrict__ part, int nparts, long long count,
                                                          const float* const* gamma, const float* const* beta,
                                                          float* const* rmean, float* const* rvar, float momentum,
                                                          float eps, int training, float* scale, float* shift,
                                                          float* mean_o, float* invstd_o, int C,
                                                          const float* __restrict__ shiftc) {
     const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][FIN_LANES][64];
     float s1 = 0.f, s2 = 0.f;
     if (c < C && training)
-        for (int i = pl; i < nparts; i += 4) {
+        for (int i = pl; i < nparts; i += FIN_LANES) {
             s1 += part[(((size_t)e * nparts + i) * 2 + 0) * C + c];
             s2 += part[(((size_t)e * nparts + i) * 2 + 1) * C + c];
         }
@@ -143,8 +145,9 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     if (pl == 0 && c < C) {
         float mean, var;
         if (training) {
-            const float t1 = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
-            const float t2 = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < FIN_LANES; ++k) { t1 += red[0][k][threadIdx.x]; t2 += red[1][k][threadIdx.x]; }
             const double md = (double)t1 / (double)count;          // mean of the deviations x - c
             double v = (double)t2 / (double)count - md * md;
             if (v < 0.0) v = 0.0;
@@ -169,14 +172,14 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts,
+__global__ void __launch_bounds__(64 * FIN_LANES) bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts,
                                                              long long count, float* dgamma, float* dbeta, float* c1,
                                                              float* c2, int C) {
     const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][FIN_LANES][64];
     float s1 = 0.f, s2 = 0.f;
     if (c < C)
-        for (int i = pl; i < nparts; i += 4) {
+        for (int i = pl; i < nparts; i += FIN_LANES) {
             s1 += part[(((size_t)e * nparts + i) * 2 + 0) * C + c];
             s2 += part[(((size_t)e * nparts + i) * 2 + 1) * C + c];
         }
@@ -184,8 +187,9 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
     red[1][pl][threadIdx.x & 63] = s2;
     __syncthreads();
     if (pl == 0 && c < C) {
-        const float t1 = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
-        const float t2 = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < FIN_LANES; ++k) { t1 += red[0][k][threadIdx.x]; t2 += red[1][k][threadIdx.x]; }
         if (dbeta) dbeta[e * C + c] = t1;
         if (dgamma) dgamma[e * C + c] = t2;
         c1[e * C + c] = t1 / (float)count;
@@ -742,7 +746,7 @@ int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const voi
                      float eps, int32_t training, float* scale, float* shift, float* mean, float* invstd, int32_t E,
                      int32_t C, const float* shiftc, void* stream) {
     if (!training && (!rmean_ptrs || !rvar_ptrs)) return PMOE_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, E), dim3(256), 0, (hipStream_t)stream, part, nparts,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, E), dim3(64 * FIN_LANES), 0, (hipStream_t)stream, part, nparts,
                        (long long)count, (const float* const*)gamma_ptrs, (const float* const*)beta_ptrs,
                        (float* const*)rmean_ptrs, (float* const*)rvar_ptrs, momentum, eps, training, scale, shift, mean,
                        invstd, C, shiftc);
@@ -751,7 +755,7 @@ int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const voi
 
 int pmoe_bn_bwd_finalize(const float* part, int32_t nparts, int64_t count, float* dgamma, float* dbeta, float* c1,
                          float* c2, int32_t E, int32_t C, void* stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, E), dim3(256), 0, (hipStream_t)stream, part, nparts,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, E), dim3(64 * FIN_LANES), 0, (hipStream_t)stream, part, nparts,
                        (long long)count, dgamma, dbeta, c1, c2, C);
     return (int)hipGetLastError();
 }

@@ -565,9 +565,10 @@ class ExpertGroupEngine:
         (E * nparts blocks of 256 threads), at least 256 rows each."""
         return min(1024, max(1, rpe // 256))
 
-    def _fold_parts(self, part, nparts, width):
-        """deterministic second stage: [E][nparts][width] -> at most 128 rows before a finalize kernel."""
-        if nparts <= 128:
+    def _fold_parts(self, part, nparts, width, cap=128):
+        """deterministic second stage: [E][nparts][width] -> at most 128 rows before a finalize kernel (``cap``: what that
+        kernel folds by itself -- the BatchNorm finalize kernels take 2048 rows over 16 partial lanes)."""
+        if nparts <= cap:
             return part, nparts
         small = torch.empty(self.E, 128, width, dtype=F32, device=self.dev)
         ops.reduce_partials(part, small, self.E, nparts, 128, width)
@@ -586,7 +587,7 @@ class ExpertGroupEngine:
                 part = torch.empty(E, nparts, 2, C_, dtype=F32, device=self.dev)
                 shiftc = torch.empty(E, C_, dtype=F32, device=self.dev)
                 ops.colstats(rpe, z.t, E, C_, part, nparts, shiftc=shiftc)
-            part, nparts = self._fold_parts(part, nparts, 2 * C_)
+            part, nparts = self._fold_parts(part, nparts, 2 * C_, cap=2048)
             ops.bn_finalize(part, nparts, rpe, self._tab("gamma", layer), self._tab("beta", layer),
                             self._tab("rm", layer), self._tab("rv", layer), layer.momentum, layer.eps, True, scale,
                             shift, mean, invstd, E, C_, shiftc)
@@ -654,7 +655,7 @@ class ExpertGroupEngine:
             part, nparts = y.bn_part
             if part.shape[2] != C_:
                 raise RuntimeError("BatchNorm reductions from the data-gradient epilogue: channel count mismatch")
-            part, nparts = self._fold_parts(part.view(E, nparts, 2 * C_), nparts, 2 * C_)
+            part, nparts = self._fold_parts(part.view(E, nparts, 2 * C_), nparts, 2 * C_, cap=2048)
             c1, c2 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(2))
             dgamma, dbeta, store = self._bn_grad_views(layer)
             ops.bn_bwd_finalize(part, nparts, rpe, dgamma, dbeta, c1, c2, E, C_)
@@ -676,7 +677,7 @@ class ExpertGroupEngine:
         gm = torch.empty_like(z.t) if (want_res and relu and ysrc is not None and self.bn_mask_in_reduce) else None
         ops.set_meta(name=layer.name, bytes=nb * ((3 if ysrc is not None else 2) + (gm is not None)))
         ops.bn_bwd_reduce(dy, ysrc, z.t, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts, gmask=gm)
-        part, nparts = self._fold_parts(part, nparts, 2 * C_)
+        part, nparts = self._fold_parts(part, nparts, 2 * C_, cap=2048)
         c1, c2 = (torch.empty(E, C_, dtype=F32, device=self.dev) for _ in range(2))
         dgamma, dbeta, store = self._bn_grad_views(layer)
         ops.bn_bwd_finalize(part, nparts, rpe, dgamma, dbeta, c1, c2, E, C_)

@@ -121,6 +121,15 @@ def test_unshuffle_add_window_and_nchw(dtype):
         for k in range(K):
             want[..., k * 23:(k + 1) * 23] = ms[k][..., :23]
         assert torch.equal(cat, want)
+    # ... windows that start inside a vector, and a source pitch that is not a multiple of the vector width (element-wise kernel)
+    for ld, coff, cwin, K, width in ((32, 5, 23, 3, 80), (40, 16, 19, 2, 48), (28, 3, 23, 2, 48)):
+        ms2 = [torch.randn(n, h, w, ld, generator=g).to(DEV, dtype) for _ in range(K)]
+        cat = torch.full((n, h, w, width), 3.0, dtype=dtype, device=DEV)
+        ops.cat_windows(ms2, cat, cwin, src_coff=coff)
+        want = torch.zeros(n, h, w, width, dtype=dtype, device=DEV)
+        for k in range(K):
+            want[..., k * cwin:(k + 1) * cwin] = ms2[k][..., coff:coff + cwin]
+        assert torch.equal(cat, want), (ld, coff, cwin, K)
     # NCHW f32 -> NHWC (zero padded): tiled kernel with a ragged last block, and the wide-row fall-back
     for (c, cp, h, w) in [(138, 144, 20, 13), (250, 256, 5, 9), (3, 16, 1, 1)]:
         img = torch.randn(n, c, h, w, generator=g)
