@@ -4,7 +4,7 @@
     GRBM_GUI_ACTIVE           busy cycles of the dispatch, summed over the 8 XCDs  -> / 8 = the kernel's duration in shader cycles
     SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT   LDS-array cycles / extra cycles from bank conflicts (per CU, summed)
 MFMA utilisation = MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs).  Writes profiles/r03_conv_pmc.json.
-    python3 tools/collect_pmc.py <rocprof output dir>"""
+    python3 tools/collect_pmc.py <rocprof output dir> [<second dir: the same counters over tools/bench_conv_f8.py>]"""
 import csv
 import json
 import sys
@@ -16,7 +16,7 @@ SIMDS = 256 * 4
 
 def main():
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-    for f in Path(sys.argv[1]).rglob("*counter_collection.csv"):
+    for f in (f for d in sys.argv[1:] for f in Path(d).rglob("*counter_collection.csv")):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
@@ -27,7 +27,8 @@ def main():
                 a[1] += 1
     out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE "
                       "--output-format csv -- python3 tools/bench_conv.py conv2 l1 l2s2 l2 l3 l4   (E=4, B=64 layer shapes of the "
-                      "headline step, random data; forward, data gradient and weight gradient of each, 11 launches per kind)",
+                      "headline step, random data; forward, data gradient and weight gradient of each, 11 launches per kind); the e4m3 kernel "
+                      "conv3x3_dma_f8_kernel from the same counters over python3 tools/bench_conv_f8.py (layer2-4 forward, beside its bf16 partner)",
            "units": "per launch; mfma_util = MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); lds_active / lds_conflict per CU "
                     "as a share of the kernel's cycles",
            "kernels": {}}

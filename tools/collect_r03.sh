@@ -14,5 +14,7 @@ echo "write rc=$?"
 python3 "$R/tools/collect_traffic.py" "$O/pmc_fetch" "$O/pmc_write" 5 && cp "$R/profiles/traffic.json" "$O/traffic.json"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$O/pmc_sq" -o s -- python3 "$R/tools/bench_conv.py" conv2 l1 l2s2 l2 l3 l4 > "$O/pmc_sq.log" 2>&1
 echo "sq rc=$?"
-python3 "$R/tools/collect_pmc.py" "$O/pmc_sq" && cp "$R/profiles/r03_conv_pmc.json" "$O/r03_conv_pmc.json"
-rm -rf "$O/pmc_fetch" "$O/pmc_write" "$O/prof" "$O/pmc_sq"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$O/pmc_f8" -o s -- python3 "$R/tools/bench_conv_f8.py" > "$O/pmc_f8.log" 2>&1
+echo "f8 rc=$?"
+python3 "$R/tools/collect_pmc.py" "$O/pmc_sq" "$O/pmc_f8" && cp "$R/profiles/r03_conv_pmc.json" "$O/r03_conv_pmc.json"
+rm -rf "$O/pmc_fetch" "$O/pmc_write" "$O/prof" "$O/pmc_sq" "$O/pmc_f8"
