@@ -132,8 +132,8 @@ __global__ void __launch_bounds__(64 * FIN_LANES) bn_finalize_kernel(const float
                                                          float* mean_o, float* invstd_o, int C,
                                                          const float* __restrict__ shiftc) {
     const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    __shared__ float red[2][FIN_LANES][64];
-    float s1 = 0.f, s2 = 0.f;
+    __shared__ double red[2][FIN_LANES][64];              // (partial rows folded in double: up to 2048 f32 rows per channel)
+    double s1 = 0.0, s2 = 0.0;
     if (c < C && training)
         for (int i = pl; i < nparts; i += FIN_LANES) {
             s1 += part[(((size_t)e * nparts + i) * 2 + 0) * C + c];
@@ -145,11 +145,11 @@ __global__ void __launch_bounds__(64 * FIN_LANES) bn_finalize_kernel(const float
     if (pl == 0 && c < C) {
         float mean, var;
         if (training) {
-            float t1 = 0.f, t2 = 0.f;
+            double t1 = 0.0, t2 = 0.0;
 #pragma unroll
             for (int k = 0; k < FIN_LANES; ++k) { t1 += red[0][k][threadIdx.x]; t2 += red[1][k][threadIdx.x]; }
-            const double md = (double)t1 / (double)count;          // mean of the deviations x - c
-            double v = (double)t2 / (double)count - md * md;
+            const double md = t1 / (double)count;                  // mean of the deviations x - c
+            double v = t2 / (double)count - md * md;
             if (v < 0.0) v = 0.0;
             const double m = md + (shiftc ? (double)shiftc[e * C + c] : 0.0);
             mean = (float)m;
@@ -176,8 +176,8 @@ __global__ void __launch_bounds__(64 * FIN_LANES) bn_bwd_finalize_kernel(const f
                                                              long long count, float* dgamma, float* dbeta, float* c1,
                                                              float* c2, int C) {
     const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    __shared__ float red[2][FIN_LANES][64];
-    float s1 = 0.f, s2 = 0.f;
+    __shared__ double red[2][FIN_LANES][64];
+    double s1 = 0.0, s2 = 0.0;
     if (c < C)
         for (int i = pl; i < nparts; i += FIN_LANES) {
             s1 += part[(((size_t)e * nparts + i) * 2 + 0) * C + c];
@@ -187,13 +187,13 @@ __global__ void __launch_bounds__(64 * FIN_LANES) bn_bwd_finalize_kernel(const f
     red[1][pl][threadIdx.x & 63] = s2;
     __syncthreads();
     if (pl == 0 && c < C) {
-        float t1 = 0.f, t2 = 0.f;
+        double t1 = 0.0, t2 = 0.0;
 #pragma unroll
         for (int k = 0; k < FIN_LANES; ++k) { t1 += red[0][k][threadIdx.x]; t2 += red[1][k][threadIdx.x]; }
-        if (dbeta) dbeta[e * C + c] = t1;
-        if (dgamma) dgamma[e * C + c] = t2;
-        c1[e * C + c] = t1 / (float)count;
-        c2[e * C + c] = t2 / (float)count;
+        if (dbeta) dbeta[e * C + c] = (float)t1;
+        if (dgamma) dgamma[e * C + c] = (float)t2;
+        c1[e * C + c] = (float)(t1 / (double)count);
+        c2[e * C + c] = (float)(t2 / (double)count);
     }
 }
 
