@@ -25,8 +25,9 @@ from oracle import weights as W  # noqa: E402
 
 GOLDEN = ROOT / "tests" / "golden"
 MOE_CASES = ["g1_moe_e4_b2_128", "g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g6_moeshared_k4_b6_96", "g10_moe_e4_b32_64",
-             "g2_moe_e4_b1_224_eval", "g7_moeshared_k6_b1_224_eval"]
-PUNET_CASES = ["p1_punet_b2_64_f2", "p2_punet_b1_64_f6_eval", "p3_punetinter_b2_64_f2", "p5_pmoe_e2_b2_64_f2"]
+             "g11_moe_e4_b8_128", "g2_moe_e4_b1_224_eval", "g7_moeshared_k6_b1_224_eval"]
+PUNET_CASES = ["p1_punet_b2_64_f2", "p2_punet_b1_64_f6_eval", "p3_punetinter_b2_64_f2", "p5_pmoe_e2_b2_64_f2",
+               "p6_punet_b8_96_f2"]
 GRAD_CASES = ["g3_moe_e8_b2_128", "g10_moe_e4_b32_64"]
 VARIANTS = ("all", "fused")
 JITTERS = 6        # extra draws of the emulation error: the same case with its images jittered by 1 % (seeds 1..JITTERS)

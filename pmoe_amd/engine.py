@@ -51,6 +51,13 @@ class Var:
         return self.base.g if self.base is not None else self.g
 
     def set_grad(self, g):
+        if (self.base if self.base is not None else self).bn_part is not None:
+            # a PMOE_RES_DBN data gradient already masked this gradient with the ReLU decision and reduced it for the
+            # BatchNorm backward (_dgrad_with_bn_reduce): it assumed this activation has exactly one consumer.  A second
+            # contribution would be added unmasked and would be missing from the reductions -- silently wrong dgamma / dbeta / dz
+            raise RuntimeError("relu(BatchNorm(z)) whose backward reductions came out of its consumer's data gradient "
+                               "(PMOE_RES_DBN) must have exactly one consumer; a second gradient contribution arrived "
+                               "(set PMOE_BN_REDUCE_IN_DGRAD=0 for graphs that fan this activation out)")
         if self.base is not None:
             self.base.g = g
         else:

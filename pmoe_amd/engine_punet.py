@@ -278,11 +278,24 @@ class PUNetEngine(ExpertGroupEngine):
         H, W = images.shape[-2:]
         nc, cpad = pu.num_classes, r16(pu.in_features)
         masks = []
+        # tests/punet_parity.py (per-pass teacher forcing): ``debug_pass_out`` (a list) collects the mask tensor every U-Net
+        # pass wrote; ``debug_forced_masks`` (T + F tensors [B,classes,H,W]) REPLACES each pass's output by the given mask
+        # before the later passes read it, so that every pass runs on the checker's inputs and errors do not compound
+        kept, forced = getattr(self, "debug_pass_out", None), getattr(self, "debug_forced_masks", None)
+
+        def _pass_done(out):
+            if kept is not None:
+                kept.append(out.t)
+            if forced is None:
+                return out
+            given = Var(torch.empty_like(out.t))
+            ops.nchw_to_nhwc(forced[len(masks)].to(self.dev).contiguous().float(), given.t)
+            return given
         for i in range(T):
             xi = Var(self._new(Bsz, H, W, cpad))
             ops.nchw_to_nhwc(images[:, i].contiguous().float(), xi.t)
             out = self._unet_fwd(self.unet, xi)[0]
-            masks.append(out)
+            masks.append(_pass_done(out))
         F_ = pu.n_future_frames
         if F_ == 0:                                    # punet.py:91-96: segmentation of the current frame
             self._pred_masks = None
@@ -307,6 +320,8 @@ class PUNetEngine(ExpertGroupEngine):
                 self.tape.append(cat_bwd)
             e = self._entry_fwd(cat)
             m, inter = self._unet_fwd(self.pred_unet, e)
+            if not self.taping:
+                m = _pass_done(m)
             masks.append(m)
         x0 = None
         if not self.return_inter:                  # torch.stack(outs,1).view(B,-1,H,W)  (punet.py:120, moe.py:311)

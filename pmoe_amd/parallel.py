@@ -46,8 +46,57 @@ class BucketedAllReduce:
         if self.mode not in ("rs_ag", "ring"):
             raise ValueError(f"PMOE_DP_COLLECTIVE: 'rs_ag' or 'ring', got {self.mode!r}")
 
+    _decided = {}            # (id of the group, device type) -> mode agreed by all ranks at the first begin() of the process
+
+    def _decide_mode(self, device):
+        """Once per process and group: run the "rs_ag" bucket shape on a small known buffer, compare the RESULT with a plain
+        all_reduce of the same data, and agree on the verdict over all ranks (all_reduce(MIN) of the success flags) -- so
+        either every rank uses the in-place reduce-scatter + all-gather or every rank uses all_reduce, from the first real
+        bucket on.  An argument-check refusal of the aliased views (raised identically on every rank, before anything is
+        enqueued) counts as "no"; so does a wrong result."""
+        key = (id(self.group), device.type)
+        if key in BucketedAllReduce._decided:
+            self.mode = BucketedAllReduce._decided[key]
+            return
+        w = self.world
+        n = 256 * w
+        base = (torch.arange(n, device=device) % 97).float() + float(self.rank)
+        ref = base.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)
+        ref /= w
+        ok = 1
+        try:
+            probe = BucketedAllReduce(self.group, 1, mode="rs_ag")
+            probe.single = False
+            x = base.clone()
+            probe.arena, probe.cuts, probe.next, probe.sent, probe.works = x, [n], 0, 0, []
+            probe._launch(0, n)
+            for wk, scale_chunk in probe.works:
+                wk.wait()
+                if scale_chunk is not None:
+                    scale_chunk.mul_(1.0 / w)
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            ok = int(torch.allclose(x, ref, rtol=1e-6, atol=1e-6))
+        except (RuntimeError, ValueError) as err:
+            ok = 0
+            if not BucketedAllReduce._warned:
+                BucketedAllReduce._warned = True
+                print(f"pmoe_amd.parallel: in-place reduce-scatter refused ({err}); using all_reduce", flush=True)
+        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        self.mode = "rs_ag" if int(flag.item()) == 1 else "ring"
+        if self.mode == "ring" and ok == 1 and not BucketedAllReduce._warned:
+            BucketedAllReduce._warned = True
+            print("pmoe_amd.parallel: a peer rank rejected the in-place reduce-scatter; using all_reduce", flush=True)
+        BucketedAllReduce._decided[key] = self.mode
+        if self.mode == "ring":
+            BucketedAllReduce._forced_mode = "ring"
+
     def begin(self, arena, cuts=None):
         self.arena = arena
+        if not self.single and self.mode == "rs_ag":
+            self._decide_mode(arena.device)
         n = arena.numel()
         if cuts is None:
             b = (n + self.n_buckets - 1) // self.n_buckets
@@ -67,17 +116,11 @@ class BucketedAllReduce:
             per = n // w
             mine = chunk[self.rank * per:(self.rank + 1) * per]
             if self._nccl:
-                # in place: the output is the rank's own slice of the input (NCCL/RCCL's in-place reduce-scatter layout)
-                try:
-                    w1 = dist.reduce_scatter_tensor(mine, chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-                except (RuntimeError, ValueError) as err:
-                    # an argument check of this torch build refusing the aliased views (raised on every rank alike, before
-                    # anything is enqueued): keep the job alive on the ring path and say so once
-                    if not BucketedAllReduce._warned:
-                        BucketedAllReduce._warned = True
-                        print(f"pmoe_amd.parallel: in-place reduce-scatter refused ({err}); falling back to all_reduce", flush=True)
-                    self.mode = BucketedAllReduce._forced_mode = "ring"
-                    return self._launch(lo, hi)
+                # in place: the output is the rank's own slice of the input (NCCL/RCCL's in-place reduce-scatter layout).
+                # Whether this torch / RCCL build accepts AND correctly executes the aliased form was decided once, by all
+                # ranks together, in begin() (_decide_mode); an error here is a real failure and propagates (a per-rank
+                # fallback would leave the peers in a different collective sequence: a hang, not a recovery)
+                w1 = dist.reduce_scatter_tensor(mine, chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
                 w2 = dist.all_gather_into_tensor(chunk, mine, group=self.group, async_op=True)
                 self.works += [(w1, None), (w2, None)]
             else:
@@ -154,3 +197,15 @@ def sync_bn_buffers(model, group=None, mode="mean"):
     for b in bufs:
         b.copy_(flat[o:o + b.numel()].view_as(b))
         o += b.numel()
+
+
+def checkpoint_state_dict(model, group=None, mode="mean"):
+    """The data-parallel trainer's checkpoint hook: call this where the reference calls ``self.model.state_dict()`` for its
+    checkpoint (``trainer/train_2.py:350``) and before an evaluation pass (``train_2.py:248``, ``model.eval()`` reads the
+    running statistics).  Every rank must call it (it holds one collective).  BatchNorm running statistics are the only
+    state that differs between replicas -- each replica normalises with ITS shard's batch statistics, exactly like the
+    reference's plain ``nn.BatchNorm2d`` on one GPU -- so they are averaged over the ranks (``mode="mean"``: the estimate
+    over the global batch; ``"rank0"``: what DistributedDataParallel's buffer broadcast would keep) and then the
+    ``state_dict`` is the same on every rank; rank 0 writes it."""
+    sync_bn_buffers(model, group, mode)
+    return model.state_dict()

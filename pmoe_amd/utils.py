@@ -69,3 +69,36 @@ def stage2_model_cfg(model_type="moe", n_experts=4, dropout=0.3, n_commands=6, n
                    unet_inter_repr=False, model_name="unet", model_path=unet_path),
         pmoe=dict(moe_dir=moe_dir, punet_dir=punet_dir),
     ))
+
+
+def write_checkpoints(tmp, model_type, n_experts, future_frames, with_moe=False):
+    """The reference constructors READ checkpoint files (``punet.py:40`` the stage-0 U-Net, ``moe.py:278`` the PU-Net,
+    ``moe.py:335`` the frozen mixture): write random-init files with the right key sets into ``tmp`` and return the three
+    paths in ``stage2_model_cfg``'s keyword form.  Used wherever a ``punet`` / ``pmoe`` model is built without a trained
+    checkpoint at hand (bench.py's synthetic-weight configs, the tests -- which then overwrite every tensor)."""
+    import torch
+
+    from .model import blocks as B
+    from .model.moe import MixtureOfExperts
+    from .model.punet import PredictiveUnet
+    tmp.mkdir(parents=True, exist_ok=True)
+    unet_path, punet_path, moe_dir = tmp / "unet.pth", tmp / "punet.pth", tmp / "moe.pth"
+    torch.save({"unet": B.UNet().state_dict()}, unet_path)
+    cfg = stage2_model_cfg(model_type, n_experts, dropout=0.0, future_frames=future_frames, unet_path=str(unet_path))
+    pu = PredictiveUnet(**{**cfg.punet, "inter_repr": model_type == "punet_inter"})
+    torch.save({"model": pu.state_dict()}, punet_path)
+    if with_moe:
+        torch.save(MixtureOfExperts(stage2_model_cfg("pmoe", n_experts, dropout=0.0)).state_dict(), moe_dir)
+    return dict(unet_path=str(unet_path), punet_path=str(punet_path), moe_dir=str(moe_dir) if with_moe else "")
+
+
+def build_product(tmp, meta, dropout=0.0, exclude_freeze=()):
+    """``get_model`` for the checkpoint-reading types (``punet``, ``punet_inter``, ``pmoe*``) with random-init checkpoint
+    files written to ``tmp`` first; ``meta`` = dict(type, n_experts, future_frames)."""
+    from .model.moe import get_model
+    t = meta["type"]
+    ck = write_checkpoints(tmp, "punet" if t.startswith("pmoe") else t, meta["n_experts"], meta["future_frames"],
+                           with_moe=t.startswith("pmoe"))
+    cfg = stage2_model_cfg(t, meta["n_experts"], dropout=dropout, future_frames=meta["future_frames"],
+                           exclude_freeze=exclude_freeze, **ck)
+    return get_model(cfg)

@@ -313,3 +313,62 @@ def run_punet_teacher_forced_bf16(tmp, name, verbose=True):
     if verbose:
         print(name, "teacher-forced bf16", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in report.items()})
     return report
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the frozen-but-train-mode U-Net chain -- what config 4 spends 97 % of its time in -- pass
+# by pass.  Every one of the T + F U-Net passes of PredictiveUnet.forward (punet.py:88-91,111-117) runs on the FLOAT64
+# oracle's inputs for that pass (engine.debug_forced_masks replaces each pass's output by the oracle's before later passes
+# read it), so errors do not compound through the chain and a flat bound per pass is meaningful.
+PASS_TOL = {torch.float32: 1e-4, torch.bfloat16: 1e-2}
+
+
+def run_punet_per_pass(tmp, name, dtype=torch.float32, verbose=True):
+    """-> report; asserts per pass |mask - oracle64| <= PASS_TOL * (1 + |oracle64|) on every logit and, after the step, every
+    BatchNorm running statistic of the PU-Net within 1e-4 (f32) / 1e-2 (bf16) of the float64 oracle's (4 updates of `unet`,
+    F of `pred_unet` and `entry_block`, momentum order as punet.py:88-91)."""
+    g = torch.load(GOLDEN / f"{name}.pt", weights_only=False)
+    m = g["meta"]
+    assert m["train"] and m["type"] == "punet"
+    ocfg, oracle, model, inp = build_pair(tmp, g, dtype)
+    o64 = copy.deepcopy(oracle).double()
+    passes = []
+    hooks = [mod.register_forward_hook(lambda m_, i, o: passes.append(o.detach().clone()))
+             for mod in (o64.punet.unet, o64.punet.pred_unet)]
+    with torch.no_grad():
+        o64.punet(inp["images"].double())
+    for h in hooks:
+        h.remove()
+    T, F_ = 4, m["future_frames"]
+    assert len(passes) == T + F_
+    eng = model._engine()
+    eng.debug_forced_masks, eng.debug_pass_out = [p.float() for p in passes], []
+    dev = {k: v.to("cuda") for k, v in inp.items()}
+    with torch.no_grad():
+        model(dev["images"], dev["speed"], dev["command"])
+    got = eng.debug_pass_out
+    eng.debug_forced_masks = eng.debug_pass_out = None
+    assert len(got) == T + F_
+    tol = PASS_TOL[dtype]
+    report = {"per_pass": []}
+    for k, (t, ref) in enumerate(zip(got, passes)):
+        mk = t[..., :ref.shape[1]].permute(0, 3, 1, 2).double().cpu()
+        err = ((mk - ref).abs() / (1 + ref.abs())).max().item()
+        report["per_pass"].append(err)
+        assert err <= tol, f"{name} [{dtype}] U-Net pass {k} ({'unet' if k < T else 'pred_unet'}): {err:.3e} > {tol:g}"
+        assert t[..., ref.shape[1]:].abs().max().item() == 0.0          # the padded class channels stay zero
+    sd, sd64 = model.state_dict(), o64.state_dict()
+    worst = (0.0, "")
+    for k, v in sd64.items():
+        if not k.startswith("punet."):
+            continue
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k].item()) == int(v.item()), k
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            e = ((sd[k].double().cpu() - v).abs() / (1e-3 + v.abs())).max().item()
+            worst = max(worst, (e, k))
+    report["bn_running_worst"] = worst
+    assert worst[0] <= (1e-4 if dtype == torch.float32 else 1e-2), worst
+    if verbose:
+        print(name, "per-pass teacher-forced", dtype, ["%.2e" % e for e in report["per_pass"]], "BN buffers %.2e %s" % worst)
+    return report

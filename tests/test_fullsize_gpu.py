@@ -182,3 +182,51 @@ def test_punet_expert_full_size_properties(tmp_path):
     for k in g1:
         assert torch.isfinite(g1[k]).all(), k
         assert (g2[k] - 2 * g1[k]).norm() <= 2e-5 * g1[k].norm() + 1e-12, k
+
+
+def test_fp8_config_full_size_properties():
+    """BASELINE config 5 at full size (E=4, B=128, 256x256, `fp8_weights=True`: e4m3 weights + activations on the block-scaled
+    fp8 matrix instruction for the policy's convolutions, oracle/fp8_policy.py): bit-identical forward AND gradients on repeat,
+    exact x2 scaling of every gradient with the loss coefficients (the quantisers use power-of-two scales, so a factor of 2
+    commutes with every rounding on the path), and outputs within the EMULATED policy's own distance of the bf16 path's on
+    the same weights and batch -- the bound is the sum of the worst emulated fp8-policy error and the worst emulated bf16
+    error over the train-mode golden cases of tests/golden/bf16_bounds.pt (both are distances to float64)."""
+    from tests.parity_util import GOLDEN, emul_worst
+    Bc = 128
+    g = torch.Generator().manual_seed(4321)
+    images = torch.rand(Bc, 4, 3, S, S, generator=g).cuda()
+    speed, target = torch.rand(Bc, 1, generator=g).cuda(), torch.rand(Bc, 1, generator=g).cuda()
+    command = torch.nn.functional.one_hot(torch.randint(0, 6, (Bc,), generator=g), 6).float().cuda()
+    control = (torch.rand(Bc, 2, generator=g) * 2 - 1).cuda()
+    batch = (images, speed, command, control, target)
+    m8 = _model()
+    m8.fp8_weights = True
+    sd = copy.deepcopy(m8.state_dict())
+    o1, l1, g1 = _step(m8, batch, (0.7, 0.3))
+    assert any(c.w_f8 is not None for c in m8._engine().all_convs), "the fp8 policy selected no convolution"
+    m8.load_state_dict(sd)
+    o1b, l1b, g1b = _step(m8, batch, (0.7, 0.3))
+    m8.load_state_dict(sd)
+    o2, l2, g2 = _step(m8, batch, (1.4, 0.6))
+    for a, b, c in zip(o1, o1b, o2):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(l1, l1b) and abs(l2.item() - 2 * l1.item()) <= 1e-6 * abs(l1.item())
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g1[k], g1b[k]), k
+        assert torch.equal(g2[k], 2 * g1[k]), k
+    del m8, g1b, g2
+    mb = _model()
+    mb.load_state_dict(sd)
+    ob, lb, gb = _step(mb, batch, (0.7, 0.3))
+    bounds = torch.load(GOLDEN / "bf16_bounds.pt", weights_only=False)["forward"]
+    cases = [c for c, r in bounds.items() if "emul_fp8" in r and "eval" not in c]
+    assert cases
+    for name, a, b in zip(("probs", "mean", "std", "speeds"), o1, ob):
+        lim = max(emul_worst(bounds[c]["emul_fp8"], name) for c in cases) + max(emul_worst(bounds[c]["emul"], name) for c in cases)
+        err = (a - b).abs() / (1 + b.abs())
+        print(f"C5 full size: fp8 vs bf16 {name}: max {err.max().item():.2e} median {err.median().item():.2e} (bound {lim:.2e})")
+        assert err.max().item() <= lim and err.median().item() <= lim / 4, (name, err.max().item(), err.median().item(), lim)
+    cos = sorted(torch.nn.functional.cosine_similarity(g1[k].flatten(), gb[k].flatten(), dim=0).item()
+                 for k in gb if gb[k].numel() >= 1024)
+    assert cos[len(cos) // 2] >= 0.8, cos[len(cos) // 2]           # straight-through gradients still point the bf16 path's way

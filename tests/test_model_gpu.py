@@ -23,9 +23,18 @@ def test_train_parity_f32(name):
     assert r["grad_worst"][0] <= 1e-3, r
 
 
-@pytest.mark.parametrize("name", ["g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g1_moe_e4_b2_128", "g6_moeshared_k4_b6_96"])
+@pytest.mark.parametrize("name", ["g4_moealt_e4_b2_64", "g5_moe_e3_b3_96", "g1_moe_e4_b2_128", "g6_moeshared_k4_b6_96",
+                                  "g11_moe_e4_b8_128"])
 def test_train_parity_bf16(name):
-    run_parity_case(name, torch.bfloat16, check_grads=True)
+    """bf16 path end to end: every output within max(1e-2, 1.25 x the bf16-storage-emulating oracle's worst of 14 draws) of
+    the float64 oracle (tests/golden/bf16_bounds.pt), the measured error printed beside north_star's flat 1e-2 and the
+    emulation's.  g11 (batch of 8, 128x128: every BatchNorm statistic over >= 128 values) is the best conditioned case, and
+    even there the EMULATION is 2.1e-2 off on `mean` (5.5e-3 / 1.1e-2 / 1.4e-2 on probs / std / speeds): the flat 1e-2 is
+    met by the outputs whose emulated error is below it, not by all four."""
+    r = run_parity_case(name, torch.bfloat16, check_grads=True)
+    flat = {k[:-4]: ("%.1e" % v[0], "meets 1e-2" if v[0] <= 1e-2 else "beyond 1e-2 (emulation: %.1e)" % v[1])
+            for k, v in r.items() if k.endswith("_abs")}
+    print(name, "bf16 vs float64, flat 1e-2:", flat)
 
 
 def test_train_parity_bf16_realistic_batch():
@@ -499,3 +508,34 @@ def test_ragged_shapes_f32_against_live_oracle(shape):
     errs = sorted(((p.grad.cpu() - on[k].grad).norm() / (on[k].grad.norm() + 1e-12)).item()
                   for k, p in model.named_parameters() if on[k].grad.norm() > 1e-7)
     assert errs[len(errs) // 2] <= 2e-3, errs[len(errs) // 2]      # median; single tensors can carry a ReLU-mask flip
+
+
+def test_bn_relu_with_two_consumers_fails_loudly():
+    """the PMOE_RES_DBN data gradient (engine._dgrad_with_bn_reduce) masks and reduces the gradient of
+    a = relu(BatchNorm(z)) inside the data gradient of a's consumer, assuming that consumer is the only one.  No shipped graph
+    fans such an activation out; one that did must raise instead of returning silently wrong dgamma / dbeta / dz."""
+    from pmoe_amd.engine import Var
+    from pmoe_amd.model.moe import get_model
+    from pmoe_amd.utils import stage2_model_cfg
+    m = get_model(stage2_model_cfg("moe", 2, dropout=0.0)).cuda()
+    m.compute_dtype = torch.bfloat16
+    m.train()
+    eng = m._engine()
+    eng._begin(torch.rand(4, 4, 3, 64, 64, device="cuda"), True, True, torch.bfloat16, 0)
+    eng._layout_arena()
+    eng._arena = torch.zeros(eng._arena_numel, device="cuda")
+    eng._filled, eng._cursor = set(), 0
+    x = Var(torch.randn(eng.N, 64, 64, 64, device="cuda").to(torch.bfloat16))
+    x.needs_grad = True
+    b0, b1 = eng.blocks[0], eng.blocks[1]
+    a = eng._conv_bn(x, b0["conv1"], b0["bn1"], relu=True)
+    assert a.bn_src is not None
+    y1 = eng._conv(a, b0["conv2"], bias=False)
+    y2 = eng._conv(a, b1["conv1"], bias=False)            # second consumer of the same BatchNorm+ReLU output
+    for y in (y1, y2):
+        y.set_grad(torch.randn_like(y.t))
+    tape = list(reversed(eng.tape))
+    tape[0]()                                             # y2's backward: takes the fused path and leaves the reductions
+    assert a.bn_part is not None, "this shape no longer takes the PMOE_RES_DBN data gradient: pick one that does"
+    with pytest.raises(RuntimeError, match="exactly one consumer"):
+        tape[1]()

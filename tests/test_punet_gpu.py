@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from tests.punet_parity import (GOLDEN, build_pair, run_pmoe_case, run_punet_case, run_punet_forced,  # noqa: E402
-                                 run_punet_teacher_forced_bf16)
+                                 run_punet_per_pass, run_punet_teacher_forced_bf16)
 
 
 def test_punet_eval_parity_f32(tmp_path):
@@ -27,7 +27,15 @@ def test_punet_inter_train_parity_f32(tmp_path):
     assert r["golden_slices_worst"] <= 5e-3 and r["bn_running_worst"] <= 1e-4, r
 
 
-@pytest.mark.parametrize("name", ["p4_punet_b3_96_f3"])          # (p1, the smaller sibling, runs in bf16 below)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_punet_train_chain_per_pass_teacher_forced(tmp_path, dtype):
+    """each of the T + F train-mode U-Net passes of the frozen PU-Net on the float64 oracle's inputs for
+    that pass (batch-of-8 golden p6): masks within 1e-4 (f32) / 1e-2 (bf16) x (1 + |ref|) on every logit, BatchNorm running
+    buffers after the step within 1e-4 / 1e-2 -- the tight test of the kernels config 4 spends 97 % of its time in."""
+    run_punet_per_pass(tmp_path, "p6_punet_b8_96_f2", dtype)
+
+
+@pytest.mark.parametrize("name", ["p4_punet_b3_96_f3", "p6_punet_b8_96_f2"])          # (p1, the smaller sibling, runs in bf16 below)
 def test_punet_train_parity_f32(tmp_path, name):
     """PUNetExpert with the 138/69-channel ResNet stem in train mode: forward within 5x the f32 oracle's own drift from
     float64, the typical gradient tensor within 4x that drift, directions and total norm preserved, frozen PU-Net
@@ -46,6 +54,9 @@ def test_punet_train_bf16(tmp_path):
     r = run_punet_case(tmp_path, "p3_punetinter_b2_64_f2", torch.bfloat16)
     assert r["grad_median_cos"] >= 0.9 and r["grad_total_rel"] <= 0.2, r
     run_punet_case(tmp_path, "p1_punet_b2_64_f2", torch.bfloat16)
+    # batch of 8 (round 3's p6): the chain is still chaotic end to end in bf16 (emulation's worst draw 0.37 on the actions);
+    # what pins the bf16 U-Net kernels is test_punet_train_chain_per_pass_teacher_forced, the trainable half the test below
+    run_punet_case(tmp_path, "p6_punet_b8_96_f2", torch.bfloat16)
 
 
 @pytest.mark.parametrize("name", ["p1_punet_b2_64_f2", "p4_punet_b3_96_f3", "p6_punet_b8_96_f2"])

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 from pmoe_amd import ops  # noqa: E402
 from pmoe_amd.loss import punet_loss  # noqa: E402
-from tests.punet_util import build_product  # noqa: E402
+from pmoe_amd.utils import build_product  # noqa: E402
 
 
 def main():
