@@ -440,6 +440,8 @@ def main():
                 return "conv_wgrad_dma_kernel<1, 2, false, *>", "void conv_wgrad_dma_kernel<1, 2, false", 1   # (last parameter: request code, PMOE_WGRAD_REQ)
             if code == 7109:                      # ... its 2 x 4 wave layout for <= 32 input channels (the stem's first convolution)
                 return "conv_wgrad_dma_kernel<1, 1, *> (<= 32 input channels)", "void conv_wgrad_dma_kernel<1, 1", 1
+            if code == 7209:                      # ... with the stem's first BatchNorm backward applied on load (round 4)
+                return "conv_wgrad_bnbwd_kernel", "conv_wgrad_bnbwd_kernel", 1
             if 6000 <= code < 7000:               # conv_wgrad_kernel<T, taps, MAXV>
                 taps, maxv = (code - 6000) // 100, (code - 6000) % 100
                 return (f"conv_wgrad_kernel<{kdt},{taps},{maxv}>", f"_Z17conv_wgrad_kernelI{tname}Li{taps}ELi{maxv}EEv9WgradArgs", 1)

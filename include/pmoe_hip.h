@@ -51,9 +51,9 @@ extern "C" {
 
 /* ABI revision of this header: bumped whenever a descriptor struct, an argument list or a buffer contract changes
  * (100: round 1; 200: round 2 -- pmoe_conv_desc 160 -> 176 bytes, pmoe_wgrad_desc.part_ws, pmoe_bn_bwd_reduce's gmask_out,
- * dw_ws overwritten instead of accumulated; 300: round 3).  A binding compares pmoe_version() with the value it was
+ * dw_ws overwritten instead of accumulated; 300: round 3; 400: round 4 -- pmoe_wgrad_desc.bn_*).  A binding compares pmoe_version() with the value it was
  * written against before its first launch (pmoe_amd/hip.py:load does). */
-#define PMOE_ABI_VERSION 300
+#define PMOE_ABI_VERSION 400
 int pmoe_version(void);
 const char* pmoe_error_string(int code);
 /* sizeof() of the descriptor structs as compiled (which: 0 = pmoe_conv_desc, 1 = pmoe_wgrad_desc);
@@ -144,6 +144,20 @@ typedef struct pmoe_wgrad_desc {
     int32_t cout_real, cin_real;
     int32_t defer_fold;   /* 1: pmoe_conv2d_wgrad runs the MFMA launch only; the caller runs pmoe_conv2d_wgrad_fold(d) afterwards
                            * (so that a profiler / per-launch events see the two kernels apart) */
+    /* round 4: BatchNorm backward applied ON LOAD (the stem's conv1 -> BatchNorm2d -> ReLU, model/blocks/basics.py:113-120,
+     * whose output gradient has this filter gradient as its only consumer).  bn_fused = 1: `dy` holds g, the ReLU-masked
+     * gradient w.r.t. the BatchNorm OUTPUT (what PMOE_RES_DBN leaves), `bn_z` the BatchNorm's input (the conv's own output,
+     * geometry of dy with row length bn_z_ld), `bn_coef` [4][n/ipe][cout] f32 = mean, invstd, gamma*invstd, beta and
+     * `bn_c1` / `bn_c2` [n/ipe][cout] the two means pmoe_bn_bwd_finalize leaves; the kernel evaluates
+     * dz = g*A + ((z - mean)*Bx + K) exactly like pmoe_bn_bwd_apply (same arithmetic, same bf16 rounding) between its
+     * loads and its LDS tile, so the gradient tensor dz is never written or read.  bf16, per_image, 3x3 stride 1 pad 1,
+     * cin <= 16, cout <= 64 (plan code 7209); anything else: PMOE_ERR_UNSUPPORTED. */
+    int32_t bn_fused;
+    const void* bn_z;
+    const float* bn_coef;
+    const float* bn_c1;
+    const float* bn_c2;
+    int32_t bn_z_ld;
 } pmoe_wgrad_desc;
 int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream);
 /* the tail of pmoe_conv2d_wgrad for the same descriptor: K-split slabs -> dw_ws, or -> `grads` when set */
@@ -152,7 +166,8 @@ int pmoe_conv2d_wgrad_fold(const pmoe_wgrad_desc* d, void* stream);
  * descriptor are not read. */
 int64_t pmoe_conv2d_wgrad_ws_floats(const pmoe_wgrad_desc* d);
 /* which kernel serves the descriptor (nothing is launched; bench.py attributes launch times to rocprof symbols with it):
- *   7009 = conv_wgrad_dma_kernel (LDS-DMA staged, dense 3x3 stride 1, bf16; 7109 = its wave layout for <= 32 input channels);  6000 + taps * 100 + MAXV = conv_wgrad_kernel<T, taps, MAXV> */
+ *   7009 = conv_wgrad_dma_kernel (LDS-DMA staged, dense 3x3 stride 1, bf16; 7109 = its wave layout for <= 32 input channels);  6000 + taps * 100 + MAXV = conv_wgrad_kernel<T, taps, MAXV>;
+ *   7209 = conv_wgrad_bnbwd_kernel (bn_fused) */
 int pmoe_conv2d_wgrad_plan(const pmoe_wgrad_desc* d);
 
 /* Master weights live in the reference's own layout (one f32 OIHW / [out][in] tensor per expert,

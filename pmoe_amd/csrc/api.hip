@@ -108,6 +108,8 @@ int pmoe_conv2d_wgrad(const pmoe_wgrad_desc* d, void* stream) {
     const int rc = to_wgrad_args(d, a);
     if (rc) return rc;
     if (!d->x || !d->dy || !d->dw_ws) return PMOE_ERR_ARG;
+    if (d->bn_fused)
+        return conv_wgrad_bnbwd_launch(a, d->bn_z, d->bn_z_ld, d->bn_coef, d->bn_c1, d->bn_c2, d->dtype, (hipStream_t)stream, false);
     return conv_wgrad_launch(a, d->dtype, (hipStream_t)stream);
 }
 
@@ -123,6 +125,10 @@ int pmoe_conv2d_wgrad_plan(const pmoe_wgrad_desc* d) {
     WgradArgs a;
     const int rc = to_wgrad_args(d, a);
     if (rc) return rc;
+    if (d->bn_fused) {
+        const int r2 = conv_wgrad_bnbwd_launch(a, nullptr, d->bn_z_ld, nullptr, nullptr, nullptr, d->dtype, nullptr, true);
+        return r2 ? r2 : 7209;
+    }
     return conv_wgrad_plan(a, d->dtype);
 }
 
@@ -130,6 +136,7 @@ int64_t pmoe_conv2d_wgrad_ws_floats(const pmoe_wgrad_desc* d) {
     WgradArgs a;
     const int rc = to_wgrad_args(d, a);
     if (rc) return rc;
+    if (d->bn_fused) return 0;                            // per image: no K-split scratch
     return conv_wgrad_ws_floats(a, d->dtype);
 }
 

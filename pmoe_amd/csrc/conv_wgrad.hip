@@ -597,6 +597,220 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the stem's first BatchNorm backward WITHOUT its apply pass.  conv1 (12 -> 16 input channels, 64 outputs, full
+// resolution) is followed by BatchNorm + ReLU (blocks/basics.py:113-120); the gradient dz1 of its output feeds exactly one
+// consumer -- this per-image filter gradient (the ECA-folded stem needs no data gradient into the frames) -- so the 2.15 GB
+// tensor never has to exist: the kernel takes g (the ReLU-masked gradient w.r.t. the BatchNorm output, left by conv2's
+// PMOE_RES_DBN data gradient) and z (conv1's output), and evaluates
+//     dz = g * A + ((z - mean) * Bx + K),   A = gamma*invstd,  Bx = -A * invstd * c2,  K = -A * c1     (bn_bwd_apply_kernel)
+// in registers between the global loads and the LDS store of the dY tile -- same arithmetic, same bf16 rounding as the
+// stand-alone pass, so the operand the MFMAs see is bit-identical to the tensor that pass would have written.  HBM: reads
+// g + z + the shared frames (4.4 GB at the headline shape) instead of read g, z + write dz (6.4 GB) and read dz again (2.2 GB).
+// Structure: the register-staged kernel above (issue early / write late, two barriers per m-block) in the narrow PAIRS
+// layout of conv_wgrad_dma_kernel<1, 1, true>: 8 waves = 2 (cout halves) x 4 (pixel quarters), two taps x 16 channels per
+// MFMA column block (5 MFMAs per k-block), X patch rows of 32 bytes (16 channels: nothing else is staged).
+struct BnBwdFuse {
+    const void* z;         // [N][H][W][z_ld] bf16: the BatchNorm's input (conv1's output), geometry of dy
+    const float* coef;     // [4][E][C]: mean, invstd, gamma*invstd, beta (engine._bn_coeffs)
+    const float* c1;       // [E][C]: mean of g over the expert's rows       (pmoe_bn_bwd_finalize)
+    const float* c2;       // [E][C]: mean of g * xhat
+    int z_ld, C;
+};
+
+__global__ void __launch_bounds__(512) conv_wgrad_bnbwd_kernel(const WgradArgs a, const BnBwdFuse f) {
+    constexpr int TAPS = 9, RS = 192, XRS = 32, WK = 4, TILE_WAVES = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int co_sub = wave & 1, k_sub = wave >> 1;
+    const int e = blockIdx.z, img = blockIdx.x;                       // one workgroup walks exactly one image
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int PW = TW + 2, PH = TH + 2, NPIX = PH * PW;
+    constexpr int BMP = 256;
+    char* dyt = smem;                                                 // [256][192 B]
+    char* patch = smem + BMP * RS;                                    // [NPIX][32 B]
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+
+    const size_t n_out = (size_t)e * a.ipe + img;
+    const bf16* dy = (const bf16*)a.dy + n_out * a.Ho * a.Wo * a.dy_ld + a.dy_coff;
+    const bf16* zz = (const bf16*)f.z + n_out * a.Ho * a.Wo * f.z_ld;
+    const bf16* x = (const bf16*)a.x + (a.x_shared ? (size_t)img : n_out) * a.H * a.W * a.x_ld + a.x_coff;
+
+    // per-thread constants: its 8 channels of the dY tile (chunk dyj of every pixel row it stages)
+    const int dyj = tid & 7;
+    float A[8], Bx[8], K[8], mu[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = dyj * 8 + k;
+        const bool ok = c < f.C;
+        const size_t ec = (size_t)e * f.C + (ok ? c : 0);
+        const size_t EC = (size_t)gridDim.z * f.C;
+        const float sc = ok ? f.coef[2 * EC + ec] : 0.f, is = ok ? f.coef[EC + ec] : 0.f;
+        mu[k] = ok ? f.coef[ec] : 0.f;
+        A[k] = sc;
+        Bx[k] = ok ? -sc * is * f.c2[ec] : 0.f;
+        K[k] = ok ? -sc * f.c1[ec] : 0.f;
+    }
+    const bool dy_cok = dyj * 8 < a.Cout;
+    // X patch items of this thread: (pixel, 16-byte half of its 32-byte row); the decode is tile-invariant
+    int xiy[2], xix[2], xoff[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = tid + u * 512, pp = it >> 1;
+        xiy[u] = pp < NPIX ? pp / PW : -100000;
+        xix[u] = pp - (pp / PW) * PW;
+        xoff[u] = pp * XRS + (it & 1) * 16;
+    }
+    const bool x_cok[2] = {0 < a.Cin, 8 < a.Cin};
+
+    v4i dyv[4], zv[4], xv[2];
+    auto issue = [&](int mbi) {
+        const int px = mbi % a.tiles_x, py = mbi / a.tiles_x;
+        const int oy0 = py * TH, ox0 = px * TW;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = (tid >> 3) + u * 64;
+            const int mx = p & (TW - 1), my = p >> lTW;
+            const int oy = oy0 + my, ox = ox0 + mx;
+            dyv[u] = zv[u] = v4i{0, 0, 0, 0};
+            if (dy_cok && oy < a.Ho && ox < a.Wo) {
+                const size_t pix = (size_t)oy * a.Wo + ox;
+                dyv[u] = ldg16(dy + pix * a.dy_ld + dyj * 8);
+                zv[u] = ldg16(zz + pix * f.z_ld + dyj * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int Y = oy0 - a.pad + xiy[u], X = ox0 - a.pad + xix[u];
+            xv[u] = v4i{0, 0, 0, 0};
+            if (x_cok[(tid + u * 512) & 1] && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W)
+                xv[u] = ldg16(x + ((size_t)Y * a.W + X) * a.x_ld + ((tid + u * 512) & 1) * 8);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = (tid >> 3) + u * 64;
+            float gv[8], xz[8], o[8];
+            unpack16<bf16>(dyv[u], gv);
+            unpack16<bf16>(zv[u], xz);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = gv[k] * A[k] + ((xz[k] - mu[k]) * Bx[k] + K[k]);
+            *reinterpret_cast<v4i*>(dyt + p * RS + (dyj << 4)) = pack16<bf16>(o);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (xiy[u] >= 0) *reinterpret_cast<v4i*>(patch + xoff[u]) = xv[u];
+    };
+
+    // lane-constant parts of the transposed-fragment addresses (conv_wgrad_kernel / the PAIRS layout of conv_wgrad_dma_kernel)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+    const int ca = (co_sub * 32 + 16 * (g & 1) + 4 * pc) * 2;
+    int pairoff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int tl = 2 * i + (g & 1) > 8 ? 8 : 2 * i + (g & 1);
+        pairoff[i] = ((tl / 3) * PW + (tl % 3)) * XRS + 8 * pc;
+    }
+
+    const int nmb = a.tiles_y * a.tiles_x;
+    issue(0);
+    for (int mbi = 0; mbi < nmb; ++mbi) {
+        __syncthreads();                                // the previous m-block's fragment reads are done
+        commit();
+        __syncthreads();
+        if (mbi + 1 < nmb) issue(mbi + 1);              // in flight under this m-block's MFMAs
+#pragma unroll
+        for (int kb = k_sub; kb < (BMP >> 4); kb += WK) {
+            const int p0 = kb << 4;
+            bf16x8 fa;
+            const char* bB[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int p = p0 + 8 * (g >> 1) + 4 * tt + q;
+                const int mx = p & (TW - 1), my = p >> lTW;
+                bB[tt] = patch + (my * PW + mx) * XRS;
+                const bf16x4 rb = __builtin_bit_cast(bf16x4, tr_read(dyt + p * RS + ca));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[4 * tt + i] = rb[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                bf16x8 fb;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const bf16x4 rb = __builtin_bit_cast(bf16x4, tr_read(bB[tt] + pairoff[i]));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[4 * tt + j] = rb[j];
+                }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+            }
+        }
+    }
+
+    // flush: accumulator i, column c = tap 2i + (c >> 4), input channel c & 15; fixed-order fold of the 4 pixel quarters through
+    // LDS, one pair per round; the 48 columns past the 16 channels are written as zeros (dw is [N][9][CoutP][CinP], overwritten)
+    float* red = reinterpret_cast<float*>(smem);
+    const size_t slab = n_out;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        __syncthreads();
+        if (k_sub > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((k_sub - 1) * TILE_WAVES + co_sub) * 16 + r) * 64 + lane] = acc[i][r];
+        }
+        __syncthreads();
+        const int tap = 2 * i + (l31 >> 4);
+        if (k_sub == 0 && tap < TAPS) {
+            float* base = a.dw + ((slab * TAPS + tap) * a.CoutP) * a.CinP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][r];
+#pragma unroll
+                for (int k = 1; k < WK; ++k) v += red[(((k - 1) * TILE_WAVES + co_sub) * 16 + r) * 64 + lane];
+                const int cout = co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float* row = base + (size_t)cout * a.CinP + (l31 & 15);
+                row[0] = v;
+                for (int z = 16; (l31 & 15) + z < a.CinP; z += 16) row[z] = 0.f;
+            }
+        }
+    }
+}
+
+// per-image filter gradient of a <= 16-input-channel 3x3 stride-1 convolution whose output gradient is given as (g, z) of the
+// BatchNorm + ReLU behind it (see the kernel).  plan == true: 0 if the descriptor fits the kernel, else an error code.
+int conv_wgrad_bnbwd_launch(WgradArgs a, const void* z, int z_ld, const float* coef, const float* c1, const float* c2,
+                            int dtype, hipStream_t st, bool plan) {
+    if (dtype != PMOE_DT_BF16 || !a.per_image || a.ks != 3 || a.stride != 1 || a.pad != 1) return PMOE_ERR_UNSUPPORTED;
+    if (a.Cin > 16 || a.Cin % 8 || a.Cout > 64 || a.Cout % 8 || a.CoutP != 64 || a.CinP != 64) return PMOE_ERR_UNSUPPORTED;
+    if (a.Ho != a.H || a.Wo != a.W || a.N % a.ipe || (long long)a.H * a.W < 256) return PMOE_ERR_UNSUPPORTED;
+    if (z_ld % 8 || z_ld < a.Cout || a.x_ld % 8 || a.dy_ld % 8) return PMOE_ERR_ARG;
+    auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    int lTW = p2(a.W); if (lTW > 5) lTW = 5;
+    const int lTH = 8 - lTW;
+    a.lTW = lTW; a.lTH = lTH; a.TN = 1; a.n_groups = a.ipe;
+    a.tiles_y = (a.H + (1 << lTH) - 1) >> lTH;
+    a.tiles_x = (a.W + (1 << lTW) - 1) >> lTW;
+    const int NPIX = ((1 << lTW) + 2) * ((1 << lTH) + 2);
+    if (NPIX * 2 > 1024) return PMOE_ERR_UNSUPPORTED;                 // two 16-byte patch items per thread
+    if (plan) return 0;
+    if (!z || !coef || !c1 || !c2 || !a.x || !a.dy || !a.dw) return PMOE_ERR_ARG;
+    size_t smem = (size_t)256 * 192 + (size_t)NPIX * 32;
+    if (smem < (size_t)3 * 2 * 4096) smem = (size_t)3 * 2 * 4096;     // fold room: (WK - 1) x 2 tile waves x 4 KiB
+    HIP_RET((ensure_dyn_lds<conv_wgrad_bnbwd_kernel>(160 * 1024)));
+    BnBwdFuse f{z, coef, c1, c2, z_ld, a.Cout};
+    hipLaunchKernelGGL(conv_wgrad_bnbwd_kernel, dim3(a.ipe, 1, a.N / a.ipe), dim3(512), smem, st, a, f);
+    return (int)hipGetLastError();
+}
+
 // dw[i] = sum over the K-split slabs, fixed order (slab s at part + s * total)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            const int nsplit, const long long total4) {

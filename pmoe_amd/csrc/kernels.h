@@ -82,3 +82,6 @@ int conv_wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);
 int conv_wgrad_fold(const WgradArgs& a, int dtype, hipStream_t st);
 long long conv_wgrad_ws_floats(const WgradArgs& a, int dtype);
 int conv_wgrad_plan(const WgradArgs& a, int dtype);
+// per-image filter gradient with the BatchNorm backward applied on load (conv_wgrad.hip, round 4)
+int conv_wgrad_bnbwd_launch(WgradArgs a, const void* z, int z_ld, const float* coef, const float* c1, const float* c2,
+                            int dtype, hipStream_t st, bool plan);

@@ -15,7 +15,7 @@ import torch
 _LIB_PATH = Path(os.environ.get("PMOE_HIP_LIB") or Path(__file__).resolve().parent / "libpmoe_hip.so")
 _lib = None
 
-ABI_VERSION = 300            # include/pmoe_hip.h: PMOE_ABI_VERSION
+ABI_VERSION = 400            # include/pmoe_hip.h: PMOE_ABI_VERSION
 DT_BF16, DT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_DRELU, RES_DELU, RES_DTANH, RES_DSIGMOID, RES_DBN = 0, 1, 2, 3, 4, 5, 6
@@ -58,6 +58,8 @@ class WgradDesc(C.Structure):
         ("per_image", C.c_int32),
         ("part_ws", C.c_void_p), ("part_ws_floats", C.c_int64),
         ("grads", C.c_void_p), ("cout_real", C.c_int32), ("cin_real", C.c_int32), ("defer_fold", C.c_int32),
+        ("bn_fused", C.c_int32), ("bn_z", C.c_void_p), ("bn_coef", C.c_void_p), ("bn_c1", C.c_void_p), ("bn_c2", C.c_void_p),
+        ("bn_z_ld", C.c_int32),
     ]
 
 

@@ -117,7 +117,7 @@ def _wgrad_part_ws(device, floats):
 
 
 def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, x_shared=False, x_coff=0, dy_coff=0,
-                 per_image=False, plan_only=False, grads=None, grads_cout=0, grads_cin=0, defer_fold=False):
+                 per_image=False, plan_only=False, grads=None, grads_cout=0, grads_cin=0, defer_fold=False, bn_fuse=None):
     """dw_ws [E | N][ks*ks][coutp][cinp] f32 is OVERWRITTEN with the weight gradient (deterministic: fixed-order folds
     of the pixel split, no atomics; csrc/conv_wgrad.hip).  ``grads`` (flat f32, E * grads_cout * grads_cin * ks * ks): the
     parameters' own gradient layout, written by the fold instead of dw_ws (which then is scratch only).  ``defer_fold``: run the
@@ -125,7 +125,21 @@ def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, 
     nin, h, w_, ldx = _nhwc(x, "x")
     n, ho, wo, ldy = _nhwc(dy, "dy")
     d = WgradDesc()
-    d.x, d.dy, d.dw_ws = ptr(x, "x"), ptr(dy, "dy", x.dtype), ptr(dw_ws, "dw_ws", torch.float32)
+    d.x, d.dy = ptr(x, "x"), ptr(dy, "dy", x.dtype)
+    d.dw_ws = ptr(dw_ws, "dw_ws", torch.float32) if dw_ws is not None else None
+    if bn_fuse is not None:
+        # ``dy`` is g, the masked gradient w.r.t. the output of the BatchNorm + ReLU behind this conv; bn_fuse = (z, coef
+        # [4,E,C], c1 [E,C], c2 [E,C]): the kernel applies that BatchNorm's backward on load (include/pmoe_hip.h, bn_fused)
+        z, coef, c1, c2 = bn_fuse
+        if z.shape[:3] != dy.shape[:3]:
+            raise ValueError("conv2d_wgrad: bn_fuse z must have the geometry of dy")
+        d.bn_fused, d.bn_z_ld = 1, z.shape[-1]
+        if not plan_only:
+            E_ = n // ipe
+            if coef.shape != (4, E_, cout) or c1.shape != (E_, cout) or c2.shape != (E_, cout):
+                raise ValueError("conv2d_wgrad: bn_fuse coefficient blocks must be [4,E,cout] / [E,cout]")
+            d.bn_z, d.bn_coef = ptr(z, "bn_z", x.dtype), ptr(coef, "bn_coef", torch.float32)
+            d.bn_c1, d.bn_c2 = ptr(c1, "bn_c1", torch.float32), ptr(c2, "bn_c2", torch.float32)
     d.n, d.h, d.w_, d.cin, d.cinp = n, h, w_, cin, cinp
     d.ho, d.wo, d.cout, d.coutp = ho, wo, cout, coutp
     d.x_ld, d.x_coff, d.dy_ld, d.dy_coff = ldx, x_coff, ldy, dy_coff
@@ -136,6 +150,8 @@ def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, 
         if per_image or grads.dtype != torch.float32 or grads.numel() != (n // ipe) * grads_cout * grads_cin * ks * ks:
             raise ValueError("conv2d_wgrad: grads must hold E * cout * cin * ks * ks float32 values (not with per_image)")
         d.grads, d.cout_real, d.cin_real = ptr(grads, "grads", torch.float32), int(grads_cout), int(grads_cin)
+    if bn_fuse is not None and plan_only:       # -> 7209 if the fused kernel serves this shape, else a negative error code
+        return load().pmoe_conv2d_wgrad_plan(C.byref(d))
     if dw_ws.numel() < (n if per_image else n // ipe) * ks * ks * coutp * cinp:
         raise ValueError("conv2d_wgrad: workspace too small")
     need = load().pmoe_conv2d_wgrad_ws_floats(C.byref(d))

@@ -1105,3 +1105,51 @@ def test_conv1x1_direct_kernel(case):
     yo = out.float().cpu()[..., :cout].reshape(E, -1, cout)
     close(st[:, 0, :cout], yo.sum(1), dtype, "1x1 direct stats sum")
     close(st[:, 1, :cout], (yo * yo).sum(1), dtype, "1x1 direct stats sumsq")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the stem's first BatchNorm backward applied ON LOAD by conv1's per-image filter gradient (conv_wgrad_bnbwd_kernel,
+# include/pmoe_hip.h pmoe_wgrad_desc.bn_fused): dz = g*A + ((z - mean)*Bx + K) is evaluated between the global loads and the LDS
+# tile, the gradient tensor dz is never written.
+@pytest.mark.parametrize("E,ipb,H,W", [(2, 2, 64, 64), (1, 3, 40, 72), (2, 1, 256, 256)])
+def test_wgrad_with_batchnorm_backward_on_load(E, ipb, H, W):
+    """against (a) pmoe_bn_bwd_apply followed by the plain per-image filter gradient -- the operand the MFMAs see is the same
+    bf16 tensor, so only the f32 summation order differs -- and (b) the CPU f32 statement of both steps."""
+    g = torch.Generator().manual_seed(E * 100 + H + W)
+    BF = torch.bfloat16
+    N, C, CI = E * ipb, 64, 16
+    x = torch.rand((ipb, 12, H, W), generator=g).to(BF).float()                    # the frames, shared by the experts
+    gy = rnd((N, C, H, W), g, BF)
+    gy = torch.where(torch.rand(gy.shape, generator=g) < 0.5, gy, torch.zeros(()))     # ReLU-masked, like PMOE_RES_DBN leaves it
+    z = rnd((N, C, H, W), g, BF, 2.0) + 0.3
+    coef = torch.empty(4, E, C)
+    coef[0] = torch.randn(E, C, generator=g) * 0.5 + 0.3
+    coef[1] = torch.rand(E, C, generator=g) + 0.5
+    coef[2] = coef[1] * (torch.randn(E, C, generator=g) * 0.5 + 1.0)
+    coef[3] = torch.randn(E, C, generator=g) * 0.3
+    c1, c2 = torch.randn(E, C, generator=g) * 0.1, torch.randn(E, C, generator=g) * 0.1
+    xd, gd, zd = nhwc(x, CI, BF), nhwc(gy, C, BF), nhwc(z, C, BF)
+    coefd, c1d, c2d = coef.to(DEV), c1.to(DEV), c2.to(DEV)
+    kw = dict(cin=CI, cout=C, cinp=64, coutp=64, ipe=ipb, ks=3, stride=1, pad=1, x_shared=True, per_image=True)
+    assert ops.conv2d_wgrad(xd, gd, None, bn_fuse=(zd, None, None, None), plan_only=True, **kw) == 7209
+    G = torch.full((N, 9, 64, 64), 7.0, device=DEV)
+    ops.conv2d_wgrad(xd, gd, G, bn_fuse=(zd, coefd, c1d, c2d), **kw)
+    # (a) the unfused pair
+    dz = torch.empty_like(gd)
+    ops.bn_bwd_apply(gd, None, zd, coefd[0], coefd[1], coefd[2], coefd[3], c1d, c2d, dz, None, ipb * H * W, E, C, False)
+    G2 = torch.full((N, 9, 64, 64), 3.0, device=DEV)
+    ops.conv2d_wgrad(xd, dz, G2, **kw)
+    scale = G2.abs().max().item()
+    assert (G - G2).abs().max().item() <= 2e-5 * scale, ((G - G2).abs().max().item(), scale)
+    assert G[:, :, :, 16:].abs().max().item() == 0.0                               # columns past the 16 channels: written as zeros
+    # (b) CPU f32: dz from the formula, then the per-image filter gradient by autograd
+    cb = coef.repeat_interleave(ipb, dim=1).view(4, N, C, 1, 1)
+    A = cb[2]
+    dzr = gy * A + ((z - cb[0]) * (-A * cb[1] * c2.repeat_interleave(ipb, 0).view(N, C, 1, 1))
+                    + (-A * c1.repeat_interleave(ipb, 0).view(N, C, 1, 1)))
+    dzr = dzr.to(BF).float()
+    for n in range(N):
+        w = torch.zeros(C, 12, 3, 3, requires_grad=True)
+        F.conv2d(x[n % ipb:n % ipb + 1], w, padding=1).backward(dzr[n:n + 1])
+        got = G[n].cpu()[:, :C, :12].permute(1, 2, 0).reshape(C, 12, 3, 3)          # [tap][cout][cin] -> [cout][cin][kh][kw]
+        close(got, w.grad, BF, f"fused per-image filter gradient, image {n}")

@@ -30,8 +30,10 @@ def test_punet_inter_train_parity_f32(tmp_path):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_punet_train_chain_per_pass_teacher_forced(tmp_path, dtype):
     """each of the T + F train-mode U-Net passes of the frozen PU-Net on the float64 oracle's inputs for
-    that pass (batch-of-8 golden p6): masks within 1e-4 (f32) / 1e-2 (bf16) x (1 + |ref|) on every logit, BatchNorm running
-    buffers after the step within 1e-4 / 1e-2 -- the tight test of the kernels config 4 spends 97 % of its time in."""
+    that pass (batch-of-8 golden p6) -- the tight test of the kernels config 4 spends 97 % of its time in.  f32: every logit
+    within 1e-4 x (1 + |ref|), BatchNorm running buffers within 1e-4.  bf16: within 1.25 x the bf16-storage-emulating CPU
+    oracle's own error on the same pass inputs (max and rms metric; that emulation is 0.3-0.4 off float64 per PASS in the max
+    metric, so the flat 1e-2 is unreachable for any bf16-storage implementation and is only printed)."""
     run_punet_per_pass(tmp_path, "p6_punet_b8_96_f2", dtype)
 
 
