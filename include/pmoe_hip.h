@@ -170,6 +170,16 @@ int64_t pmoe_conv2d_wgrad_ws_floats(const pmoe_wgrad_desc* d);
  *   7209 = conv_wgrad_bnbwd_kernel (bn_fused) */
 int pmoe_conv2d_wgrad_plan(const pmoe_wgrad_desc* d);
 
+/* round 4: weight and bias gradient of a Linear layer of the expert MLPs (autograd of nn.Linear in make_mlp,
+ * model/blocks/basics.py:31, and of the heads model/moe.py:70-72) in ONE launch, written in the parameters' own layout:
+ *   grads[e][o][i] = sum over the expert's ipe batch rows m of dy[e*ipe + m][dy_coff + o] * x[(x_shared ? m : e*ipe + m)][x_coff + i]
+ *   bias_grads[e][o] = sum_m dy[e*ipe + m][dy_coff + o]          (optional)
+ * x [Nx][x_ld], dy [n][dy_ld]: bf16 rows (1x1 "images" of the grouped engine); cin / cout: staged channel counts (multiples
+ * of 8, zero-padded columns), cin_real / cout_real: the Linear's in_features / out_features.  Deterministic (fixed order). */
+int pmoe_mlp_wgrad(const void* x, const void* dy, float* grads, float* bias_grads, int32_t n, int32_t ipe, int32_t x_shared,
+                   int32_t cin, int32_t cout, int32_t cin_real, int32_t cout_real, int32_t x_ld, int32_t x_coff,
+                   int32_t dy_ld, int32_t dy_coff, int32_t dtype, void* stream);
+
 /* Master weights live in the reference's own layout (one f32 OIHW / [out][in] tensor per expert,
  * state_dict keys of SURVEY.md section 8b); these repack all E experts of a layer in one launch.
  * src_ptrs: device array of E pointers to f32 [cout][cin][ks][ks].

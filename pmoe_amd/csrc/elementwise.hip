@@ -122,32 +122,54 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     }
 }
 
-// finalize: block = 64 channels x 16 partial lanes (round 3: up to 2048 partial rows are folded HERE in fixed order instead of by
-// a reduce_partials launch in front of every finalize: ~250 launches fewer in the stage-1 step, ~200 in the PU-Net expert's)
-constexpr int FIN_LANES = 16;
-__global__ void __launch_bounds__(64 * FIN_LANES) bn_finalize_kernel(const float* __restrict__ part, int nparts, long long count,
+// finalize: block = 32 channels x 32 partial lanes (round 3: up to 2048 partial rows are folded HERE in fixed order instead of by
+// a reduce_partials launch in front of every finalize: ~250 launches fewer in the stage-1 step, ~200 in the PU-Net expert's).
+// Round 4: these 44 launches per headline step ran 13-15 us each for ~1 MB of partial rows -- E x C/64 workgroups whose threads
+// walked up to 128 rows one dependent load at a time.  Now 32 lanes per channel, four independent accumulation chains per lane
+// (fixed association: ((a0 + a1) + (a2 + a3)), bit-reproducible), i.e. <= 16 dependent steps with 4 loads in flight each.
+constexpr int FIN_LANES = 32, FIN_CH = 32;
+__device__ __forceinline__ void fin_fold(const float* __restrict__ part, int nparts, int C, int e, int c, int pl, bool on,
+                                         double (*red)[FIN_LANES][FIN_CH], double& t1, double& t2) {
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (on) {
+        const float* p = part + ((size_t)e * nparts * 2) * C + c;
+        int i = pl;
+        for (; i + 3 * FIN_LANES < nparts; i += 4 * FIN_LANES) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a1[k] += p[((size_t)(i + k * FIN_LANES) * 2 + 0) * C];
+                a2[k] += p[((size_t)(i + k * FIN_LANES) * 2 + 1) * C];
+            }
+        }
+        for (; i < nparts; i += FIN_LANES) {                  // (< 4 rows left for this lane)
+            a1[0] += p[((size_t)i * 2 + 0) * C];
+            a2[0] += p[((size_t)i * 2 + 1) * C];
+        }
+    }
+    const int cl = threadIdx.x & (FIN_CH - 1);
+    red[0][pl][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    red[1][pl][cl] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+    __syncthreads();
+    t1 = t2 = 0.0;
+    if (pl == 0) {
+#pragma unroll
+        for (int k = 0; k < FIN_LANES; ++k) { t1 += red[0][k][cl]; t2 += red[1][k][cl]; }
+    }
+}
+
+__global__ void __launch_bounds__(FIN_CH * FIN_LANES) bn_finalize_kernel(const float* __restrict__ part, int nparts, long long count,
                                                          const float* const* gamma, const float* const* beta,
                                                          float* const* rmean, float* const* rvar, float momentum,
                                                          float eps, int training, float* scale, float* shift,
                                                          float* mean_o, float* invstd_o, int C,
                                                          const float* __restrict__ shiftc) {
-    const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    __shared__ double red[2][FIN_LANES][64];              // (partial rows folded in double: up to 2048 f32 rows per channel)
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C && training)
-        for (int i = pl; i < nparts; i += FIN_LANES) {
-            s1 += part[(((size_t)e * nparts + i) * 2 + 0) * C + c];
-            s2 += part[(((size_t)e * nparts + i) * 2 + 1) * C + c];
-        }
-    red[0][pl][threadIdx.x & 63] = s1;
-    red[1][pl][threadIdx.x & 63] = s2;
-    __syncthreads();
+    const int e = blockIdx.y, c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), pl = threadIdx.x / FIN_CH;
+    __shared__ double red[2][FIN_LANES][FIN_CH];          // (partial rows folded in double: up to 2048 f32 rows per channel)
+    double t1, t2;
+    fin_fold(part, nparts, C, e, c, pl, c < C && training, red, t1, t2);
     if (pl == 0 && c < C) {
         float mean, var;
         if (training) {
-            double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-            for (int k = 0; k < FIN_LANES; ++k) { t1 += red[0][k][threadIdx.x]; t2 += red[1][k][threadIdx.x]; }
             const double md = t1 / (double)count;                  // mean of the deviations x - c
             double v = t2 / (double)count - md * md;
             if (v < 0.0) v = 0.0;
@@ -172,24 +194,14 @@ __global__ void __launch_bounds__(64 * FIN_LANES) bn_finalize_kernel(const float
     }
 }
 
-__global__ void __launch_bounds__(64 * FIN_LANES) bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts,
+__global__ void __launch_bounds__(FIN_CH * FIN_LANES) bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts,
                                                              long long count, float* dgamma, float* dbeta, float* c1,
                                                              float* c2, int C) {
-    const int e = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    __shared__ double red[2][FIN_LANES][64];
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int i = pl; i < nparts; i += FIN_LANES) {
-            s1 += part[(((size_t)e * nparts + i) * 2 + 0) * C + c];
-            s2 += part[(((size_t)e * nparts + i) * 2 + 1) * C + c];
-        }
-    red[0][pl][threadIdx.x & 63] = s1;
-    red[1][pl][threadIdx.x & 63] = s2;
-    __syncthreads();
+    const int e = blockIdx.y, c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), pl = threadIdx.x / FIN_CH;
+    __shared__ double red[2][FIN_LANES][FIN_CH];
+    double t1, t2;
+    fin_fold(part, nparts, C, e, c, pl, c < C, red, t1, t2);
     if (pl == 0 && c < C) {
-        double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < FIN_LANES; ++k) { t1 += red[0][k][threadIdx.x]; t2 += red[1][k][threadIdx.x]; }
         if (dbeta) dbeta[e * C + c] = (float)t1;
         if (dgamma) dgamma[e * C + c] = (float)t2;
         c1[e * C + c] = (float)(t1 / (double)count);
@@ -746,7 +758,7 @@ int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const voi
                      float eps, int32_t training, float* scale, float* shift, float* mean, float* invstd, int32_t E,
                      int32_t C, const float* shiftc, void* stream) {
     if (!training && (!rmean_ptrs || !rvar_ptrs)) return PMOE_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, E), dim3(64 * FIN_LANES), 0, (hipStream_t)stream, part, nparts,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH, E), dim3(FIN_CH * FIN_LANES), 0, (hipStream_t)stream, part, nparts,
                        (long long)count, (const float* const*)gamma_ptrs, (const float* const*)beta_ptrs,
                        (float* const*)rmean_ptrs, (float* const*)rvar_ptrs, momentum, eps, training, scale, shift, mean,
                        invstd, C, shiftc);
@@ -755,7 +767,7 @@ int pmoe_bn_finalize(const float* part, int32_t nparts, int64_t count, const voi
 
 int pmoe_bn_bwd_finalize(const float* part, int32_t nparts, int64_t count, float* dgamma, float* dbeta, float* c1,
                          float* c2, int32_t E, int32_t C, void* stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, E), dim3(64 * FIN_LANES), 0, (hipStream_t)stream, part, nparts,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH, E), dim3(FIN_CH * FIN_LANES), 0, (hipStream_t)stream, part, nparts,
                        (long long)count, dgamma, dbeta, c1, c2, C);
     return (int)hipGetLastError();
 }

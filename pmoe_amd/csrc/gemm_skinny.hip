@@ -202,3 +202,112 @@ int gemm_skinny_launch(const ConvArgs& a, hipStream_t st) {
     if (nw8 > 0 && a.ks * a.ks * a.Cin >= nw8) return skinny_launch_nw<8>(a, grid, st);
     return skinny_launch_nw<4>(a, grid, st);
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: weight (and bias) gradients of the expert MLP layers (autograd of nn.Linear in make_mlp, blocks/basics.py:31, and of
+// the heads moe.py:70-72):   dW[e][n][k] = sum over the expert's batch rows m of dY[m][n] * X[m][k],   db[e][n] = sum_m dY[m][n].
+// GEMM-K is the batch (64..256 rows): 10 launches per step that the generic conv_wgrad_kernel served at ~45 us each -- its
+// 256-pixel m-block is three quarters zero fill at 64 rows, its workgroups are one per CU (96 KB of LDS tiles), its K-split
+// machinery adds a fold launch -- plus a column-sum launch chain per bias.  Here: one 4-wave workgroup per 64 x 64 tile of
+// ONE expert (24 KB of LDS: six workgroups per CU, the whole grid resident at once), both operands staged as [row][channel]
+// rows of 192 bytes and read TRANSPOSED (ds_read_b64_tr_b16, as conv_wgrad.hip), the tile written straight into the
+// parameter's own [E][out][in] gradient, the bias gradient folded from the staged dY tile by the workgroups of input-tile 0.
+// Fixed summation order, no atomics: bit-reproducible.
+struct MlpWgradArgs {
+    const void* x;         // [Nx][x_ld] bf16 rows; channels [x_coff, x_coff + Cin)
+    const void* dy;        // [N][dy_ld] bf16 rows; channels [dy_coff, dy_coff + Cout)
+    float* grads;          // [E][cout_real][cin_real] f32
+    float* bias_grads;     // [E][cout_real] f32 or null
+    int N, ipe, x_shared;
+    int Cin, Cout, cin_real, cout_real;      // Cin / Cout: staged channel counts (multiples of 8)
+    int x_ld, x_coff, dy_ld, dy_coff;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_m;
+__device__ __forceinline__ s16x4 mlp_tr_read(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_m*)(p)); }
+
+__global__ void __launch_bounds__(256) mlp_wgrad_kernel(const MlpWgradArgs a) {
+    constexpr int RS = 192;
+    __shared__ __attribute__((aligned(16))) char dyt[64 * RS];
+    __shared__ __attribute__((aligned(16))) char xt[64 * RS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int co_sub = wave & 1, ci_sub = wave >> 1;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, e = blockIdx.z;
+    const bf16* dy = (const bf16*)a.dy + (size_t)e * a.ipe * a.dy_ld + a.dy_coff + co0;
+    const bf16* x = (const bf16*)a.x + (a.x_shared ? (size_t)0 : (size_t)e * a.ipe * a.x_ld) + a.x_coff + ci0;
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    const int sj = tid & 7, sr = tid >> 3;                           // staging: chunk sj of rows sr, sr + 32
+    const bool dy_cok = co0 + sj * 8 < a.Cout, x_cok = ci0 + sj * 8 < a.Cin;
+    const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+    const int ca = (co_sub * 32 + 16 * (g & 1) + 4 * pc) * 2, cb = (ci_sub * 32 + 16 * (g & 1) + 4 * pc) * 2;
+    float bsum = 0.f;                                                // threads 0..63 of the input-tile-0 workgroups: column tid of dY
+    const bool want_bias = a.bias_grads && blockIdx.x == 0;
+    for (int r0 = 0; r0 < a.ipe; r0 += 64) {
+        v4i dv[2], xv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = r0 + sr + 32 * u;
+            dv[u] = xv[u] = v4i{0, 0, 0, 0};
+            if (r < a.ipe) {
+                if (dy_cok) dv[u] = ldg16(dy + (size_t)r * a.dy_ld + sj * 8);
+                if (x_cok) xv[u] = ldg16(x + (size_t)r * a.x_ld + sj * 8);
+            }
+        }
+        __syncthreads();                                             // the previous chunk's fragment reads are done
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<v4i*>(dyt + (sr + 32 * u) * RS + sj * 16) = dv[u];
+            *reinterpret_cast<v4i*>(xt + (sr + 32 * u) * RS + sj * 16) = xv[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            bf16x8 fa, fb;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int p = kb * 16 + 8 * (g >> 1) + 4 * tt + q;
+                const bf16x4 ra = __builtin_bit_cast(bf16x4, mlp_tr_read(dyt + p * RS + ca));
+                const bf16x4 rb = __builtin_bit_cast(bf16x4, mlp_tr_read(xt + p * RS + cb));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { fa[4 * tt + i] = ra[i]; fb[4 * tt + i] = rb[i]; }
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+        if (want_bias && tid < 64) {
+            const bf16* col = reinterpret_cast<const bf16*>(dyt) + tid;
+            for (int r = 0; r < 64; ++r) bsum += (float)col[r * (RS / 2)];       // rows beyond the batch were staged as zeros
+        }
+    }
+    const int cin = ci0 + ci_sub * 32 + l31;
+    if (cin < a.cin_real) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cout = co0 + co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (cout < a.cout_real) a.grads[((size_t)e * a.cout_real + cout) * a.cin_real + cin] = acc[r];
+        }
+    }
+    if (want_bias && tid < 64 && co0 + tid < a.cout_real) a.bias_grads[(size_t)e * a.cout_real + co0 + tid] = bsum;
+}
+
+int mlp_wgrad_launch(const MlpWgradArgs& a, hipStream_t st) {
+    if (!a.x || !a.dy || !a.grads || a.ipe <= 0 || a.N % a.ipe) return PMOE_ERR_ARG;
+    if (a.Cin % 8 || a.Cout % 8 || a.x_ld % 8 || a.x_coff % 8 || a.dy_ld % 8 || a.dy_coff % 8) return PMOE_ERR_ARG;
+    if (a.x_coff + a.Cin > a.x_ld || a.dy_coff + a.Cout > a.dy_ld) return PMOE_ERR_ARG;
+    if (a.cin_real <= 0 || a.cin_real > a.Cin || a.cout_real <= 0 || a.cout_real > a.Cout) return PMOE_ERR_ARG;
+    const dim3 grid((a.Cin + 63) / 64, (a.Cout + 63) / 64, a.N / a.ipe);
+    hipLaunchKernelGGL(mlp_wgrad_kernel, grid, dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmoe_mlp_wgrad(const void* x, const void* dy, float* grads, float* bias_grads, int32_t n, int32_t ipe,
+                              int32_t x_shared, int32_t cin, int32_t cout, int32_t cin_real, int32_t cout_real, int32_t x_ld,
+                              int32_t x_coff, int32_t dy_ld, int32_t dy_coff, int32_t dtype, void* stream) {
+    if (dtype != PMOE_DT_BF16) return PMOE_ERR_UNSUPPORTED;
+    MlpWgradArgs a{x, dy, grads, bias_grads, n, ipe, x_shared, cin, cout, cin_real, cout_real, x_ld, x_coff, dy_ld, dy_coff};
+    return mlp_wgrad_launch(a, (hipStream_t)stream);
+}

@@ -188,6 +188,9 @@ class ExpertGroupEngine:
         self.fuse_bn_gap = os.environ.get("PMOE_FUSE_BN_GAP", "1") != "0"
         # round 4: the stem's first BatchNorm backward applied on load by conv1's per-image filter gradient (no dz1 tensor)
         self.stem_bn_fuse = os.environ.get("PMOE_STEM_BN_FUSE", "1") != "0"
+        # round 4: weight + bias gradient of the expert MLP layers in one small launch each (PMOE_MLP_WGRAD=0: the generic
+        # weight-gradient kernel + fold + column-sum chain of rounds 1-3)
+        self.mlp_wgrad_fused = os.environ.get("PMOE_MLP_WGRAD", "1") != "0"
         # BASELINE config 5: e4m3 weights + e4m3 activations on the fp8 matrix cores for the layer1-4 forward convolutions
         # (policy: include/pmoe_hip.h, pmoe_pack_conv_weights_fp8).  fp8_min_cin: smallest input-channel count that takes it
         self.fp8 = False
@@ -478,6 +481,27 @@ class ExpertGroupEngine:
 
     def _wgrad_block(self, x, layer, o, dy, in_shared, flop):
         E = self.E
+        if (self.mlp_wgrad_fused and layer.ks == 1 and self.dtype == torch.bfloat16 and dy.shape[1] == 1 and dy.shape[2] == 1
+                and x.t.shape[1] == 1 and x.t.shape[2] == 1 and not hasattr(layer, "store_grads")):
+            # round 4: a Linear layer of the expert MLPs -- weight AND bias gradient in one launch, written in the parameters'
+            # own layout (csrc/gemm_skinny.hip mlp_wgrad_kernel); the fused 5-row head goes through a dense temporary
+            parts = getattr(layer, "parts", None)
+            ops.set_meta(flop=flop, name=layer.name)
+            if parts is None:
+                ops.mlp_wgrad(x.t, dy, self._grad_slot("w", layer), self._grad_slot("b", layer) if layer.biases is not None else None,
+                              cin=layer.cinp, cout=layer.cout_st, cin_real=layer.cin, cout_real=layer.cout, ipe=self.B,
+                              x_shared=in_shared, x_coff=x.coff, dy_coff=o.coff)
+                return
+            full = torch.empty(E, layer.cout, layer.cin, dtype=F32, device=self.dev)
+            fb = torch.empty(E, layer.cout, dtype=F32, device=self.dev)
+            ops.mlp_wgrad(x.t, dy, full, fb, cin=layer.cinp, cout=layer.cout_st, cin_real=layer.cin, cout_real=layer.cout,
+                          ipe=self.B, x_shared=in_shared, x_coff=x.coff, dy_coff=o.coff)
+            ra = parts[0][2]
+            self._grad_slot("w_part", (layer, "action_pred")).view(E, ra, layer.cin).copy_(full[:, 0:ra])
+            self._grad_slot("w_part", (layer, "alpha")).view(E, layer.cout - ra, layer.cin).copy_(full[:, ra:])
+            self._grad_slot("b_part", (layer, "action_pred")).view(E, ra).copy_(fb[:, 0:ra])
+            self._grad_slot("b_part", (layer, "alpha")).view(E, layer.cout - ra).copy_(fb[:, ra:])
+            return
         ckw = 64 if self.dtype == torch.bfloat16 else 32
         cpw = (layer.cinp + ckw - 1) // ckw * ckw
         cow = (layer.cout_st + ckw - 1) // ckw * ckw

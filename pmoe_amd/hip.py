@@ -77,6 +77,7 @@ SIGNATURES = {
     "pmoe_conv2d_wgrad_fold": [C.POINTER(WgradDesc), _P],
     "pmoe_conv2d_wgrad_ws_floats": [C.POINTER(WgradDesc)],
     "pmoe_conv2d_wgrad_plan": [C.POINTER(WgradDesc)],
+    "pmoe_mlp_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights_fp8": [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights_scaled": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

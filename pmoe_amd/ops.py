@@ -169,6 +169,20 @@ def conv2d_wgrad(x, dy, dw_ws, *, cin, cout, cinp, coutp, ipe, ks, stride, pad, 
     return d if defer_fold else dw_ws
 
 
+def mlp_wgrad(x, dy, grads, bias_grads, *, cin, cout, cin_real, cout_real, ipe, x_shared=False, x_coff=0, dy_coff=0):
+    """weight (+ bias) gradient of one Linear layer of all experts, in the parameters' own [E][out][in] / [E][out] layout
+    (csrc/gemm_skinny.hip: mlp_wgrad_kernel).  x [Nx,1,1,ldx] / dy [N,1,1,ldy]: bf16 rows."""
+    n, ldy = dy.shape[0], dy.shape[-1]
+    E = n // ipe
+    if x.dtype != torch.bfloat16 or dy.numel() != n * ldy or x.numel() != x.shape[0] * x.shape[-1]:
+        raise ValueError("mlp_wgrad: bf16 rows [N,1,1,ld]")
+    if grads.numel() != E * cout_real * cin_real or (bias_grads is not None and bias_grads.numel() != E * cout_real):
+        raise ValueError("mlp_wgrad: grads must hold E * out * in (bias_grads: E * out) float32 values")
+    check(load().pmoe_mlp_wgrad(ptr(x, "x"), ptr(dy, "dy", x.dtype), ptr(grads, "grads", torch.float32),
+                                ptr(bias_grads, "bias_grads", torch.float32), n, ipe, int(x_shared), cin, cout, cin_real,
+                                cout_real, x.shape[-1], x_coff, ldy, dy_coff, dt(x), stream_ptr()), "pmoe_mlp_wgrad")
+
+
 def conv2d_wgrad_fold(d):
     """the deferred tail of :func:`conv2d_wgrad` (``defer_fold``): K-split slabs -> the parameter-layout gradient / dw_ws"""
     check(load().pmoe_conv2d_wgrad_fold(C.byref(d), stream_ptr()), "pmoe_conv2d_wgrad_fold")

@@ -1140,7 +1140,9 @@ def test_wgrad_with_batchnorm_backward_on_load(E, ipb, H, W):
     G2 = torch.full((N, 9, 64, 64), 3.0, device=DEV)
     ops.conv2d_wgrad(xd, dz, G2, **kw)
     scale = G2.abs().max().item()
-    assert (G - G2).abs().max().item() <= 2e-5 * scale, ((G - G2).abs().max().item(), scale)
+    per_img = [((G[n] - G2[n]).abs().max().item() / scale) for n in range(N)]
+    per_tap = [((G[:, t] - G2[:, t]).abs().max().item() / scale) for t in range(9)]
+    assert max(per_img) <= 2e-5, ("fused vs unfused, per image / per tap", per_img, per_tap)
     assert G[:, :, :, 16:].abs().max().item() == 0.0                               # columns past the 16 channels: written as zeros
     # (b) CPU f32: dz from the formula, then the per-image filter gradient by autograd
     cb = coef.repeat_interleave(ipb, dim=1).view(4, N, C, 1, 1)
@@ -1153,3 +1155,40 @@ def test_wgrad_with_batchnorm_backward_on_load(E, ipb, H, W):
         F.conv2d(x[n % ipb:n % ipb + 1], w, padding=1).backward(dzr[n:n + 1])
         got = G[n].cpu()[:, :C, :12].permute(1, 2, 0).reshape(C, 12, 3, 3)          # [tap][cout][cin] -> [cout][cin][kh][kw]
         close(got, w.grad, BF, f"fused per-image filter gradient, image {n}")
+
+
+@pytest.mark.parametrize("E,ipe,K,Kr,Nn,Nr,shared,xcoff,ycoff", [
+    (3, 64, 1536, 1536, 512, 512, False, 0, 0),          # speed_prediction.0 / action_head.0 (moe.py:62-66)
+    (2, 100, 16, 1, 512, 512, True, 0, 0),               # speed_encoder.0: one real input column, input rows shared by the experts
+    (2, 7, 512, 512, 16, 5, False, 0, 0),                # the fused 5-row head (action_pred + alpha), ragged batch
+    (4, 64, 512, 512, 512, 512, False, 512, 1024),       # channel windows: input slot of the 1536-d feature, output slot
+    (1, 130, 96, 90, 80, 72, False, 0, 0),               # ragged tiles, three row chunks
+])
+def test_mlp_wgrad_one_launch(E, ipe, K, Kr, Nn, Nr, shared, xcoff, ycoff):
+    """pmoe_mlp_wgrad (round 4): weight + bias gradient of a Linear layer of all experts in one launch, parameter layout,
+    against dY^T X / column sums in f32 on the CPU (inputs pre-rounded to bf16: only the summation order differs)."""
+    g = torch.Generator().manual_seed(E + ipe + K + Nn)
+    BF = torch.bfloat16
+    xld, yld = max(K + xcoff, 1536 if xcoff else K), max(Nn + ycoff, 1536 if ycoff else Nn)
+    nx = ipe if shared else E * ipe
+    x = torch.zeros(nx, xld)
+    x[:, xcoff:xcoff + Kr] = rnd((nx, Kr), g, BF)
+    dy = torch.zeros(E * ipe, yld)
+    dy[:, ycoff:ycoff + Nr] = rnd((E * ipe, Nr), g, BF)
+    if xcoff:
+        x[:, :xcoff] = 9.0                              # neighbouring slots must not leak in
+    if ycoff:
+        dy[:, :ycoff] = 9.0
+    xd = x.to(BF).to(DEV).view(nx, 1, 1, xld)
+    dyd = dy.to(BF).to(DEV).view(E * ipe, 1, 1, yld)
+    grads = torch.full((E, Nr, Kr), 7.0, device=DEV)
+    bg = torch.full((E, Nr), 7.0, device=DEV)
+    ops.mlp_wgrad(xd, dyd, grads, bg, cin=K, cout=Nn, cin_real=Kr, cout_real=Nr, ipe=ipe, x_shared=shared, x_coff=xcoff, dy_coff=ycoff)
+    g2 = torch.full((E, Nr, Kr), 7.0, device=DEV)
+    ops.mlp_wgrad(xd, dyd, g2, None, cin=K, cout=Nn, cin_real=Kr, cout_real=Nr, ipe=ipe, x_shared=shared, x_coff=xcoff, dy_coff=ycoff)
+    assert torch.equal(grads, g2)                       # deterministic, and the bias output is optional
+    for e in range(E):
+        xe = x[(0 if shared else e * ipe):(0 if shared else e * ipe) + ipe, xcoff:xcoff + Kr]
+        de = dy[e * ipe:(e + 1) * ipe, ycoff:ycoff + Nr]
+        close(grads[e], de.t() @ xe, BF, f"mlp wgrad e{e}")
+        close(bg[e], de.sum(0), BF, f"mlp bias grad e{e}")
