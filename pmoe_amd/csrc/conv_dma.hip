@@ -59,8 +59,34 @@ __device__ __forceinline__ int cswz(int x) { return (x >> 1) & 7; }
 // MF16 (default for >= 256 input channels, conv_dma_launch): the same 64 x 64 wave tile on v_mfma_f32_16x16x32_bf16 -- 16 MFMAs of half the
 // cycles per 32 channels instead of 4 per 16, identical LDS traffic (8 ds_read_b128 per 32 channels either way).  On this part
 // the clock an MFMA-dense loop holds depends on the MFMA shape (MI355X_MICROARCH.md, DVFS give-back item 7).
-template <bool MF16>
-__global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, const int pbuf_bytes) {
+//
+// PROD (round 4): a NINTH wave that issues every LDS-DMA request of the workgroup and nothing else.  In the
+// 8-wave kernel each wave issues up to three requests per tap right behind the barrier (60-185 cycles each at the texture
+// path's port, MI355X_MICROARCH.md cycle constants) and cannot issue MFMAs meanwhile.  Here the eight accumulating waves have
+// NO vector-memory instruction in the main loop at all -- barrier, fragment reads, 16 MFMAs -- and the producer wave, which
+// owns the in-order vmcnt bookkeeping of the whole stream (all pieces are its own), publishes a tap with the same barrier:
+// before barrier(tt) it waits until only the requests issued after W(tt) are outstanding (= the group it issued during tap
+// tt-1: the patch pieces of the next chunk first, the weight tile of tap tt+1 last).  576 threads: three waves on one SIMD, so
+// the kernel must fit 168 VGPRs (it needs ~150 without the z / residual prefetch) -- forward launches only (no res, no bias, no
+// activation); the data-gradient modes keep the 8-wave kernel.  The producer ends after the last tap; s_barrier then counts
+// the surviving eight waves (the epilogue's barriers).  PMOE_DMA_PRODUCER=0: A/B switch.
+#define VMCASE(n) case n: VMCNT(n); break;
+__device__ __forceinline__ void vm_wait_prod(int n) {     // s_waitcnt vmcnt(n), n <= 24 (a wave-uniform scalar)
+    switch (n) {
+        VMCASE(0) VMCASE(1) VMCASE(2) VMCASE(3) VMCASE(4) VMCASE(5) VMCASE(6) VMCASE(7) VMCASE(8) VMCASE(9) VMCASE(10) VMCASE(11)
+        VMCASE(12) VMCASE(13) VMCASE(14) VMCASE(15) VMCASE(16) VMCASE(17) VMCASE(18) VMCASE(19) VMCASE(20) VMCASE(21) VMCASE(22)
+        VMCASE(23)
+        default: VMCNT(24); break;
+    }
+}
+
+template <bool MF16, bool PROD = false>
+__global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3_dma_kernel(const ConvArgs a_in, const int pbuf_bytes) {
+    ConvArgs a = a_in;
+    if constexpr (PROD) {                                // forward launches only (conv_dma_uses_producer): the epilogue's side-input /
+        a.res_mode = PMOE_RES_NONE; a.res = nullptr;     // bias / activation / dropout branches fold away at compile time (168 VGPRs)
+        a.bias = nullptr; a.act = PMOE_ACT_NONE; a.drop_p = 0.f; a.bn = nullptr;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     STAMP_INIT
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,6 +126,71 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
 
     // ---- per-lane source offsets of this wave's DMA pieces (loop invariant; the channel chunk and the tap travel in soffset)
     constexpr int OOB = 0x7ff80000;                    // beyond every num_records: the lane's 16 bytes arrive as zeros
+    if constexpr (PROD) {
+        if (wave == 8) {
+            // the producer wave: per-lane offsets of ALL pieces (48 patch + 16 weight-tile), then the request stream
+            int pv[48], wv[16];
+#pragma unroll
+            for (int i = 0; i < 48; ++i) {
+                const int pp = (i << 3) + (lane >> 3);
+                const int jj = lane & 7;
+                const int px = pp % PW;
+                const int rowq = pp / PW;
+                const int prow = rowq % PH, pn = rowq / PH;
+                const int Y = oy0 - 1 + prow, X = ox0 - 1 + px;
+                const bool ok = pp < NPIX && n0 + pn < n_end && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+                pv[i] = ok ? ((((pn * a.H + Y) * a.W + X) * a.in_ld) << 1) + ((jj ^ cswz(px)) << 4) : OOB;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i << 3) + (lane >> 3);
+                wv[i] = ((row * 9 * a.Cin) << 1) + (((lane & 7) ^ cswz(row)) << 4);
+            }
+            auto req_w = [&](int slot, int tap, int c0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(wring + slot * WSLOT + (i << 10)), 16, wv[i],
+                                                             (tap * a.Cin + c0) << 1, 0, 0);
+            };
+            const int nch = a.Cin / CK, TT = nch * 9;
+#pragma unroll
+            for (int i = 0; i < 48; ++i)
+                if (i < NPIECE) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(smem + (i << 10)), 16, pv[i], 0, 0, 0);
+            req_w(0, 0, 0);
+            req_w(1, 1, 0);
+            int after = 16;                              // requests issued after W(tt): the group of the previous tap
+            for (int ch = 0; ch < nch; ++ch) {
+                const int c0 = ch * CK;
+                const bool more = ch + 1 < nch;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int tt = ch * 9 + tap;
+                    vm_wait_prod(after);
+                    __builtin_amdgcn_s_barrier();
+                    int n = 0;
+                    if (tap >= 1 && tap <= 6 && more) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int idx = (tap - 1) * 8 + j;
+                            if (idx < NPIECE) {
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                    rs_in, (lds_void*)(smem + ((ch + 1) & 1) * pbuf_bytes + (idx << 10)), 16, pv[idx], (c0 + CK) << 1, 0, 0);
+                                ++n;
+                            }
+                        }
+                    }
+                    if (tt + 2 < TT) {
+                        int ntap = tap + 2, nc0 = c0;
+                        if (ntap >= 9) { ntap -= 9; nc0 += CK; }
+                        req_w((tt + 2) & (RING - 1), ntap, nc0);
+                        n += 16;
+                    }
+                    after = n;
+                }
+            }
+            return;
+        }
+    }
     int pvoff[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -193,18 +284,20 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
     // The same prefetch serves PMOE_RES_ADD (a data gradient accumulating into the gradient the identity branch left: layer2-4
     // `.1.conv1`), which then also takes the one-phase bf16 read-out (the sum is formed on the rounded accumulator, as the
     // resident-filter kernel always did: 0.46 -> 0.37 ms on layer2.1.conv1's data gradient).
-    const bool zpre_on = (a.res_mode == PMOE_RES_DBN || a.res_mode == PMOE_RES_ADD) && !a.bias && a.act == PMOE_ACT_NONE &&
+    const bool zpre_on = !PROD && (a.res_mode == PMOE_RES_DBN || a.res_mode == PMOE_RES_ADD) && !a.bias && a.act == PMOE_ACT_NONE &&
                          a.drop_p == 0.f;
     v4i zpre[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) zpre[u] = v4i{0, 0, 0, 0};
 
     // ---- prologue: patch of chunk 0, weight tiles of taps 0 and 1
+    if constexpr (!PROD) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-        if (i < my_pieces) dma_patch(i, 0, 0);
-    dma_w(0, 0, 0);
-    dma_w(1, 1, 0);
+        for (int i = 0; i < 6; ++i)
+            if (i < my_pieces) dma_patch(i, 0, 0);
+        dma_w(0, 0, 0);
+        dma_w(1, 1, 0);
+    }
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
@@ -216,19 +309,23 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_kernel(const ConvArgs a, 
             // W(tt) has landed for this wave once at most {W(tt+1), the patch piece issued in the previous iteration}
             // are outstanding (vmcnt counts in issue order)
             const bool prev_piece = tap >= 2 && tap <= 7 && more && (tap - 2) < my_pieces;
-            if (tt + 1 >= T) VMCNT(0);
-            else if (zpre_on && !more && tap == 1) VMCNT(10);      // W(tt) is older than both W(tt+1) and the 8 loads of tap 0
-            else if (prev_piece) VMCNT(3);
-            else VMCNT(2);
+            if constexpr (!PROD) {
+                if (tt + 1 >= T) VMCNT(0);
+                else if (zpre_on && !more && tap == 1) VMCNT(10);      // W(tt) is older than both W(tt+1) and the 8 loads of tap 0
+                else if (prev_piece) VMCNT(3);
+                else VMCNT(2);
+            }
             __builtin_amdgcn_s_barrier();                // every wave's share of tap tt (and of this chunk's patch) is in LDS
 #ifdef PMOE_STAMP
             if (tt == 0) LAP(0)                          // prologue: descriptors, offsets, first patch + two weight tiles landed
 #endif
+            if constexpr (!PROD) {
             if (tap >= 1 && tap <= 6 && more && (tap - 1) < my_pieces) dma_patch(tap - 1, (ch + 1) & 1, c0 + CK);
             if (tt + 2 < T) {
                 int ntap = tap + 2, nc0 = c0;
                 if (ntap >= 9) { ntap -= 9; nc0 += CK; }
                 dma_w((tt + 2) & (RING - 1), ntap, nc0);
+            }
             }
             if (tap == 0 && zpre_on && !more) {
                 const int zc = tid & 15, zr = tid >> 4;      // the read-out's (cc, pr): 16 channel vectors x 32 pixel rows of threads
@@ -774,6 +871,13 @@ bool conv_dma_uses_mf16(const ConvArgs& a) {
     return ev ? atoi(ev) != 0 : a.Cin >= 256;
 }
 
+// the producer-wave instantiation (round 4): forward launches -- nothing added to or derived from a side input in the epilogue
+bool conv_dma_uses_producer(const ConvArgs& a) {
+    const char* ev = getenv("PMOE_DMA_PRODUCER");
+    if (ev && !atoi(ev)) return false;
+    return a.res_mode == PMOE_RES_NONE && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f;
+}
+
 int conv_dma_launch(ConvArgs a, hipStream_t st) {
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
@@ -781,7 +885,15 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     // v_mfma_f32_16x16x32_bf16 for the layers with >= 4 channel chunks (interleaved A/B, profiles/r03_kernel_ab.log: layer3 forward
     // +0.6 %, data gradient +3.5 %; layer4 +3.5 % / +5 %; layer2 -3 % / +0.7 %: the shorter the main loop, the less the shape's
     // higher sustained clock buys).  PMOE_DMA_MF16=0 | 1 forces one shape (read per launch).
-    if (conv_dma_uses_mf16(a)) {
+    if (conv_dma_uses_producer(a)) {
+        if (conv_dma_uses_mf16(a)) {
+            HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<true, true>>(160 * 1024)));
+            hipLaunchKernelGGL((conv3x3_dma_kernel<true, true>), dim3(mblocks * (a.CoutP / BN)), dim3(NTHR + 64), smem, st, a, pbuf);
+        } else {
+            HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<false, true>>(160 * 1024)));
+            hipLaunchKernelGGL((conv3x3_dma_kernel<false, true>), dim3(mblocks * (a.CoutP / BN)), dim3(NTHR + 64), smem, st, a, pbuf);
+        }
+    } else if (conv_dma_uses_mf16(a)) {
         HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<true>>(160 * 1024)));
         hipLaunchKernelGGL(conv3x3_dma_kernel<true>, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
     } else {

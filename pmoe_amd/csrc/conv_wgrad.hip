@@ -672,9 +672,11 @@ __global__ void __launch_bounds__(512) conv_wgrad_bnbwd_kernel(const WgradArgs a
     const bool x_cok[2] = {0 < a.Cin, 8 < a.Cin};
 
     v4i dyv[4], zv[4], xv[2];
+    unsigned live = 0;                                  // bit u: pixel u of this thread's staging rows lies inside the image
     auto issue = [&](int mbi) {
         const int px = mbi % a.tiles_x, py = mbi / a.tiles_x;
         const int oy0 = py * TH, ox0 = px * TW;
+        live = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int p = (tid >> 3) + u * 64;
@@ -682,6 +684,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_bnbwd_kernel(const WgradArgs a
             const int oy = oy0 + my, ox = ox0 + mx;
             dyv[u] = zv[u] = v4i{0, 0, 0, 0};
             if (dy_cok && oy < a.Ho && ox < a.Wo) {
+                live |= 1u << u;
                 const size_t pix = (size_t)oy * a.Wo + ox;
                 dyv[u] = ldg16(dy + pix * a.dy_ld + dyj * 8);
                 zv[u] = ldg16(zz + pix * f.z_ld + dyj * 8);
@@ -704,7 +707,9 @@ __global__ void __launch_bounds__(512) conv_wgrad_bnbwd_kernel(const WgradArgs a
             unpack16<bf16>(zv[u], xz);
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = gv[k] * A[k] + ((xz[k] - mu[k]) * Bx[k] + K[k]);
-            *reinterpret_cast<v4i*>(dyt + p * RS + (dyj << 4)) = pack16<bf16>(o);
+            // pixels of a ragged tile beyond the image carry NO gradient (the affine map does not send g = z = 0 to 0, and
+            // their left / upper neighbours' patch pixels are real)
+            *reinterpret_cast<v4i*>(dyt + p * RS + (dyj << 4)) = (live >> u) & 1u ? pack16<bf16>(o) : v4i{0, 0, 0, 0};
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u)

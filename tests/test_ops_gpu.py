@@ -143,7 +143,7 @@ def _conv_case(case, dtype, plan=None):
     ops.conv2d(dyd, wd, dx, cin=r16(cout), cout=cinp, coutp=r64(cin), ipe=ipe, ks=ks, stride=1,
                pad=ks - 1 - pad, dilate=(stride == 2))
     close(from_nhwc(dx, cin), xr.grad, dtype, "conv dgrad")
-    if stride == 1 and ks == 3 and plan is not None and plan[1] in (5007, 5017, 1207):
+    if stride == 1 and ks == 3 and plan is not None and plan[1] in (5007, 5017, 5027, 5037, 1207):
         # a data gradient accumulating into the gradient another consumer left (BasicBlock `.1.conv1`: the identity branch's):
         # PMOE_RES_ADD with the residual prefetched under the MFMAs on both LDS-DMA kernels
         prev = rnd((N, cin, H, W), torch.Generator().manual_seed(9), dtype)
@@ -204,11 +204,11 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
 # parity test).  Codes: include/pmoe_hip.h pmoe_conv2d_plan; the third number = workgroups of the weight-gradient launch.
 BASELINE_CONV_CASES = [
     # (E, ipe, cin, cout, H, W, ks, stride), (fwd, dgrad, wgrad workgroups)
-    ((1, 4, 128, 128, 64, 64, 3, 1), (5007, 5007, 256)),       # layer2: conv3x3_dma_kernel (LDS-DMA), 2 channel chunks
-    ((1, 8, 256, 256, 32, 32, 3, 1), (5017, 5017, 256)),       # layer3: 4 chunks, 32 x 8 pixel tiles; the 16x16x32 MFMA instantiation
-    ((2, 32, 512, 512, 16, 16, 3, 1), (5017, 5017, 256)),      # layer4: 8 chunks, one 16 x 16 image per tile (two patch rows per
+    ((1, 4, 128, 128, 64, 64, 3, 1), (5027, 5027, 256)),       # layer2: conv3x3_dma_kernel<false, true> (LDS-DMA, producer wave), 2 channel chunks
+    ((1, 8, 256, 256, 32, 32, 3, 1), (5037, 5037, 256)),       # layer3: 4 chunks, 32 x 8 pixel tiles; the 16x16x32 MFMA instantiation
+    ((2, 32, 512, 512, 16, 16, 3, 1), (5037, 5037, 256)),      # layer4: 8 chunks, one 16 x 16 image per tile (two patch rows per
                                                                # 32-lane fragment: the column-keyed swizzle), 2 experts
-    ((1, 5, 128, 256, 40, 24, 3, 1), (5007, 5017, 200)),       # ragged: 24-wide rows in 32-wide tiles, 40 rows in strips of 8, 5 images
+    ((1, 5, 128, 256, 40, 24, 3, 1), (5027, 5037, 200)),       # ragged: 24-wide rows in 32-wide tiles, 40 rows in strips of 8, 5 images
     ((1, 1, 64, 64, 256, 256, 3, 1), (1207, 1207, 256)),       # stem conv2: conv3x3_respipe_kernel, 256 tiles of one image
     ((2, 2, 64, 64, 128, 128, 3, 1), (1207, 1207, 256)),       # layer1: resident kernel, persistent workgroups per expert
     ((1, 4, 64, 128, 128, 128, 3, 2), (5207, 4741, 256)),      # layer2.0.conv1: conv3x3s2_dma_kernel (parity planes by LDS-DMA); its data gradient (64 gradient rows) stays on the generic kernel's 4 parity-class launches
@@ -304,7 +304,17 @@ def test_conv_dma_mfma16_variant(monkeypatch, case):
     """PMOE_DMA_MF16=1 (read per launch): conv3x3_dma_kernel on v_mfma_f32_16x16x32_bf16 -- other fragment / accumulator layouts,
     same tile, same parity bar (forward with fused statistics, data gradient)."""
     monkeypatch.setenv("PMOE_DMA_MF16", "1")
-    _conv_case(case, torch.bfloat16, (5017, 5017, None))
+    _conv_case(case, torch.bfloat16, (5037, 5037, None))
+
+
+@pytest.mark.parametrize("case,codes", [((1, 4, 128, 128, 64, 64, 3, 1), (5007, 5007, None)), ((2, 32, 512, 512, 16, 16, 3, 1), (5017, 5017, None)),
+                                        ((1, 5, 128, 256, 40, 24, 3, 1), (5007, 5017, None))])
+def test_conv_dma_without_producer_wave(monkeypatch, case, codes):
+    """PMOE_DMA_PRODUCER=0 (read per launch): plain forward / data-gradient launches back on the 8-wave conv3x3_dma_kernel<MF16> in
+    which every wave issues its own LDS-DMA requests -- the A/B partner of the round-4 producer-wave instantiation, and the kernel
+    the side-input epilogue modes (PMOE_RES_DBN / PMOE_RES_ADD) always run on."""
+    monkeypatch.setenv("PMOE_DMA_PRODUCER", "0")
+    _conv_case(case, torch.bfloat16, codes)
 
 
 @pytest.mark.parametrize("req", ["0", "2"])
@@ -1111,7 +1121,7 @@ def test_conv1x1_direct_kernel(case):
 # Round 4: the stem's first BatchNorm backward applied ON LOAD by conv1's per-image filter gradient (conv_wgrad_bnbwd_kernel,
 # include/pmoe_hip.h pmoe_wgrad_desc.bn_fused): dz = g*A + ((z - mean)*Bx + K) is evaluated between the global loads and the LDS
 # tile, the gradient tensor dz is never written.
-@pytest.mark.parametrize("E,ipb,H,W", [(2, 2, 64, 64), (1, 3, 40, 72), (2, 1, 256, 256)])
+@pytest.mark.parametrize("E,ipb,H,W", [(2, 2, 64, 64), (1, 3, 40, 72), (2, 2, 52, 20), (2, 1, 256, 256)])
 def test_wgrad_with_batchnorm_backward_on_load(E, ipb, H, W):
     """against (a) pmoe_bn_bwd_apply followed by the plain per-image filter gradient -- the operand the MFMAs see is the same
     bf16 tensor, so only the f32 summation order differs -- and (b) the CPU f32 statement of both steps."""
@@ -1154,7 +1164,7 @@ def test_wgrad_with_batchnorm_backward_on_load(E, ipb, H, W):
         w = torch.zeros(C, 12, 3, 3, requires_grad=True)
         F.conv2d(x[n % ipb:n % ipb + 1], w, padding=1).backward(dzr[n:n + 1])
         got = G[n].cpu()[:, :C, :12].permute(1, 2, 0).reshape(C, 12, 3, 3)          # [tap][cout][cin] -> [cout][cin][kh][kw]
-        close(got, w.grad, BF, f"fused per-image filter gradient, image {n}")
+        close(got, w.grad, BF, f"fused per-image filter gradient, image {n}", floor=0.25)     # (dz is a re-rounded derived operand)
 
 
 @pytest.mark.parametrize("E,ipe,K,Kr,Nn,Nr,shared,xcoff,ycoff", [
