@@ -436,6 +436,8 @@ def main():
         kdt = "f32" if args.dtype == "f32" else "bf16"
 
         def symbol(code):
+            if code == 7309:                      # ... with separated roles (round 4): 4 accumulating waves + 1 request-only wave
+                return "conv_wgrad_dma2_kernel<*>", "void conv_wgrad_dma2_kernel<", 1
             if code == 7009:                      # LDS-DMA staged weight gradient (conv_wgrad.hip)
                 return "conv_wgrad_dma_kernel<1, 2, false, *>", "void conv_wgrad_dma_kernel<1, 2, false", 1   # (last parameter: request code, PMOE_WGRAD_REQ)
             if code == 7109:                      # ... its 2 x 4 wave layout for <= 32 input channels (the stem's first convolution)

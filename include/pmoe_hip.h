@@ -168,7 +168,7 @@ int pmoe_conv2d_wgrad_fold(const pmoe_wgrad_desc* d, void* stream);
 int64_t pmoe_conv2d_wgrad_ws_floats(const pmoe_wgrad_desc* d);
 /* which kernel serves the descriptor (nothing is launched; bench.py attributes launch times to rocprof symbols with it):
  *   7009 = conv_wgrad_dma_kernel (LDS-DMA staged, dense 3x3 stride 1, bf16; 7109 = its wave layout for <= 32 input channels);  6000 + taps * 100 + MAXV = conv_wgrad_kernel<T, taps, MAXV>;
- *   7209 = conv_wgrad_bnbwd_kernel (bn_fused) */
+ *   7209 = conv_wgrad_bnbwd_kernel (bn_fused);  7309 = conv_wgrad_dma2_kernel (round 4: the 7009 launches with one accumulating wave per SIMD and a request-only producer wave) */
 int pmoe_conv2d_wgrad_plan(const pmoe_wgrad_desc* d);
 
 /* round 4: weight and bias gradient of a Linear layer of the expert MLPs (autograd of nn.Linear in make_mlp,

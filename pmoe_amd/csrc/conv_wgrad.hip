@@ -598,6 +598,214 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const WgradArgs a, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 4: conv_wgrad_dma_kernel with the roles SEPARATED -- four accumulating waves, ONE per SIMD, and a
+// fifth wave that issues every LDS-DMA request of the workgroup and nothing else.
+// Why: the 8-wave kernel above sits at 0.46 MFMA utilisation although neither the LDS array (55 % busy) nor HBM limits it.  Its
+// k-loop reads the transposed X fragment of tap t+1 one MFMA (32 cycles, 64 with the SIMD partner's turn) ahead of its use, and
+// a ds_read_b64_tr_b16 under this load returns after ~130-200 cycles: every MFMA waits for its operand, and the partner wave --
+// in the same phase of the same barrier-synchronous loop -- waits for ITS operand at the same time.  Deeper read-ahead did not
+// fit: two waves per SIMD leave 256 registers, 144 of them accumulators.  And every wave spends ~1300 of an m-block's ~10 000
+// cycles at the texture path's request port, where it cannot issue MFMAs.
+// Here a wave owns its SIMD: same 32 x 32 x 9-tap accumulators (144 registers), the fragments of a WHOLE k-block (2 dY + 18 X
+// transposed reads = 40 registers) double-buffered, the 20 reads of k-block kb+1 issued between the 9 MFMAs of k-block kb --
+// a read-ahead of 288 MFMA cycles instead of 32 -- and all 16 k-blocks of an m-block on one wave (no pixel split: the flush
+// needs no LDS fold).  The accumulating waves have no vector-memory instruction at all; the producer wave requests m-block
+// i+1 right behind the barrier that publishes m-block i and waits for its own vmcnt(0) before the next one.  320 threads:
+// five waves, <= 2 per SIMD, 256 registers each.  Same LDS image (swizzles, tile geometry, zero fill by the buffer range
+// check), same accumulation order per output element as conv_wgrad_dma_kernel<1, 2> with its pixel halves folded -- but the
+// halves are now one chain, so results agree to f32 summation order, not bit for bit.  PMOE_WGRAD_V2=0: A/B switch.
+template <int LTW>
+__global__ void __launch_bounds__(320) conv_wgrad_dma2_kernel(const WgradArgs a, const int magic_pw, const int magic_ph) {
+    constexpr int TAPS = 9, RS = 128, CKW = 64, TW = 1 << LTW, PW = TW + 2, BMP = 256;
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int e = blockIdx.z;
+    const int n_ci_blk = (a.Cin + CKW - 1) / CKW;
+    const int npairs = n_ci_blk * ((a.Cout + CKW - 1) / CKW);
+    const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
+    const int nsplit = (int)(gridDim.x / npairs);
+    const int pair = (int)(flat % npairs), split = (int)(flat / npairs);
+    const int cob = pair / n_ci_blk, cib = pair % n_ci_blk;
+    const int co0 = cob * CKW, ci0 = cib * CKW;
+
+    const int lTH = a.lTH, TH = 1 << lTH, PH = TH + 2;
+    const int NPIX = a.TN * PH * PW;
+    const int NPIECE = (NPIX + 7) >> 3;
+    const int XB = NPIECE << 10;
+    const int pair_bytes = (BMP << 7) + XB;
+    const int mbpe = a.n_groups * a.tiles_y * a.tiles_x;
+    const int mb_begin = split * a.mb_per_wg;
+    int mb_end = mb_begin + a.mb_per_wg;
+    if (mb_end > mbpe) mb_end = mbpe;
+
+    if (wave == 4) {
+        // ---------------- producer wave: the request stream of conv_wgrad_dma_kernel (REQ = 1 geometry), all pieces its own
+        const bf16* xb = (const bf16*)a.x + (a.x_shared ? (size_t)0 : (size_t)e * a.ipe * a.H * a.W * a.x_ld) + a.x_coff + ci0;
+        const bf16* dyb = (const bf16*)a.dy + (size_t)e * a.ipe * a.Ho * a.Wo * a.dy_ld + a.dy_coff + co0;
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)xb, (short)0, (int)(((long long)a.ipe * a.H * a.W * a.x_ld - a.x_coff - ci0) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)dyb, (short)0, (int)(((long long)a.ipe * a.Ho * a.Wo * a.dy_ld - a.dy_coff - co0) * 2), 0x00020000);
+        constexpr int OOB = 0x7ff80000;
+        constexpr int GUARD = (1 << 9) | (1 << 19) | (1 << 29);
+        int drel[32], dgeo[32], xrel[48], xgeo[48];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int p = (i << 3) + (lane >> 3);
+            const int mx = p & (TW - 1), my = (p >> LTW) & (TH - 1), pn = p >> (LTW + lTH);
+            const int j = (lane & 7) ^ (((p >> 1) & 1) << 2);
+            drel[i] = ((((pn * a.Ho + my) * a.Wo + mx) * a.dy_ld) << 1) + (j << 4);
+            dgeo[i] = (co0 + j * 8 < a.Cout ? (pn << 20) | (my << 10) | mx : (511 << 20)) | GUARD;
+        }
+        // (a piece index beyond the patch's last requests the LAST piece again -- same bytes to the same place -- so that the
+        //  request stream is branch-free straight-line code)
+#pragma unroll
+        for (int i = 0; i < 48; ++i) {
+            const int pp = ((i < NPIECE ? i : NPIECE - 1) << 3) + (lane >> 3);
+            const int rowq = (pp * magic_pw) >> 16, px = pp - rowq * PW;
+            const int pn = (rowq * magic_ph) >> 16, prow = rowq - pn * PH;
+            const int j = (lane & 7) ^ (((px >> 1) & 1) << 2);
+            xrel[i] = ((((pn * a.H + prow) * a.W + px) * a.x_ld) << 1) + (j << 4);
+            xgeo[i] = (pp < NPIX && ci0 + j * 8 < a.Cin ? (pn << 20) | (prow << 10) | px : (511 << 20)) | GUARD;
+        }
+        int wpx, wpy, wng;
+        {
+            int t = mb_begin;
+            wpx = t % a.tiles_x; t /= a.tiles_x;
+            wpy = t % a.tiles_y; wng = t / a.tiles_y;
+        }
+        auto imin = [](int x, int y) { return x < y ? x : y; };
+        auto req_all = [&](int buf) {                    // every piece of the m-block the walk points at, then advance the walk
+            const int n0 = wng * a.TN, oy0 = wpy * TH, ox0 = wpx * TW, Y0 = oy0 - a.pad, X0 = ox0 - a.pad;
+            const int nmax = imin(a.ipe - n0, 511) - 1;
+            const int dbase = (((n0 * a.Ho + oy0) * a.Wo + ox0) * a.dy_ld) << 1;
+            const int dkk = (((nmax << 20) | ((imin(TH, a.Ho - oy0) - 1) << 10) | (imin(TW, a.Wo - ox0) - 1)) | GUARD) + GUARD;
+            const int xbase = (((n0 * a.H + Y0) * a.W + X0) * a.x_ld) << 1;
+            const int xlo = ((Y0 < 0 ? -Y0 : 0) << 10) | (X0 < 0 ? -X0 : 0);
+            const int xkk = (((nmax << 20) | ((imin(PH, a.H - Y0) - 1) << 10) | (imin(PW, a.W - X0) - 1)) | GUARD) + GUARD;
+            char* base = smem + buf * pair_bytes;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const bool ok = ((dkk - dgeo[i]) & GUARD) == GUARD;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void*)(base + (i << 10)), 16, ok ? dbase + drel[i] : OOB, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 48; ++i) {
+                const bool ok = ((xgeo[i] - xlo) & (xkk - xgeo[i]) & GUARD) == GUARD;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void*)(base + (BMP << 7) + ((i < NPIECE ? i : NPIECE - 1) << 10)),
+                                                         16, ok ? xbase + xrel[i] : OOB, 0, 0, 0);
+            }
+            if (++wpx == a.tiles_x) { wpx = 0; if (++wpy == a.tiles_y) { wpy = 0; ++wng; } }
+        };
+        // iteration it: publish m-block it - 1 (wait for its requests, barrier), then request m-block it into the other buffer pair
+        const int nmb = mb_end - mb_begin;
+#pragma unroll 1
+        for (int it = 0; it <= nmb; ++it) {
+            if (it > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();            // m-block it - 1 is in LDS; the other buffer pair is free
+            }
+            if (it < nmb) req_all(it & 1);
+        }
+        return;
+    }
+
+    // ---------------- accumulating waves: 2 (cout halves) x 2 (cin halves), all 16 k-blocks of every m-block
+    const int co_sub = wave >> 1, ci_sub = wave & 1;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    // lane-constant parts of the transposed-fragment addresses (as conv_wgrad_dma_kernel): g = lane >> 4 (channel block g & 1,
+    // k half g >> 1), q = (lane >> 2) & 3 (pixel of the 4-row block), pc = lane & 3 (4-channel column group)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+    int la[2], lb[2][3];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int pl = 8 * (g >> 1) + 4 * tt + q;                     // pixel inside the 16-pixel k-block = its column offset
+        la[tt] = pl * RS + (((co_sub * 4 + (g & 1) * 2 + (pc >> 1)) ^ (((q >> 1) & 1) << 2)) << 4) + 8 * (pc & 1);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+            lb[tt][kx] = (pl + kx) * RS + (((ci_sub * 4 + (g & 1) * 2 + (pc >> 1)) ^ ((((q + kx) >> 1) & 1) << 2)) << 4) + 8 * (pc & 1);
+    }
+    // fragment registers: the dY fragment (A) of the current and the next k-block, and a ring of SIX X fragments (B) that runs
+    // AHEAD taps ahead of the MFMA stream (u = 9 kb + tap indexes the stream; slot u % 6; the 18-tap loop body keeps every
+    // index static).  A whole k-block of read-ahead (2 x 40 registers) spilled: 144 accumulators leave ~100 registers.
+    constexpr int AHEAD = 5, RINGB = 6;
+    s16x4 fa_[2][2], fb_[RINGB][2];
+    auto kb_brow = [&](const char* patch, int kb) {      // address of (patch row, column base) of k-block kb
+        const int r = LTW == 5 ? kb >> 1 : kb;
+        const int colb = LTW == 5 ? (kb & 1) * 16 : 0;
+        const int my = r & (TH - 1), pn = r >> lTH;
+        return patch + ((pn * PH + my) * PW + colb) * RS;
+    };
+    auto frag8 = [](const s16x4& x, const s16x4& y) {
+        const bf16x4 u = __builtin_bit_cast(bf16x4, x), v = __builtin_bit_cast(bf16x4, y);
+        return bf16x8{u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+    };
+
+    for (int mbi = mb_begin; mbi < mb_end; ++mbi) {
+        const int buf = (mbi - mb_begin) & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (all fragment reads of the previous m-block were consumed)
+        __builtin_amdgcn_s_barrier();
+        const char* dyt = smem + buf * pair_bytes;
+        const char* patch = dyt + (BMP << 7);
+        // prologue: A(0) and the first AHEAD taps of k-block 0
+        {
+            const char* br = kb_brow(patch, 0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) fa_[0][tt] = tr_read(dyt + la[tt]);
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) fb_[u % RINGB][tt] = tr_read(br + ((u / 3) * PW) * RS + lb[tt][u % 3]);
+        }
+#pragma unroll 1
+        for (int kb0 = 0; kb0 < 16; kb0 += 2) {
+            // rows of the three k-blocks this body touches (the read-ahead reaches at most into k-block kb0 + 2)
+            const char* brow[3] = {kb_brow(patch, kb0), kb_brow(patch, kb0 + 1), kb_brow(patch, kb0 + 2 < 16 ? kb0 + 2 : 0)};
+#pragma unroll
+            for (int v = 0; v < 18; ++v) {               // v = 9 (kb - kb0) + tap: the ring slot (9 kb0 + v) % 6 = v % 6 (kb0 even)
+                const int kbl = v / 9, tap = v % 9;
+                const bf16x8 fa = frag8(fa_[kbl][0], fa_[kbl][1]);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, frag8(fb_[v % RINGB][0], fb_[v % RINGB][1]), acc[tap], 0, 0, 0);
+                // reads issued behind this MFMA: the X fragment AHEAD taps on; at tap 3 the next k-block's dY fragment
+                const int w = v + AHEAD, wk = w / 9, wt = w % 9;
+                if (kb0 + wk < 16) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        fb_[w % RINGB][tt] = tr_read(brow[wk] + ((wt / 3) * PW) * RS + lb[tt][wt % 3]);
+                }
+                if (tap == 3 && kb0 + kbl + 1 < 16) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) fa_[(kbl + 1) & 1][tt] = tr_read(dyt + (kb0 + kbl + 1) * (16 * RS) + la[tt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // flush: D[row = cout][col = cin], lanes along cin; one wave owns a whole (cout half, cin half) tile: plain stores, no fold
+    const int cin = ci0 + ci_sub * 32 + l31;
+    const size_t slab = a.per_image ? (size_t)e * a.ipe + split : (size_t)split * gridDim.z + e;
+    float* dst = (a.per_image || nsplit == 1) ? a.dw : a.part;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        float* base = dst + ((slab * TAPS + tap) * a.CoutP) * a.CinP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cout = co0 + co_sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            base[(size_t)cout * a.CinP + cin] = acc[tap][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Round 4: the stem's first BatchNorm backward WITHOUT its apply pass.  conv1 (12 -> 16 input channels, 64 outputs, full
 // resolution) is followed by BatchNorm + ReLU (blocks/basics.py:113-120); the gradient dz1 of its output feeds exactly one
 // consumer -- this per-image filter gradient (the ECA-folded stem needs no data gradient into the frames) -- so the 2.15 GB
@@ -907,6 +1115,15 @@ template <typename T, int TAPS, int MAXV> static int launch_wg(const WgradArgs& 
     return wgrad_finish(a, E, TAPS, nsplit, st);
 }
 
+// the separated-roles kernel serves the wide layout (>= 64 input channels) on 16- or 32-pixel-wide tiles
+static bool wgrad_v2_ok(const WgradArgs& a, int lTW) {
+    const char* ev = getenv("PMOE_WGRAD_V2");
+    if (ev && !atoi(ev)) return false;
+    const char* evx = getenv("PMOE_WGRAD_PIPE");
+    if (evx) return false;                              // (the PIN / timing modes belong to the 8-wave kernel)
+    return (lTW == 4 || lTW == 5) && a.ipe <= 511;
+}
+
 // plan == true: nothing is launched, *ws_floats receives the size of the K-split workspace the launch needs (0: none)
 template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool plan, long long* ws_floats, int* code = nullptr) {
     constexpr int CKW = 128 / (int)sizeof(T);
@@ -971,7 +1188,7 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                 xbytes < 0x7ff00000ll && dybytes < 0x7ff00000ll && 2 * ((size_t)BMP * 128 + (size_t)npiece * 1024) <= 160 * 1024) {
                 const char* evn = getenv("PMOE_WGRAD_NARROW");           // A/B: 0 = the 2 x 2 x 2 wave layout for every layer
                 const bool narrow = a.Cin <= 32 && !(evn && !atoi(evn));
-                if (plan) { *code = narrow ? 7109 : 7009; return 0; }       // conv_wgrad_dma_kernel<1, 1> / <1, 2>
+                if (plan) { *code = narrow ? 7109 : wgrad_v2_ok(a, lTW) ? 7309 : 7009; return 0; }   // conv_wgrad_dma_kernel<1, 1> / dma2 / <1, 2>
                 size_t sm = 2 * ((size_t)BMP * 128 + (size_t)npiece * 1024);
                 if (sm < 49152) sm = 49152;               // room for the flush's fold
                 const int nsp = (mbpe + a.mb_per_wg - 1) / a.mb_per_wg;
@@ -998,6 +1215,15 @@ template <typename T> static int wgrad_dtype(WgradArgs a, hipStream_t st, bool p
                 } else if (evx && !atoi(evx)) {
                     HIP_RET((ensure_dyn_lds<conv_wgrad_dma_kernel<0>>(160 * 1024)));
                     hipLaunchKernelGGL(conv_wgrad_dma_kernel<0>, grid, block, sm, st, a, mpw, mph);
+                } else if (wgrad_v2_ok(a, lTW)) {
+                    // round 4: four accumulating waves (one per SIMD, k-block-deep fragment read-ahead) + one request-only wave
+                    if (lTW == 5) {
+                        HIP_RET((ensure_dyn_lds<conv_wgrad_dma2_kernel<5>>(160 * 1024)));
+                        hipLaunchKernelGGL(conv_wgrad_dma2_kernel<5>, grid, dim3(320, 1, 1), sm, st, a, mpw, mph);
+                    } else {
+                        HIP_RET((ensure_dyn_lds<conv_wgrad_dma2_kernel<4>>(160 * 1024)));
+                        hipLaunchKernelGGL(conv_wgrad_dma2_kernel<4>, grid, dim3(320, 1, 1), sm, st, a, mpw, mph);
+                    }
                 } else {
                     const char* evr = getenv("PMOE_WGRAD_REQ");             // A/B: 0 = round-2 request code, 1 = precomputed, at the top
                     const int req = a.ipe > 511 ? 0 : evr ? atoi(evr) : 1;
