@@ -153,12 +153,10 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
                                                              (tap * a.Cin + c0) << 1, 0, 0);
             };
             const int nch = a.Cin / CK, TT = nch * 9;
-#pragma unroll
-            for (int i = 0; i < 48; ++i)
-                if (i < NPIECE) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(smem + (i << 10)), 16, pv[i], 0, 0, 0);
-            req_w(0, 0, 0);
-            req_w(1, 1, 0);
-            int after = 16;                              // requests issued after W(tt): the group of the previous tap
+            // (the prologue -- first patch, weight tiles of taps 0 and 1 -- is requested by the EIGHT accumulating waves, as in the
+            //  8-wave kernel: one wave issues a request every 60-150 cycles, and 75 requests in a row from this wave alone cost the
+            //  two-chunk layers (layer2) 9 % -- profiles/r04_kernel_ab.log; from the first barrier on the stream is this wave's)
+            int after = 0;                               // own requests issued after W(tt): the group of the previous tap
             for (int ch = 0; ch < nch; ++ch) {
                 const int c0 = ch * CK;
                 const bool more = ch + 1 < nch;
@@ -290,14 +288,12 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
 #pragma unroll
     for (int u = 0; u < 8; ++u) zpre[u] = v4i{0, 0, 0, 0};
 
-    // ---- prologue: patch of chunk 0, weight tiles of taps 0 and 1
-    if constexpr (!PROD) {
+    // ---- prologue: patch of chunk 0, weight tiles of taps 0 and 1 (PROD: too -- every wave issues its share, see the producer)
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (i < my_pieces) dma_patch(i, 0, 0);
-        dma_w(0, 0, 0);
-        dma_w(1, 1, 0);
-    }
+    for (int i = 0; i < 6; ++i)
+        if (i < my_pieces) dma_patch(i, 0, 0);
+    dma_w(0, 0, 0);
+    dma_w(1, 1, 0);
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;
@@ -309,7 +305,9 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
             // W(tt) has landed for this wave once at most {W(tt+1), the patch piece issued in the previous iteration}
             // are outstanding (vmcnt counts in issue order)
             const bool prev_piece = tap >= 2 && tap <= 7 && more && (tap - 2) < my_pieces;
-            if constexpr (!PROD) {
+            if constexpr (PROD) {
+                if (tt == 0) VMCNT(0);                   // this wave's share of the prologue (W(1) too: the producer does not track it)
+            } else {
                 if (tt + 1 >= T) VMCNT(0);
                 else if (zpre_on && !more && tap == 1) VMCNT(10);      // W(tt) is older than both W(tt+1) and the 8 loads of tap 0
                 else if (prev_piece) VMCNT(3);
@@ -875,6 +873,9 @@ bool conv_dma_uses_mf16(const ConvArgs& a) {
 bool conv_dma_uses_producer(const ConvArgs& a) {
     const char* ev = getenv("PMOE_DMA_PRODUCER");
     if (ev && !atoi(ev)) return false;
+    // >= 4 channel chunks: layer3 / layer4 forward +8 % / +12 %; with two chunks (layer2) the tile is prologue + epilogue for a
+    // third of its time and the ninth wave buys nothing (-2 %): profiles/r04_kernel_ab.log.  PMOE_DMA_PRODUCER=2: every layer
+    if (a.Cin < 256 && !(ev && atoi(ev) == 2)) return false;
     return a.res_mode == PMOE_RES_NONE && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f;
 }
 
