@@ -16,7 +16,9 @@ SIMDS = 256 * 4
 
 def main():
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-    for f in (f for d in sys.argv[1:] for f in Path(d).rglob("*counter_collection.csv")):
+    args = [x for x in sys.argv[1:] if not x.startswith("--out=")]
+    out_name = next((x[6:] for x in sys.argv[1:] if x.startswith("--out=")), "r03_conv_pmc.json")
+    for f in (f for d in args for f in Path(d).rglob("*counter_collection.csv")):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
@@ -42,7 +44,7 @@ def main():
             rec["lds_active_per_cu_share"] = round(per.get("SQ_LDS_IDX_ACTIVE", 0.0) / 256 / cyc, 4)
             rec["lds_conflict_share_of_lds_cycles"] = round(per.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(per.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0), 4)
         out["kernels"][name] = rec
-    dst = Path(__file__).resolve().parents[1] / "profiles" / "r03_conv_pmc.json"
+    dst = Path(__file__).resolve().parents[1] / "profiles" / out_name
     dst.write_text(json.dumps(out, indent=1))
     for k, v in out["kernels"].items():
         print(f"{k[:70]:70s} n={v['launches']:3d} mfma_util {v.get('mfma_util')}  lds {v.get('lds_active_per_cu_share')}  conflicts {v.get('lds_conflict_share_of_lds_cycles')}")
