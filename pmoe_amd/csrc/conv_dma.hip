@@ -403,199 +403,13 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Round 4: conv3x3_dma_kernel with the roles SEPARATED, after the weight-gradient kernel showed what that buys
-// (conv_wgrad_dma2_kernel: +15..23 %).  Same workgroup tile (256 pixels x 128 output channels), same LDS image (two halo-patch
-// buffers, ring of four weight tap tiles, swizzles, zero fill by the buffer range check), same epilogue -- but
-//   * FOUR accumulating waves, one per SIMD, each 64 pixels x ALL 128 output channels (8 MFMAs per 6 fragment reads instead
-//     of 4 per 4: a quarter less LDS traffic), their fragments double-buffered one 16-channel step ahead, NO vector-memory
-//     instruction in the main loop;
-//   * FOUR request-only waves, one per SIMD, that own the LDS-DMA stream (a wave issues a request every 60-150 cycles: the
-//     stream needs several issuers, profiles/r04_kernel_ab.log) and its in-order vmcnt bookkeeping, per wave: before barrier(tt)
-//     a loader waits until only its own requests issued after W(tt) are outstanding (the group of the previous tap: patch
-//     pieces of the next chunk first, its share of the weight tile of tap tt+1 last);
-//   * the per-tap barrier EARLY: an accumulating wave executes barrier(tt+1) when it has issued the last fragment reads of tap
-//     tt -- before that tap's last eight MFMAs -- and requests the first fragments of tap tt+1 right behind it, so the matrix
-//     pipe never waits for the first LDS round trip of a tap.  Safe on the four-slot ring: the loaders overwrite the slot of
-//     tap tt-2 after barrier(tt), the reads that may still be in flight then belong to tap tt-1; the next chunk's patch goes to
-//     the buffer last read two chunks... one chunk ago, whose reads were consumed by MFMAs long before.
-// The prologue (first patch, weight tiles of taps 0 and 1) is requested by all eight waves.  Launches WITHOUT a prefetched side
-// input (forward, plain / activation-derivative data gradients): with the z / residual prefetch of PMOE_RES_DBN / PMOE_RES_ADD
-// (32 registers per read-out thread) the accumulating waves' 128 accumulators + 48 fragment registers no longer fit 256 -- hipcc
-// parked the prefetch in scratch, i.e. waited for it inside the main loop -- so those modes keep conv3x3_dma_kernel.
-// 32x32x16 MFMA shape only.  PMOE_DMA_V2=0: A/B switch back to conv3x3_dma_kernel<MF16, PROD>.
-__global__ void __launch_bounds__(NTHR, 2) conv3x3_dma2_kernel(const ConvArgs a, const int pbuf_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    STAMP_INIT
-    constexpr bool MF16 = false;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    const bool loader = wave >= 4;
-    const int wm = wave & 3, wn = 0;                     // accumulating wave wm: pixels [64 wm, 64 wm + 64) x all 128 couts
-
-    const int nblk = a.CoutP / BN;
-    const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned mb = flat / nblk;
-    const int nb = (int)(flat % nblk);
-    int t = (int)mb;
-    const int px_t = t % a.tiles_x; t /= a.tiles_x;
-    const int py_t = t % a.tiles_y; t /= a.tiles_y;
-    const int ng = t % a.n_groups;
-    const int e = t / a.n_groups;
-    const int lTW = a.lTW, lTH = a.lTH;
-    const int TW = 1 << lTW, TH = 1 << lTH;
-    const int PW = TW + 2, PH = TH + 2;
-    const int NPIX = a.TN * PH * PW;
-    const int NPIECE = (NPIX + 7) >> 3;
-    const int n0 = e * a.ipe + ng * a.TN, n_end = (e + 1) * a.ipe;
-    const int oy0 = py_t * TH, ox0 = px_t * TW;
-    const int cout0 = nb * BN;
-    char* wring = smem + 2 * pbuf_bytes;
-
-    const bf16* inb = (const bf16*)a.in + (size_t)n0 * a.H * a.W * a.in_ld + a.in_coff;
-    long long in_bytes = ((long long)(n_end - n0) * a.H * a.W * a.in_ld - a.in_coff) * 2;
-    if (in_bytes > 0x7ff00000ll) in_bytes = 0x7ff00000ll;
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, (int)in_bytes, 0x00020000);
-    const bf16* wb = (const bf16*)a.w + ((size_t)e * a.CoutP + cout0) * 9 * a.Cin;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, BN * 9 * a.Cin * 2, 0x00020000);
-    constexpr int OOB = 0x7ff80000;
-    auto patch_off = [&](int piece) {                    // per-lane source offset of patch piece `piece` (out of range: zero fill)
-        const int pp = (piece << 3) + (lane >> 3);
-        const int jj = lane & 7;
-        const int px = pp % PW;
-        const int rowq = pp / PW;
-        const int prow = rowq % PH, pn = rowq / PH;
-        const int Y = oy0 - 1 + prow, X = ox0 - 1 + px;
-        const bool ok = pp < NPIX && n0 + pn < n_end && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
-        return ok ? ((((pn * a.H + Y) * a.W + X) * a.in_ld) << 1) + ((jj ^ cswz(px)) << 4) : OOB;
-    };
-    auto w_off = [&](int piece) {
-        const int row = (piece << 3) + (lane >> 3);
-        return ((row * 9 * a.Cin) << 1) + (((lane & 7) ^ cswz(row)) << 4);
-    };
-    const int nchunks = a.Cin / CK;
-    const int T = nchunks * 9;
-
-    // ---- prologue: all eight waves request the first patch and the weight tiles of taps 0 and 1 (pieces striped over the waves)
-    {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int piece = wave + 8 * i;
-            if (piece < NPIECE)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(smem + (piece << 10)), 16, patch_off(piece), 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int piece = wave + 8 * i;
-            const int wo = w_off(piece);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(wring + (piece << 10)), 16, wo, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(wring + WSLOT + (piece << 10)), 16, wo, a.Cin << 1, 0, 0);
-        }
-    }
-
-    f32x16 acc[4][2];
-    if (loader) {
-        // ---------------- request-only wave lw: weight-tile pieces lw, lw + 4, ...; patch pieces lw + 4 j of each tap's eight
-        const int lw = wave - 4;
-        int pv[12], wv[4];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) pv[i] = patch_off(lw + 4 * i);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wv[i] = w_off(lw + 4 * i);
-        int after = 0;                                   // own requests issued after this wave's share of W(tt)
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int c0 = ch * CK;
-            const bool more = ch + 1 < nchunks;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int tt = ch * 9 + tap;
-                if (tt == 0) VMCNT(0);                   // the prologue share
-                else vm_wait_prod(after);
-                __builtin_amdgcn_s_barrier();
-                int n = 0;
-                if (tap >= 1 && tap <= 6 && more) {      // pieces 8 (tap - 1) + lw and + lw + 4 of the next chunk's patch
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int idx = 2 * (tap - 1) + j, piece = lw + 4 * idx;
-                        if (piece < NPIECE) {
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(smem + ((ch + 1) & 1) * pbuf_bytes + (piece << 10)),
-                                                                     16, pv[idx], (c0 + CK) << 1, 0, 0);
-                            ++n;
-                        }
-                    }
-                }
-                if (tt + 2 < T) {
-                    int ntap = tap + 2, nc0 = c0;
-                    if (ntap >= 9) { ntap -= 9; nc0 += CK; }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(wring + ((tt + 2) & (RING - 1)) * WSLOT + ((lw + 4 * i) << 10)),
-                                                                 16, wv[i], (ntap * a.Cin + nc0) << 1, 0, 0);
-                    n += 4;
-                }
-                after = n;
-            }
-        }
-    } else {
-        // ---------------- accumulating wave
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-        int pbase[2], pcol[2], aoffk[4];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int p = wm * 64 + mt * 32 + l31;
-            const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
-            pbase[mt] = ((pn * PH + my) * PW + mx) << LOG_RB;
-            pcol[mt] = mx;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) aoffk[ks] = l31 * RB + (((ks * 2 + h) ^ cswz(l31)) << 4);   // row nt*32 + l31: cswz(row) = cswz(l31)
-        v4i fa[2][4], fb[2][2];                          // fragments of 16-channel step s in buffer s & 1
-        auto rd = [&](int buf, int tt_, int ks) {        // fragment reads of (tap tt_ of the stream, step ks)
-            const int ch_ = tt_ / 9, tap_ = tt_ - ch_ * 9;
-            const char* wt = wring + (tt_ & (RING - 1)) * WSLOT;
-            const char* pt = smem + (ch_ & 1) * pbuf_bytes + (((tap_ / 3) * PW + (tap_ % 3)) << LOG_RB);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) fa[buf][nt] = *reinterpret_cast<const v4i*>(wt + nt * (32 * RB) + aoffk[ks]);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                fb[buf][mt] = *reinterpret_cast<const v4i*>(pt + pbase[mt] + (((ks * 2 + h) ^ cswz(pcol[mt] + (tap_ % 3))) << 4));
-        };
-        VMCNT(0);                                        // the prologue share
-        __builtin_amdgcn_s_barrier();                    // barrier(0): patch of chunk 0 and W(0) (W(1) too) are in LDS
-        rd(0, 0, 0);
-        for (int tt = 0; tt < T; ++tt) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < 3) rd((ks + 1) & 1, tt, ks + 1);
-                else if (tt + 1 < T) {
-                    __builtin_amdgcn_s_barrier();        // barrier(tt + 1), early: W(tt + 1) (and a new chunk's patch) are in LDS
-                    rd(0, tt + 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks & 1][nt]),
-                                                                              __builtin_bit_cast(bf16x8, fb[ks & 1][mt]),
-                                                                              acc[nt][mt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-#define DMA_NT 4
-#define DMA_STAGER (!loader)
-#include "conv_dma_epilogue.inc"
-#undef DMA_NT
-#undef DMA_STAGER
-}
-
+// Round 4, measured and REMOVED: this kernel with the roles separated like conv_wgrad_dma2_kernel (conv_wgrad.hip) -- four
+// accumulating waves of 64 pixels x 128 output channels (one per SIMD, fragments double-buffered a 16-channel step ahead, the
+// per-tap barrier executed before the tap's last eight MFMAs) + four request-only waves.  Correct (the conv suite passed on it) and
+// 4 / 8 / 14 % SLOWER on layer2 / 3 / 4 (profiles/r04_kernel_ab.log, block 4): per tap the workgroup issues 24 LDS-DMA requests for
+// 1024 cycles of MFMAs per SIMD; a wave issues one request per 60-150 cycles, so four issuers need 600-900 cycles per tap and
+// arrive at every barrier last, while the weight-gradient kernel's 80 requests per 4600-cycle m-block leave its four issuers idle
+// half of the time.  This kernel's request rate needs all eight waves as issuers, which is what it has.
 // ------------------------------------------------------------------------------------------------------------------------
 // Round 3: the three stride-2 3x3 forward convolutions (ResNet layer2-4 `.0.conv1`, torchvision BasicBlock with stride 2:
 // model/blocks/backbone.py:57-70) on the same LDS-DMA structure.  They ran on the generic register-staged kernel at
@@ -1063,13 +877,6 @@ bool conv_dma_uses_mf16(const ConvArgs& a) {
     return ev ? atoi(ev) != 0 : a.Cin >= 256;
 }
 
-// the separated-roles kernel (round 4): PMOE_DMA_V2=0 | 1 (read per launch)
-bool conv_dma_uses_v2(const ConvArgs& a) {
-    const char* ev = getenv("PMOE_DMA_V2");
-    if (ev && !atoi(ev)) return false;
-    return a.res_mode != PMOE_RES_DBN && a.res_mode != PMOE_RES_ADD;
-}
-
 // the producer-wave instantiation (round 4): forward launches -- nothing added to or derived from a side input in the epilogue
 bool conv_dma_uses_producer(const ConvArgs& a) {
     const char* ev = getenv("PMOE_DMA_PRODUCER");
@@ -1087,10 +894,7 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     // v_mfma_f32_16x16x32_bf16 for the layers with >= 4 channel chunks (interleaved A/B, profiles/r03_kernel_ab.log: layer3 forward
     // +0.6 %, data gradient +3.5 %; layer4 +3.5 % / +5 %; layer2 -3 % / +0.7 %: the shorter the main loop, the less the shape's
     // higher sustained clock buys).  PMOE_DMA_MF16=0 | 1 forces one shape (read per launch).
-    if (conv_dma_uses_v2(a)) {
-        HIP_RET((ensure_dyn_lds<conv3x3_dma2_kernel>(160 * 1024)));
-        hipLaunchKernelGGL(conv3x3_dma2_kernel, dim3(mblocks * (a.CoutP / BN)), dim3(NTHR), smem, st, a, pbuf);
-    } else if (conv_dma_uses_producer(a)) {
+    if (conv_dma_uses_producer(a)) {
         if (conv_dma_uses_mf16(a)) {
             HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<true, true>>(160 * 1024)));
             hipLaunchKernelGGL((conv3x3_dma_kernel<true, true>), dim3(mblocks * (a.CoutP / BN)), dim3(NTHR + 64), smem, st, a, pbuf);
