@@ -200,3 +200,37 @@ def test_buffer_stores_with_sgpr_offset_keep_their_data_registers(tmp_path):
                     break
                 w = re.match(r"v_(?!cmp)\S+ v\[?(\d+)", t)
                 assert not (w and lo <= int(w.group(1)) <= hi), (name, l.strip(), t)
+
+
+def test_vmcnt_counting_kernels_have_no_scratch_in_their_main_loops(tmp_path):
+    """the LDS-DMA kernels order their operands with COUNTED `s_waitcnt vmcnt(N)`; a register spill would put scratch
+    loads / stores -- which count in vmcnt too -- into the stream and let an MFMA read a tile that has not landed, silently.
+    Static guard on the ISA: conv3x3_dma_kernel<*> (incl. the producer-wave instantiations), conv3x3s2_dma_kernel<*>,
+    conv3x3_dma_f8_kernel and conv3x3_respipe_kernel<*> have NO scratch access at all; conv_wgrad_dma2_kernel's request-only
+    waves may spill set-up values once (they wait for vmcnt(0) anyway), but nothing between its accumulating waves' MFMAs."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.split("\n")[0]
+
+    def kernels(name):
+        out = tmp_path / f"{name}.s"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               str(REPO / "pmoe_amd" / "csrc" / f"{name}.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+        text = out.read_text()
+        for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+            yield m.group(1), m.group(2).split("\n")
+    checked = 0
+    for src, pats in (("conv_dma", ("conv3x3_dma_kernel", "conv3x3s2_dma_kernel", "conv3x3_dma_f8_kernel")),
+                      ("conv_res", ("conv3x3_respipe_kernel",))):
+        for sym, body in kernels(src):
+            if any(p in sym for p in pats):
+                bad = [l.strip() for l in body if "scratch_" in l]
+                assert not bad, (ver, sym, bad[:4])
+                checked += 1
+    for sym, body in kernels("conv_wgrad"):
+        if "conv_wgrad_dma2_kernel" in sym:
+            mf = [k for k, l in enumerate(body) if "v_mfma" in l]
+            assert mf and not [l for l in body[mf[0]:mf[-1] + 1] if "scratch_" in l], (ver, sym)
+            checked += 1
+    assert checked >= 10, checked
