@@ -504,8 +504,9 @@ def main():
                 pk = json.loads(tf.read_text()).get("per_kernel", {})
                 norm = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "")
                 hit = [v for k, v in pk.items() if norm(k).startswith(norm(mangled))]
-                if hit:
-                    traffic = hit[0]["fetch_bytes_per_launch_x2"] + hit[0]["write_bytes_per_launch"]
+                if hit:          # (several instantiations of one template: launch-weighted mean)
+                    traffic = (sum((v["fetch_bytes_per_launch_x2"] + v["write_bytes_per_launch"]) * v["launches"] for v in hit)
+                               / sum(v["launches"] for v in hit))
             # the dominant kernel = the MFMA kernel instantiation with the most time per step (forward / data-gradient and
             # weight-gradient kernels alike); every instantiation's own figure is in `conv_kernels`
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "rocprof_name": mangled,

@@ -95,6 +95,13 @@ typedef struct pmoe_conv_desc {
                            * matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 (plan code 8507), twice the bf16 rate */
     const float* bn_coef; /* PMOE_RES_DBN: [4][n / bn_ipe][cout] f32 = mean, invstd, gamma*invstd, beta of the BatchNorm  */
     int32_t bn_ipe;       /* PMOE_RES_DBN: images per BatchNorm parameter set (= ipe unless the conv runs per image)     */
+    int32_t shuffle_c;    /* round 4, > 0: nn.ConvTranspose2d(k=2, s=2) of model/blocks/unet.py:28-45 in ONE launch -- the layer is a 1x1
+                           * convolution into 4*shuffle_c channels (row (2 dy + dx)*shuffle_c + c of the packed weights) whose
+                           * output pixel (oy, ox) is scattered to (2 oy + dy, 2 ox + dx): `out` is then the DESTINATION
+                           * [n][2 ho][2 wo][out_ld] and receives channels [out_coff, out_coff + shuffle_c) (the "up" half of the
+                           * skip-concatenation buffer); cout = 4*shuffle_c, ho / wo powers of two.  conv1x1_direct_kernel only
+                           * (pmoe_conv2d_plan returns 1452 | 1454, anything else PMOE_ERR_UNSUPPORTED); replaces the
+                           * pmoe_pixel_shuffle2 launch and the [n][ho][wo][4c] intermediate. */
 } pmoe_conv_desc;
 
 int pmoe_conv2d_igemm(const pmoe_conv_desc* d, void* stream);
@@ -267,6 +274,13 @@ int pmoe_bn_bwd_reduce(const void* dy, const void* y, const void* x, const float
 int pmoe_bn_bwd_finalize(const float* part, int32_t nparts, int64_t count, float* dgamma, float* dbeta, float* c1,
                          float* c2, int32_t E, int32_t C, void* stream);
 /* dx = gamma*invstd * (g - c1 - xhat*c2); optionally also stores g (the masked grad) to gmask_out */
+/* round 4: y = [relu](BatchNorm(x)) into the channel window [y_coff, y_coff + C) of rows y_ld wide AND pooled = MaxPool2d(2, 2)(y)
+ * (dense [E*ipe][H/2][W/2][C]) in one pass -- nn.Sequential(conv3) followed by nn.MaxPool2d(2) of the U-Net's down path
+ * (model/blocks/unet.py:54-68) without re-reading y.  x dense [E*ipe][H][W][C]; H, W even; bit-identical to pmoe_bn_apply +
+ * pmoe_maxpool2s2_fwd. */
+int pmoe_bn_apply_pool2(const void* x, void* y, void* pooled, const float* scale, const float* shift, const float* mean,
+                        int32_t ipe, int32_t H, int32_t W, int32_t E, int32_t C, int32_t relu, int32_t y_ld, int32_t y_coff,
+                        int32_t dtype, void* stream);
 int pmoe_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                       const float* scale, const float* shift, const float* c1, const float* c2, void* dx, void* gmask_out,
                       int64_t rows_per_expert, int32_t E, int32_t C, int32_t relu, int32_t dtype, void* stream);

@@ -18,6 +18,7 @@ static ConvArgs to_args(const pmoe_conv_desc* d) {
     a.lTW = a.lTH = a.TN = a.n_groups = a.tiles_y = a.tiles_x = 0;
     a.kh = a.kw = d->ks; a.use_tapmap = 0; a.tapmap[0] = a.tapmap[1] = a.tapmap[2] = a.tapmap[3] = 0;
     a.out_step = 1; a.out_offy = a.out_offx = 0; a.OH = d->ho; a.OW = d->wo; a.prefetch = 0; a.stagger = 0;
+    a.shuf_c = d->shuffle_c > 0 ? d->shuffle_c : 0;
     return a;
 }
 
@@ -28,7 +29,9 @@ static int check_conv(const pmoe_conv_desc* d) {
     if (d->in_fp8 && (!d->w_fp8 || d->dtype != PMOE_DT_BF16 || d->in_ld % 16 || d->in_coff % 16)) return PMOE_ERR_ARG;
     if (d->in_ld % ve || d->in_coff % ve || d->out_ld % ve || d->out_coff % ve) return PMOE_ERR_ARG;
     if (d->res && (d->res_ld % ve || d->res_coff % ve)) return PMOE_ERR_ARG;
-    if (d->cout > d->coutp || d->in_coff + d->cin > d->in_ld || d->out_coff + d->cout > d->out_ld) return PMOE_ERR_ARG;
+    if (d->shuffle_c > 0 ? (d->cout != 4 * d->shuffle_c || d->shuffle_c % ve || d->out_coff + d->shuffle_c > d->out_ld || d->cout > d->coutp)
+                         : (d->cout > d->coutp || d->out_coff + d->cout > d->out_ld)) return PMOE_ERR_ARG;
+    if (d->in_coff + d->cin > d->in_ld) return PMOE_ERR_ARG;
     if (d->drop_p < 0.f || d->drop_p >= 1.f) return PMOE_ERR_ARG;
     if (d->res && d->res_mode == PMOE_RES_DBN &&
         (!d->bn_coef || !d->stats || d->dtype != PMOE_DT_BF16 || (d->bn_ipe > 0 && (d->bn_ipe % d->ipe || d->n % d->bn_ipe))))

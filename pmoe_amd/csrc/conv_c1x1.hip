@@ -51,9 +51,10 @@ __global__ void __launch_bounds__(256, 2) conv1x1_direct_kernel(ConvArgs a, int 
     const size_t in_img0 = a.in_shared ? 0 : (size_t)e * a.ipe, out_img0 = (size_t)e * a.ipe;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const bf16*>(a.in) + in_img0 * a.H * a.W * a.in_ld + a.in_coff), (short)0, (int)in_bytes, 0x00020000);
+    // shuf_c: the destination is the [ipe][2 Ho][2 Wo][out_ld] concatenation buffer (4x the pixels), addressed per store below
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<bf16*>(a.out) + out_img0 * a.Ho * a.Wo * a.out_ld + a.out_coff + cout0), (short)0,
-        (int)(out_bytes - (unsigned)cout0 * 2u), 0x00020000);
+        (void*)(reinterpret_cast<bf16*>(a.out) + out_img0 * a.Ho * a.Wo * a.out_ld * (a.shuf_c ? 4 : 1) + a.out_coff + (a.shuf_c ? 0 : cout0)),
+        (short)0, (int)(out_bytes - (a.shuf_c ? 0u : (unsigned)cout0 * 2u)), 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
     const int px_l = lane & 31, kh = lane >> 5;
     const unsigned old2 = (unsigned)a.out_ld * 2u;
@@ -64,6 +65,10 @@ __global__ void __launch_bounds__(256, 2) conv1x1_direct_kernel(ConvArgs a, int 
     constexpr int PPP = 64 / CHUNKS, PASSES = 32 / PPP;
     const int rb_c = lane % CHUNKS, rb_p = lane / CHUNKS;
     const bool chunk_ok = cout0 + rb_c * 8 < a.Cout;
+    // shuf_c: this lane's 8 output channels belong to one (dy, dx) of the 2x2 scatter and to channels [shuf_cc, +8) of the destination
+    const int shuf_q = a.shuf_c ? (cout0 + rb_c * 8) / a.shuf_c : 0;
+    const int shuf_cc = a.shuf_c ? (cout0 + rb_c * 8) - shuf_q * a.shuf_c : 0;
+    const int lWo = a.shuf_c ? __builtin_ctz(a.Wo) : 0, lHo = a.shuf_c ? __builtin_ctz(a.Ho) : 0;      // powers of two (conv_c1x1_plan)
     f32x2 s1[4], s2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s1[j] = s2[j] = f32x2{0.f, 0.f};
@@ -117,6 +122,14 @@ __global__ void __launch_bounds__(256, 2) conv1x1_direct_kernel(ConvArgs a, int 
             const int p = i * PPP + rb_p;
             const v4i v = tb[p * CHUNKS + (rb_c ^ (p & (CHUNKS - 1)))];
             const bool ok = t * 32 + p < npix;
+            if (a.shuf_c) {
+                // pixel (img, oy, ox) of the low-resolution map -> (img, 2 oy + dy, 2 ox + dx) of the destination
+                const int P = t * 32 + p;
+                const int ox = P & (a.Wo - 1), oy = (P >> lWo) & (a.Ho - 1), img = P >> (lWo + lHo);
+                const unsigned dpix = (unsigned)((img * 2 * a.Ho + 2 * oy + (shuf_q >> 1)) * 2 * a.Wo + 2 * ox + (shuf_q & 1));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs_out,
+                                                       (int)(ok && chunk_ok ? dpix * old2 + (unsigned)shuf_cc * 2u : OOB), 0, 0);
+            } else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs_out,
                                                    (int)(ok && chunk_ok ? (unsigned)p * old2 + (unsigned)rb_c * 16u : OOB), (int)osoff, 0);
             if (a.stats && ok) {
@@ -182,6 +195,8 @@ bool conv_c1x1_plan(const ConvArgs& a, int dtype, int* wgs_per_expert, int* tile
     if (dtype != PMOE_DT_BF16 || a.w_fp8 || a.ks != 1 || a.pad != 0 || a.dilate || a.kh != 1 || a.kw != 1) return false;
     if (a.stride != 1 && a.stride != 2) return false;
     if (a.use_tapmap || a.out_step != 1) return false;
+    if (a.shuf_c && (a.stride != 1 || a.stats || a.Cout != 4 * a.shuf_c || a.shuf_c % 8 || (a.Ho & (a.Ho - 1)) || (a.Wo & (a.Wo - 1)) ||
+                     (long long)a.ipe * a.Ho * a.Wo * 4 * a.out_ld * 2 >= 0xfff00000ll)) return false;
     if (a.Cin % 16 || a.Cin < 64 || a.Cin > 512 || a.CoutP % 64 || a.Cout % 8) return false;
     if (a.act != PMOE_ACT_NONE || a.res_mode != PMOE_RES_NONE || a.drop_p > 0.f) return false;
     if (a.N % a.ipe || a.Ho != (a.H - 1) / a.stride + 1 || a.Wo != (a.W - 1) / a.stride + 1) return false;
@@ -208,7 +223,7 @@ int conv_c1x1_launch(const ConvArgs& a, hipStream_t st) {
     size_t sm;
     if (!conv_c1x1_plan(a, PMOE_DT_BF16, &wpe, &tpe, &slabs, &m, &sm)) return PMOE_ERR_ARG;
     const long long in_b = (long long)a.ipe * a.H * a.W * a.in_ld * 2 - (long long)a.in_coff * 2;
-    const long long out_b = (long long)a.ipe * a.Ho * a.Wo * a.out_ld * 2 - (long long)a.out_coff * 2;
+    const long long out_b = (long long)a.ipe * a.Ho * a.Wo * a.out_ld * 2 * (a.shuf_c ? 4 : 1) - (long long)a.out_coff * 2;
     const int kch = (a.Cin + 127) / 128;
     dim3 grid(wpe * slabs, a.N / a.ipe), block(256);
     if (m == 4) {

@@ -594,6 +594,11 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
         }
         return launch_dtype<bf16, fp8>(a, st, nullptr);
     }
+    if (a.shuf_c) {                                  // ConvTranspose2d scatter fused into the store: the 1x1 direct kernel only
+        int wpe, tpe, slabs, mt;
+        size_t sm;
+        return conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &sm) ? conv_c1x1_launch(a, st) : PMOE_ERR_UNSUPPORTED;
+    }
     if (a.res_mode == PMOE_RES_DBN) {                // BatchNorm-backward reductions in the epilogue: the two LDS-DMA kernels only
         ResPlan plan;
         int pb, mpw, mph, mb;
@@ -646,6 +651,11 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         int mb = 0, cfg = 0;
         const int rc = dtype == PMOE_DT_BF16 && !a.dilate ? launch_dtype<bf16, fp8>(c, nullptr, &mb, &cfg) : PMOE_ERR_ARG;
         return rc ? rc : cfg;
+    }
+    if (a.shuf_c) {
+        int wpe, tpe, slabs, mt;
+        size_t smx;
+        return conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &smx) ? 1450 + mt : PMOE_ERR_UNSUPPORTED;
     }
     if (a.res_mode == PMOE_RES_DBN) {
         ResPlan plan;

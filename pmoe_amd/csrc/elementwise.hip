@@ -317,6 +317,56 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 4: y = relu(BatchNorm(z)) AND MaxPool2d(2, 2)(y) in one pass (the U-Net's down blocks, blocks/unet.py:54-68: the last
+// BatchNorm + ReLU of a block writes the skip half of the concatenation buffer, the pooled tensor feeds the next block): a thread
+// owns one 2x2 pixel quad x one 16-byte channel vector -- 4 loads, 4 stores + the pooled store; the separate pooling launch read
+// y again (2.5 ms per PU-Net expert step).  max of the ROUNDED values = rounded max (rounding is monotone): bit-identical to the pair.
+template <typename T>
+__global__ void __launch_bounds__(256) bn_apply_pool2_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ pooled,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, int ipe, int H, int W, int C, int relu,
+                                                            int y_ld, int y_coff) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int CV = C / VE;
+    const int e = blockIdx.y, Ho = H / 2, Wo = W / 2;
+    const long long nq = (long long)ipe * Ho * Wo * CV;
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cv = (int)(i0 % CV);                   // CV is a power of two dividing 256 * gridDim.x: constant over the grid stride
+    float sc[VE], sh[VE], mu[VE];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) {
+        sc[k] = scale[e * C + cv * VE + k]; sh[k] = shift[e * C + cv * VE + k]; mu[k] = mean[e * C + cv * VE + k];
+    }
+    const size_t rpe = (size_t)ipe * H * W;
+    for (long long i = i0; i < nq; i += (long long)gridDim.x * 256) {
+        long long t = i / CV;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const size_t r00 = (size_t)e * rpe + ((size_t)n * H + 2 * oy) * W + 2 * ox;
+        float m[VE];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t r = r00 + (q >> 1) * (size_t)W + (q & 1);
+            float xv[VE];
+            unpack16<T>(ldg16(x + r * C + (size_t)cv * VE), xv);
+#pragma unroll
+            for (int k = 0; k < VE; ++k) {
+                xv[k] = (xv[k] - mu[k]) * sc[k] + sh[k];
+                if (relu) xv[k] = fmaxf(xv[k], 0.f);
+            }
+            const v4i pk = pack16<T>(xv);
+            stg16(y + r * y_ld + y_coff + (size_t)cv * VE, pk);
+            float rr[VE];
+            unpack16<T>(pk, rr);                     // the pooled value is the max of the STORED values
+#pragma unroll
+            for (int k = 0; k < VE; ++k) m[k] = q ? fmaxf(m[k], rr[k]) : rr[k];
+        }
+        stg16(pooled + ((size_t)e * (rpe / 4) + ((size_t)n * Ho + oy) * Wo + ox) * C + (size_t)cv * VE, pack16<T>(m));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MaxPool2d(kernel 3, stride 2, pad 1).  First maximum in (row, col) scan order wins, as in
 // ATen's CPU kernel; the winning tap (0..8) is kept per element for the backward gather.
 template <typename T>
@@ -787,6 +837,22 @@ int pmoe_bn_apply(const void* x, const void* res, void* y, const float* scale, c
         hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(nvec, 2048), E), dim3(256), 0, (hipStream_t)stream,
                            (const T*)x, (const T*)res, (T*)y, scale, shift, mean, (long long)rows_per_expert, C, relu,
                            y_ld, y_coff, log_cv, (unsigned char*)y_fp8, in_scale);
+        return (int)hipGetLastError();
+    });
+}
+
+int pmoe_bn_apply_pool2(const void* x, void* y, void* pooled, const float* scale, const float* shift, const float* mean,
+                        int32_t ipe, int32_t H, int32_t W, int32_t E, int32_t C, int32_t relu, int32_t y_ld, int32_t y_coff,
+                        int32_t dtype, void* stream) {
+    if (!x || !y || !pooled || ipe < 1 || E < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return PMOE_ERR_ARG;
+    DISPATCH_DT(dtype, {
+        constexpr int VE = 16 / (int)sizeof(T);
+        if (C % VE || !pow2(C / VE) || C / VE > 256) return PMOE_ERR_ARG;
+        if (y_ld <= 0) { y_ld = C; y_coff = 0; }
+        if (y_ld % VE || y_coff % VE || y_coff + C > y_ld) return PMOE_ERR_ARG;
+        const long long nq = (long long)ipe * (H / 2) * (W / 2) * (C / VE);
+        hipLaunchKernelGGL((bn_apply_pool2_kernel<T>), dim3(grid_for(nq, 2048), E), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                           (T*)y, (T*)pooled, scale, shift, mean, ipe, H, W, C, relu, y_ld, y_coff);
         return (int)hipGetLastError();
     });
 }

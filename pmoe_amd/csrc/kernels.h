@@ -35,6 +35,8 @@ struct ConvArgs {
     int bn_ipe;
     int stagger;           // launcher: waves 4-7 of the 8-wave tile run one k-substep behind their SIMD partners
     int prefetch;          // launcher: 2 patch buffers, the next channel chunk's halo patch is fetched under the MFMAs
+    int shuf_c;            // > 0 (1x1 direct kernel, round 4): ConvTranspose2d(k2,s2) scatter fused -- out is [N][2Ho][2Wo][out_ld], output
+                           // channel q*shuf_c + c (q = 2 dy + dx) goes to pixel (2 oy + dy, 2 ox + dx), channel out_coff + c
 };
 
 struct WgradArgs {

@@ -633,7 +633,7 @@ class ExpertGroupEngine:
                             self._tab("rv", layer), layer.momentum, layer.eps, False, scale, shift, mean, invstd, E, C_)
         return scale, shift, mean, invstd
 
-    def _bn(self, z, layer, relu, res=None, stats=None, out=None, out_coff=0, want_gap=False, want_f8=False):
+    def _bn(self, z, layer, relu, res=None, stats=None, out=None, out_coff=0, want_gap=False, want_f8=False, pool_to=None):
         """y = [relu](bn(z) [+ res]); train mode: batch statistics (fused conv partials or a colstats pass).
         want_gap: the pass also leaves the per-image channel sums of y in ``y.gap_part`` (part, nparts) for the ECA block that
         follows (_eca_conv_folded), instead of a separate pass over y."""
@@ -658,6 +658,9 @@ class ExpertGroupEngine:
             part = torch.empty(n, nparts, C_, dtype=F32, device=self.dev)
             ops.bn_apply_gap(z.t, y.t, scale, shift, mean, part, nparts, self.B, relu)
             y.gap_part = (part, nparts)
+        elif pool_to is not None and res is None:
+            # round 4: the pass also leaves MaxPool2d(2, 2) of its output in ``pool_to`` (U-Net down blocks, engine_punet._unet_fwd)
+            ops.bn_apply_pool2(z.t, y.t, pool_to, scale, shift, mean, self.B, E, C_, relu, y_coff=y.coff)
         else:
             if want_f8 and out is None and self.dtype == torch.bfloat16:
                 y.f8 = torch.empty(y.t.shape, dtype=torch.uint8, device=self.dev)      # e4m3(y * in_scale) for the fp8 consumer
@@ -1164,13 +1167,13 @@ class ExpertGroupEngine:
             o = self._conv_bn(aA, blk["conv2"], blk["bn2"], relu=True, res=idn, want_f8=nxt is not None and nxt.fp8)
         self._gap_to(o, feat, 0)
 
-    def _conv_bn(self, x, conv, bn, relu, res=None, out=None, want_f8=False):
+    def _conv_bn(self, x, conv, bn, relu, res=None, out=None, want_f8=False, pool_to=None):
         """[relu](bn(conv(x)) [+ res]).  Training / taped: conv (+ fused statistics) then the BatchNorm passes.
         Inference (eval mode, nothing taped): the BatchNorm is FOLDED into the conv -- weights scaled per output channel,
         beta - mean*scale as the bias, residual add and ReLU in the conv epilogue: no pass over the activation at all."""
         if self.training or self.taping or not self.fold_bn_eval or conv.w_f8 is not None:      # (the fp8 policy is not folded)
             z, st = self._conv_stats(x, conv)
-            return self._bn(z, bn, relu=relu, res=res, stats=st, out=out, want_f8=want_f8)
+            return self._bn(z, bn, relu=relu, res=res, stats=st, out=out, want_f8=want_f8, pool_to=pool_to)
         E = self.E
         key = (self.dtype, str(self.dev)) + tuple(p._version for p in conv.weights) + tuple(
             v for m in bn.mods for v in (m.weight._version, m.bias._version, m.running_mean._version, m.running_var._version))

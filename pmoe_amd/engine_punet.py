@@ -186,14 +186,18 @@ class PUNetEngine(ExpertGroupEngine):
                 m.running_var.copy_(l.shadow["rv"][:c])
 
     # ------------------------------------------------------------------ PU-Net forward
-    def _conv3(self, x, blk, out=None):
-        a = self._conv_bn(x, blk["c1"], blk["bn1"], relu=True)
-        return self._conv_bn(a, blk["c2"], blk["bn2"], relu=True, out=out)
+    fuse_bn_pool = True            # round 4: the down blocks' last BatchNorm + ReLU pass also writes MaxPool2d(2, 2) of its output
 
-    def _maxpool2(self, x, cat=None):
+    def _conv3(self, x, blk, out=None, pool_to=None):
+        a = self._conv_bn(x, blk["c1"], blk["bn1"], relu=True)
+        return self._conv_bn(a, blk["c2"], blk["bn2"], relu=True, out=out, pool_to=pool_to)
+
+    def _maxpool2(self, x, cat=None, fused=None):
+        """``fused``: the pooled tensor was already written by the pass that produced x (_bn, pool_to): only the tape entry is added."""
         n, h, w, _ = x.t.shape
-        y = Var(self._new(n, h // 2, w // 2, x.c))
-        ops.maxpool2_fwd(x.t, y.t, c=x.c, x_coff=x.coff)      # x may be the skip window of a concatenation buffer
+        y = Var(fused if fused is not None else self._new(n, h // 2, w // 2, x.c))
+        if fused is None:
+            ops.maxpool2_fwd(x.t, y.t, c=x.c, x_coff=x.coff)      # x may be the skip window of a concatenation buffer
         y.needs_grad = x.needs_grad
         if self.taping and y.needs_grad:
             def bwd():
@@ -233,13 +237,20 @@ class PUNetEngine(ExpertGroupEngine):
         for i in range(4):
             c = U["dwn"][i]["c2"].cout
             cat = Var(self._new(n, hh, ww, 2 * c))          # torch.cat([x_k, up], 1) buffer (unet.py:72)
-            a = self._conv3(h, U["dwn"][i], out=cat)       # the block's last BatchNorm writes the skip half directly
+            # the block's last BatchNorm writes the skip half directly -- and, fused, the pooled tensor of the next level
+            # (train mode or taped: the eval-mode fold has no BatchNorm pass to fuse into)
+            fused = (self._new(n, hh // 2, ww // 2, c) if self.fuse_bn_pool and (self.training or self.taping or not self.fold_bn_eval)
+                     else None)
+            a = self._conv3(h, U["dwn"][i], out=cat, pool_to=fused)
             cats.append(cat)
-            h = self._maxpool2(a, cat)
+            h = self._maxpool2(a, cat, fused=fused)
             hh, ww = hh // 2, ww // 2
         x5 = h = self._conv3(h, U["dwn"][4])
         for j in range(4):
             cat, up = cats[3 - j], U["up"][j]
+            if not self.taping and self.fuse_upconv_shuffle and self._upconv_fused(h, up, cat):
+                h = self._conv3(cat, U["up_forw"][j])
+                continue
             t = self._conv(h, up, bias=True)                                  # [n, h, w, 4*Cout]
             ops.pixel_shuffle2(t.t, cat.t, up.c_up, dst_coff=up.c_up)
             if self.taping and t.needs_grad:
@@ -247,6 +258,22 @@ class PUNetEngine(ExpertGroupEngine):
                 self.tape.append(lambda t=t, up=up, cat=cat: self._up_bwd(t, up, cat))
             h = self._conv3(cat, U["up_forw"][j])
         return self._conv(h, U["out"], bias=True), x5
+
+    fuse_upconv_shuffle = True     # round 4: ConvTranspose2d = 1x1 GEMM whose store scatters the 2x2 blocks itself (frozen / untaped path)
+
+    def _upconv_fused(self, h, up, cat):
+        """ConvTranspose2d(k2, s2) + its half of torch.cat in ONE launch: the 1x1 direct kernel writes channel (2 dy + dx) c_up + c
+        of pixel (y, x) to cat[2 y + dy, 2 x + dx, c_up + c] (pmoe_conv_desc.shuffle_c) -- no [n, h, w, 4 c_up] intermediate, no
+        pixel-shuffle launch.  False: this shape is not served (small maps, sides that are not powers of two): the caller runs the pair."""
+        kw = dict(cin=up.cinp, cout=up.cout_st, coutp=up.coutp, ipe=self.B, ks=1, stride=1, pad=0, in_coff=h.coff,
+                  out_coff=up.c_up, bias=up.bias_packed, shuffle2_c=up.c_up)
+        if h.t.dtype != torch.bfloat16 or up.cout_st != 4 * up.c_up:
+            return False
+        if ops.conv2d(h.t, up.w_fwd, cat.t, plan_only=True, **kw) not in (1452, 1454):
+            return False
+        ops.set_meta(flop=2.0 * h.t.shape[0] * h.t.shape[1] * h.t.shape[2] * up.cout * up.cin, name=up.name + "+shuffle")
+        ops.conv2d(h.t, up.w_fwd, cat.t, **kw)
+        return True
 
     def _entry_fwd(self, masks):
         eb = self.entry

@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("res_mode", C.c_int32),
         ("drop_p", C.c_float), ("seed", C.c_uint64), ("dtype", C.c_int32),
         ("w_fp8", C.c_int32), ("in_scale", C.c_float), ("out_scale", C.c_void_p),
-        ("in_fp8", C.c_int32), ("bn_coef", C.c_void_p), ("bn_ipe", C.c_int32),
+        ("in_fp8", C.c_int32), ("bn_coef", C.c_void_p), ("bn_ipe", C.c_int32), ("shuffle_c", C.c_int32),
     ]
 
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "pmoe_conv2d_wgrad_ws_floats": [C.POINTER(WgradDesc)],
     "pmoe_conv2d_wgrad_plan": [C.POINTER(WgradDesc)],
     "pmoe_mlp_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "pmoe_bn_apply_pool2": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights_fp8": [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "pmoe_pack_conv_weights_scaled": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

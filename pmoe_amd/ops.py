@@ -28,12 +28,18 @@ def _nhwc(t, name):
 
 def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=False, in_shared=False,
            in_coff=0, out_coff=0, res=None, res_coff=0, res_mode=hip.RES_NONE, bias=None, act=hip.ACT_NONE,
-           drop_p=0.0, seed=0, stats=None, plan_only=False, out_scale=None, in_scale=1.0, bn_coef=None, bn_ipe=0):
+           drop_p=0.0, seed=0, stats=None, plan_only=False, out_scale=None, in_scale=1.0, bn_coef=None, bn_ipe=0, shuffle2_c=0):
     """out[..., out_coff:out_coff+cout] = epilogue(conv(x[..., in_coff:in_coff+cin], w)).
     ``x`` [Nin,H,W,ldx], ``out`` [N,Ho,Wo,ldo] preallocated; also used for dgrad and grouped GEMM.
     ``plan_only``: launch nothing, return the kernel-instantiation code of ``pmoe_conv2d_plan`` (include/pmoe_hip.h)."""
     nin, h, w_, ldx = _nhwc(x, "x")
     n, ho, wo, ldo = _nhwc(out, "out")
+    if shuffle2_c:
+        # ConvTranspose2d(k2, s2) in one launch (pmoe_conv_desc.shuffle_c): ``out`` is the DESTINATION [N, 2 Ho, 2 Wo, ld]; the 1x1
+        # convolution's own output map has half its sides
+        if ho % 2 or wo % 2 or ks != 1 or cout != 4 * shuffle2_c:
+            raise ValueError("conv2d: shuffle2_c needs a 1x1 layer with 4 * shuffle2_c outputs and an even-sided destination")
+        ho, wo = ho // 2, wo // 2
     w_fp8 = w_packed.dtype == torch.uint8          # e4m3 bytes (pack_conv_weights_fp8): BASELINE config 5
     in_fp8 = w_fp8 and x.dtype == torch.uint8      # ... and e4m3 activations (bn_apply's fp8 side output): the block-scaled MFMA kernel
     if (x.dtype != out.dtype and not in_fp8) or (w_packed.dtype != out.dtype and not w_fp8):
@@ -54,6 +60,7 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
     d.ks, d.stride, d.pad, d.dilate = ks, stride, pad, int(dilate)
     d.act, d.res_mode = act, res_mode if res is not None else hip.RES_NONE
     d.drop_p, d.seed, d.dtype = float(drop_p), int(seed), dt(out)
+    d.shuffle_c = int(shuffle2_c)
     if w_fp8:
         d.w_fp8, d.in_scale, d.out_scale = 1, float(in_scale), ptr(out_scale, "out_scale", torch.float32)
         d.in_fp8 = int(in_fp8)
@@ -267,6 +274,16 @@ def bn_apply(x, res, y, scale, shift, mean, rpe, E, C_, relu, y_coff=0, y_fp8=No
                                ptr(mean, "mean", torch.float32), rpe,
                                E, C_, int(relu), y.shape[-1], y_coff, dt(x), ptr(y_fp8, "y_fp8", torch.uint8),
                                float(in_scale), stream_ptr()), "pmoe_bn_apply")
+
+
+def bn_apply_pool2(x, y, pooled, scale, shift, mean, ipe, E, C_, relu, y_coff=0):
+    """y[..., y_coff:y_coff+C] = [relu]((x - mean)*scale + shift) and pooled = MaxPool2d(2,2)(that), one pass (U-Net down blocks)."""
+    n, h, w_, c = _nhwc(x, "x")
+    if c != C_ or tuple(pooled.shape) != (n, h // 2, w_ // 2, C_) or tuple(y.shape[:3]) != (n, h, w_) or n != E * ipe:
+        raise ValueError("bn_apply_pool2: x [E*ipe,H,W,C], y [E*ipe,H,W,ld], pooled [E*ipe,H/2,W/2,C]")
+    check(load().pmoe_bn_apply_pool2(ptr(x, "x"), ptr(y, "y", x.dtype), ptr(pooled, "pooled", x.dtype), ptr(scale), ptr(shift),
+                                     ptr(mean, "mean", torch.float32), ipe, h, w_, E, C_, int(relu), y.shape[-1], y_coff, dt(x),
+                                     stream_ptr()), "pmoe_bn_apply_pool2")
 
 
 def bn_bwd_reduce(dy, y, x, mean, invstd, scale, shift, rpe, E, C_, relu, part, nparts, gmask=None):

@@ -1203,3 +1203,53 @@ def test_mlp_wgrad_one_launch(E, ipe, K, Kr, Nn, Nr, shared, xcoff, ycoff):
         de = dy[e * ipe:(e + 1) * ipe, ycoff:ycoff + Nr]
         close(grads[e], de.t() @ xe, BF, f"mlp wgrad e{e}")
         close(bg[e], de.sum(0), BF, f"mlp bias grad e{e}")
+
+
+@pytest.mark.parametrize("E,ipe,cin,c_up,H,W", [(1, 4, 128, 64, 64, 64), (2, 3, 512, 256, 16, 32), (1, 2, 256, 128, 64, 128)])
+def test_upconv_with_fused_pixel_shuffle(E, ipe, cin, c_up, H, W):
+    """pmoe_conv_desc.shuffle_c (round 4): ConvTranspose2d(k=2, s=2) (blocks/unet.py:28-45) as ONE launch -- the 1x1 direct kernel
+    scatters its 4*c_up output channels to the 2x2 block itself.  Bit-identical to the 1x1 launch + pmoe_pixel_shuffle2 pair it
+    replaces, the other half of the concatenation buffer untouched, and equal to F.conv_transpose2d on the CPU."""
+    g = torch.Generator().manual_seed(cin + c_up + H)
+    BF = torch.bfloat16
+    N = E * ipe
+    x = rnd((N, cin, H, W), g, BF)
+    wt = [rnd((cin, c_up, 2, 2), g, BF, (1.0 / cin) ** 0.5) for _ in range(E)]            # ConvTranspose2d weight layout
+    bias = [torch.randn(c_up, generator=g) * 0.1 for _ in range(E)]
+    ws = [w.permute(2, 3, 1, 0).reshape(4 * c_up, cin, 1, 1).contiguous() for w in wt]       # rows (dy, dx, c)
+    wf, _, _keep = pack(ws, 1, BF)
+    bp = torch.stack([b.repeat(4) for b in bias]).to(DEV).contiguous()
+    xd = nhwc(x, cin, BF)
+    kw = dict(cin=cin, cout=4 * c_up, coutp=4 * c_up, ipe=ipe, ks=1, stride=1, pad=0, bias=bp)
+    cat_a = torch.full((N, 2 * H, 2 * W, 2 * c_up), 3.0, dtype=BF, device=DEV)
+    assert ops.conv2d(xd, wf, cat_a, plan_only=True, out_coff=c_up, shuffle2_c=c_up, **kw) in (1452, 1454)
+    ops.conv2d(xd, wf, cat_a, out_coff=c_up, shuffle2_c=c_up, **kw)
+    t = torch.empty(N, H, W, 4 * c_up, dtype=BF, device=DEV)
+    ops.conv2d(xd, wf, t, **kw)
+    cat_b = torch.full((N, 2 * H, 2 * W, 2 * c_up), 3.0, dtype=BF, device=DEV)
+    ops.pixel_shuffle2(t, cat_b, c_up, dst_coff=c_up)
+    assert torch.equal(cat_a, cat_b)
+    assert (cat_a[..., :c_up] == 3.0).all()
+    for e in range(E):
+        ref = F.conv_transpose2d(x[e * ipe:(e + 1) * ipe], wt[e], bias[e], stride=2)
+        close(from_nhwc(cat_a[e * ipe:(e + 1) * ipe, :, :, c_up:], c_up), ref, BF, f"fused transposed conv e{e}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("E,ipe,C,H,W,coff,ld", [(1, 3, 64, 32, 48, 0, 128), (2, 2, 128, 16, 16, 0, 256), (1, 2, 512, 8, 8, 0, 512)])
+def test_bn_apply_with_fused_maxpool2(dtype, E, ipe, C, H, W, coff, ld):
+    """pmoe_bn_apply_pool2 (round 4): BatchNorm + ReLU into the skip window of a concatenation buffer AND MaxPool2d(2, 2) of it in
+    one pass: bit-identical to pmoe_bn_apply + pmoe_maxpool2s2_fwd, rest of the buffer untouched."""
+    g = torch.Generator().manual_seed(C + H)
+    N = E * ipe
+    x = nhwc(rnd((N, C, H, W), g, dtype, 2.0), C, dtype)
+    scale, shift, mean = (torch.randn(E, C, generator=g).to(DEV) for _ in range(3))
+    ya = torch.full((N, H, W, ld), 5.0, dtype=dtype, device=DEV)
+    pa = torch.empty(N, H // 2, W // 2, C, dtype=dtype, device=DEV)
+    ops.bn_apply_pool2(x, ya, pa, scale, shift, mean, ipe, E, C, True, y_coff=coff)
+    yb = torch.full((N, H, W, ld), 5.0, dtype=dtype, device=DEV)
+    pb = torch.empty_like(pa)
+    ops.bn_apply(x, None, yb, scale, shift, mean, ipe * H * W, E, C, True, y_coff=coff)
+    ops.maxpool2_fwd(yb, pb, c=C, x_coff=coff)
+    assert torch.equal(ya, yb) and torch.equal(pa, pb)
+    assert ld == C or (ya[..., C:] == 5.0).all()
