@@ -455,6 +455,9 @@ def main():
             if code >= 8000:                      # e4m3 operands (BASELINE config 5): same tiles, TL = fp8
                 r, m, n = symbol(code - 8000)
                 return r.replace("<bf16,", "<bf16+e4m3,"), m.replace(f"E{tname}Ev8ConvArgs", "E3fp8Ev8ConvArgs"), n
+            if code in (5047, 5057):              # ... persistent, the producer wave's request stream running across tiles (round 4)
+                tf = "true" if code == 5057 else "false"
+                return f"conv3x3_dma_stream_kernel<{tf}>", f"void (anonymous namespace)::conv3x3_dma_stream_kernel<{tf}>", 1
             if code in (5007, 5017, 5027, 5037):  # LDS-DMA staged 3x3 kernel (conv_dma.hip): 32x32x16 | 16x16x32 MFMA instantiation;
                 tf = "true" if code in (5017, 5037) else "false"          # + 20: the producer-wave instantiation (forward launches)
                 pr = "true" if code >= 5027 else "false"

@@ -403,6 +403,277 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Round 4: PERSISTENT workgroups whose request stream runs ACROSS tile boundaries (forward launches: the modes of the producer-wave
+// instantiation above).  A tile of conv3x3_dma_kernel spends 7.5 k cycles in its prologue (first patch + two weight tiles: a cold
+// round trip) and 6 k in its epilogue before / after a main loop of 25 k (two chunks: layer2, the 128-channel U-Net levels) to 100 k
+// (layer4) -- and one workgroup per CU (150 KiB of LDS) means nothing overlaps them.  Round 2 tried persistence and lost 4-8 %: the
+// epilogue's stores shared the in-order vmcnt counter with the prefetch.  With a request-only ninth wave that problem is gone -- the
+// stream and its counter belong to the producer alone -- so here the producer treats the tiles of its workgroup as ONE stream of
+// chunks and taps: during the last chunk of tile i it requests the first patch of tile i+1 (into the patch buffer that chunk does not
+// use) and at its last two taps the weight tiles of taps 0 and 1 of tile i+1 (the ring simply continues, slot = stream tap & 3).
+// The eight accumulating waves go main loop -> epilogue -> main loop; their epilogue stages the tile in what the stream is NOT
+// filling at that moment: the patch buffer of the chunk just finished (rows 0..159) and the two ring slots that hold neither W(0)
+// nor W(1) of the next tile (rows 160..223, 224..255).  The producer joins the epilogue's barriers (s_barrier counts every live wave)
+// and issues nothing between the last tap of a tile and the first barrier of the next one.
+// PMOE_DMA_STREAM=0: A/B switch back to the one-tile-per-workgroup kernels.
+template <bool MF16>
+__global__ void __launch_bounds__(NTHR + 64, 1) conv3x3_dma_stream_kernel(const ConvArgs a_in, const int pbuf_bytes, const int ntiles,
+                                                                          const int magic_pw, const int magic_ph) {
+    ConvArgs a = a_in;
+    a.res_mode = PMOE_RES_NONE; a.res = nullptr; a.bias = nullptr; a.act = PMOE_ACT_NONE; a.drop_p = 0.f; a.bn = nullptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) & 3, wn = wave & 1;
+    const int nblk = a.CoutP / BN;
+    const int lTW = a.lTW, lTH = a.lTH;
+    const int TW = 1 << lTW, TH = 1 << lTH;
+    const int PW = TW + 2, PH = TH + 2;
+    const int NPIX = a.TN * PH * PW;
+    const int NPIECE = (NPIX + 7) >> 3;
+    char* wring = smem + 2 * pbuf_bytes;
+    const int nchunks = a.Cin / CK;
+    const int T = nchunks * 9;
+    const int G = (int)gridDim.x;
+    // step s of workgroup b: logical tile s*G + xcd_remap(b, G) -- the workgroups of one XCD walk neighbouring tiles at every step
+    const int b0 = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int nbar_epi = a.stats ? 4 : 2;               // barriers of the epilogue (conv_dma_epilogue.inc, one-phase read-out)
+    struct Tile { int e, n0, n_end, oy0, ox0, cout0; unsigned mb; };
+    auto decode = [&](int L) {
+        Tile q;
+        q.mb = (unsigned)(L / nblk);
+        const int nb = L % nblk;
+        int t = (int)q.mb;
+        const int px_t = t % a.tiles_x; t /= a.tiles_x;
+        const int py_t = t % a.tiles_y; t /= a.tiles_y;
+        const int ng = t % a.n_groups;
+        q.e = t / a.n_groups;
+        q.n0 = q.e * a.ipe + ng * a.TN; q.n_end = (q.e + 1) * a.ipe;
+        q.oy0 = py_t * TH; q.ox0 = px_t * TW; q.cout0 = nb * BN;
+        return q;
+    };
+    constexpr int OOB = 0x7ff80000;
+
+    if (wave == 8) {
+        // ---------------- producer.  No per-lane offset tables: 112 registers of them (+ the compiler's hoisted per-tile copies) spilled
+        // at the 168-register budget of a 9-wave workgroup, and scratch traffic counts in this wave's vmcnt stream.  A piece's
+        // source offset is computed when it is requested (two magic-number divisions + ~10 VALU; 8 pieces per tap).
+        // one input descriptor per EXPERT (conv_dma_plan: an expert's images span < 2^31 bytes), the tile's image group in the offset
+        auto rs_in_of = [&](const Tile& q) {
+            const bf16* inb = (const bf16*)a.in + (size_t)q.e * a.ipe * a.H * a.W * a.in_ld + a.in_coff;
+            return __builtin_amdgcn_make_buffer_rsrc((void*)inb, (short)0, (int)(((long long)a.ipe * a.H * a.W * a.in_ld - a.in_coff) * 2),
+                                                     0x00020000);
+        };
+        auto rs_w_of = [&](const Tile& q) {
+            const bf16* wb = (const bf16*)a.w + ((size_t)q.e * a.CoutP + q.cout0) * 9 * a.Cin;
+            return __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, BN * 9 * a.Cin * 2, 0x00020000);
+        };
+        const int lrow = lane >> 3, ljj = lane & 7;
+        auto req_patch = [&](const Tile& q, const __amdgpu_buffer_rsrc_t& rs, int i, int buf, int c0, int opaque) {
+            // (`opaque` is 0 at run time, unknown at compile time: keeps the offsets from being hoisted into per-tile tables)
+            const int pp = (i << 3) + lrow + opaque;
+            const int rowq = (pp * magic_pw) >> 16, px = pp - rowq * PW;
+            const int pn = (rowq * magic_ph) >> 16, prow = rowq - pn * PH;
+            const int n = q.n0 - q.e * a.ipe + pn, Y = q.oy0 - 1 + prow, X = q.ox0 - 1 + px;
+            const bool ok = pp < NPIX && n < a.ipe && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+            const int off = ((((n * a.H + Y) * a.W + X) * a.in_ld) << 1) + ((ljj ^ cswz(px)) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + buf * pbuf_bytes + (i << 10)), 16, ok ? off : OOB, c0 << 1, 0, 0);
+        };
+        auto req_w = [&](const __amdgpu_buffer_rsrc_t& rs, int slot, int tap, int c0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i << 3) + lrow;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(wring + slot * WSLOT + (i << 10)), 16,
+                                                         ((row * 9 * a.Cin) << 1) + ((ljj ^ cswz(row)) << 4), (tap * a.Cin + c0) << 1, 0, 0);
+            }
+        };
+        int L = b0;
+        if (L >= ntiles) return;
+        Tile cur = decode(L);
+        __amdgpu_buffer_rsrc_t rin = rs_in_of(cur), rw = rs_w_of(cur);
+        // prologue of the FIRST tile only
+        for (int i = 0; i < NPIECE; ++i) req_patch(cur, rin, i, 0, 0, 0);
+        req_w(rw, 0, 0, 0);
+        req_w(rw, 1, 1, 0);
+        int after = 16;                                  // requests issued after W(stream tap): the group of the previous tap
+        int gtt = 0, gch = 0;                            // stream position of the current tile's first tap / chunk
+        for (;;) {
+            const bool has_next = L + G < ntiles;
+            const Tile nxt = decode(has_next ? L + G : L);
+            const __amdgpu_buffer_rsrc_t rin_n = rs_in_of(nxt), rw_n = rs_w_of(nxt);
+            for (int ch = 0; ch < nchunks; ++ch) {
+                const int c0 = ch * CK;
+                const bool more = ch + 1 < nchunks;
+                int opaque = 0;
+                asm volatile("" : "+s"(opaque));
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int tt = ch * 9 + tap;
+                    vm_wait_prod(after);
+                    __builtin_amdgcn_s_barrier();
+                    int n = 0;
+                    if (tap >= 1 && tap <= 6 && (more || has_next)) {
+                        // the next chunk's patch: of this tile, or chunk 0 of the NEXT tile during this tile's last chunk
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int idx = (tap - 1) * 8 + j;
+                            if (idx < NPIECE) {
+                                if (more) req_patch(cur, rin, idx, (gch + ch + 1) & 1, c0 + CK, opaque);
+                                else req_patch(nxt, rin_n, idx, (gch + ch + 1) & 1, 0, opaque);
+                                ++n;
+                            }
+                        }
+                    }
+                    if (tt + 2 < T) {
+                        int ntap = tap + 2, nc0 = c0;
+                        if (ntap >= 9) { ntap -= 9; nc0 += CK; }
+                        req_w(rw, (gtt + tt + 2) & (RING - 1), ntap, nc0);
+                        n += 16;
+                    } else if (has_next) {               // taps 0 / 1 of the next tile's first chunk
+                        req_w(rw_n, (gtt + tt + 2) & (RING - 1), tt + 2 - T, 0);
+                        n += 16;
+                    }
+                    after = n;
+                }
+            }
+            for (int i = 0; i < nbar_epi; ++i) __builtin_amdgcn_s_barrier();      // the accumulating waves' epilogue
+            if (!has_next) return;
+            gtt += T; gch += nchunks;
+            L += G; cur = nxt; rin = rin_n; rw = rw_n;
+        }
+    }
+
+    // ---------------- accumulating waves
+    int pbase[2], pcol[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int p = wm * 64 + mt * 32 + l31;
+        const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+        pbase[mt] = ((pn * PH + my) * PW + mx) << LOG_RB;
+        pcol[mt] = mx;
+    }
+    int aoff[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = wn * 64 + nt * 32 + l31;
+            aoff[nt][ks] = row * RB + (((ks * 2 + h) ^ cswz(row)) << 4);
+        }
+    int pbase16[4], pcol16[4], aoff16[4][2];
+    if constexpr (MF16) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int p = wm * 64 + mt * 16 + (lane & 15);
+            const int mx = p & (TW - 1), my = (p >> lTW) & (TH - 1), pn = p >> (lTW + lTH);
+            pbase16[mt] = ((pn * PH + my) * PW + mx) << LOG_RB;
+            pcol16[mt] = mx;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = wn * 64 + nt * 16 + (lane & 15);
+                aoff16[nt][ks] = row * RB + (((ks * 4 + (lane >> 4)) ^ cswz(row)) << 4);
+            }
+    }
+    int gtt = 0, gch = 0;
+    for (int L = b0; L < ntiles; L += G) {
+        const Tile q = decode(L);
+        const int e = q.e, n0 = q.n0, n_end = q.n_end, oy0 = q.oy0, ox0 = q.ox0, cout0 = q.cout0;
+        const unsigned mb = q.mb;
+        f32x16 acc[2][2];
+        f32x4 acc16[4][4];
+        if constexpr (MF16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+        }
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const char* patch = smem + ((gch + ch) & 1) * pbuf_bytes;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int tt = ch * 9 + tap;
+                __builtin_amdgcn_s_barrier();            // the producer has this tap's weight tile (and this chunk's patch) in LDS
+                const char* wt = wring + ((gtt + tt) & (RING - 1)) * WSLOT;
+                const int tapoff = ((tap / 3) * PW + (tap % 3)) << LOG_RB;
+                if constexpr (MF16) {
+                    int bsw16[4];
+                    const char* bp16[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        bp16[mt] = patch + pbase16[mt] + tapoff;
+                        bsw16[mt] = cswz(pcol16[mt] + (tap % 3));
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        v4i af[4], bfr[4];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) af[nt] = *reinterpret_cast<const v4i*>(wt + aoff16[nt][ks]);
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            bfr[mt] = *reinterpret_cast<const v4i*>(bp16[mt] + (((ks * 4 + (lane >> 4)) ^ bsw16[mt]) << 4));
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt)
+                                acc16[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[nt]),
+                                                                                        __builtin_bit_cast(bf16x8, bfr[mt]),
+                                                                                        acc16[nt][mt], 0, 0, 0);
+                    }
+                } else {
+                    int bsw[2];
+                    const char* bp[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        bp[mt] = patch + pbase[mt] + tapoff;
+                        bsw[mt] = cswz(pcol[mt] + (tap % 3));
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        v4i af[2], bfr[2];
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) af[nt] = *reinterpret_cast<const v4i*>(wt + aoff[nt][ks]);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            bfr[mt] = *reinterpret_cast<const v4i*>(bp[mt] + (((ks * 2 + h) ^ bsw[mt]) << 4));
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+                                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[nt]),
+                                                                                      __builtin_bit_cast(bf16x8, bfr[mt]),
+                                                                                      acc[nt][mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        gtt += T; gch += nchunks;
+        // staging map of this tile's epilogue: the patch buffer of the chunk just finished + the two ring slots that hold neither of the
+        // next tile's first two weight tiles (slots gtt & 3 and (gtt + 1) & 3)
+        char* stg_lo = smem + ((gch - 1) & 1) * pbuf_bytes;
+        char* stg_s0 = wring + ((gtt + 2) & (RING - 1)) * WSLOT;
+        char* stg_s1 = wring + ((gtt + 3) & (RING - 1)) * WSLOT;
+#define DMA_STG_ROW(p) ((p) < 160 ? stg_lo + (p) * 256 : (p) < 224 ? stg_s0 + ((p) - 160) * 256 : stg_s1 + ((p) - 224) * 256)
+#define DMA_RED_BASE stg_lo
+#define DMA_HAS_MF16
+#include "conv_dma_epilogue.inc"
+#undef DMA_STG_ROW
+#undef DMA_RED_BASE
+#undef DMA_HAS_MF16
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Round 4, measured and REMOVED: this kernel with the roles separated like conv_wgrad_dma2_kernel (conv_wgrad.hip) -- four
 // accumulating waves of 64 pixels x 128 output channels (one per SIMD, fragments double-buffered a 16-channel step ahead, the
 // per-tap barrier executed before the tap's last eight MFMAs) + four request-only waves.  Correct (the conv suite passed on it) and
@@ -877,6 +1148,24 @@ bool conv_dma_uses_mf16(const ConvArgs& a) {
     return ev ? atoi(ev) != 0 : a.Cin >= 256;
 }
 
+// the persistent, streaming instantiation (round 4): forward launches whose piece decode the magic-number division reproduces
+bool conv_dma_uses_stream(const ConvArgs& a0) {
+    const char* ev = getenv("PMOE_DMA_STREAM");
+    if (ev && !atoi(ev)) return false;
+    if (!(a0.res_mode == PMOE_RES_NONE && !a0.bias && a0.act == PMOE_ACT_NONE && a0.drop_p == 0.f)) return false;
+    ConvArgs a = a0;
+    int mblocks = 0, pbuf = 0;
+    size_t smem = 0;
+    if (!conv_dma_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return false;
+    if (pbuf < 160 * 256) return false;                  // rows 0..159 of the epilogue's staging live in a patch buffer
+    const int PW = (1 << a.lTW) + 2, PH = (1 << a.lTH) + 2;
+    const int npiece = (a.TN * PH * PW + 7) / 8;
+    const int mpw = 65536 / PW + 1, mph = 65536 / PH + 1;
+    for (int pp = 0; pp < npiece * 8; ++pp)
+        if (((pp * mpw) >> 16) != pp / PW || ((((pp / PW) * mph) >> 16) != (pp / PW) / PH)) return false;
+    return a.TN * PH < 1024 && PW < 1024 && a.ipe < 2047;      // the packed (image, row, column) fields of a piece
+}
+
 // the producer-wave instantiation (round 4): forward launches -- nothing added to or derived from a side input in the epilogue
 bool conv_dma_uses_producer(const ConvArgs& a) {
     const char* ev = getenv("PMOE_DMA_PRODUCER");
@@ -894,7 +1183,20 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     // v_mfma_f32_16x16x32_bf16 for the layers with >= 4 channel chunks (interleaved A/B, profiles/r03_kernel_ab.log: layer3 forward
     // +0.6 %, data gradient +3.5 %; layer4 +3.5 % / +5 %; layer2 -3 % / +0.7 %: the shorter the main loop, the less the shape's
     // higher sustained clock buys).  PMOE_DMA_MF16=0 | 1 forces one shape (read per launch).
-    if (conv_dma_uses_producer(a)) {
+    if (conv_dma_uses_stream(a)) {
+        // persistent workgroups, one per CU; the request stream of each runs across its tiles
+        const int ntiles = mblocks * (a.CoutP / BN);
+        const int PWp = (1 << a.lTW) + 2, PHp = (1 << a.lTH) + 2;
+        const int mpw = 65536 / PWp + 1, mph = 65536 / PHp + 1;
+        int grid = ntiles < 256 ? ntiles : 256;
+        if (conv_dma_uses_mf16(a)) {
+            HIP_RET((ensure_dyn_lds<conv3x3_dma_stream_kernel<true>>(160 * 1024)));
+            hipLaunchKernelGGL(conv3x3_dma_stream_kernel<true>, dim3(grid), dim3(NTHR + 64), smem, st, a, pbuf, ntiles, mpw, mph);
+        } else {
+            HIP_RET((ensure_dyn_lds<conv3x3_dma_stream_kernel<false>>(160 * 1024)));
+            hipLaunchKernelGGL(conv3x3_dma_stream_kernel<false>, dim3(grid), dim3(NTHR + 64), smem, st, a, pbuf, ntiles, mpw, mph);
+        }
+    } else if (conv_dma_uses_producer(a)) {
         if (conv_dma_uses_mf16(a)) {
             HIP_RET((ensure_dyn_lds<conv3x3_dma_kernel<true, true>>(160 * 1024)));
             hipLaunchKernelGGL((conv3x3_dma_kernel<true, true>), dim3(mblocks * (a.CoutP / BN)), dim3(NTHR + 64), smem, st, a, pbuf);

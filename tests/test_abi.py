@@ -81,8 +81,8 @@ def test_conv_plan_reports_the_kernel_instantiation():
         return load().pmoe_conv2d_plan(C.byref(d))
     assert plan(64, 64, 128, 3, 1, torch.bfloat16) == 1207                 # conv3x3_respipe_kernel<false, 0> (filter bank resident, LDS-DMA patches)
     assert plan(16, 64, 256, 3, 1, torch.bfloat16) == 1316                 # 12(16)-channel stem: conv3x3_c16_kernel (direct form)
-    assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 5037                # conv3x3_dma_kernel<true, true> (LDS-DMA staged, 16x16x32 MFMA shape from 256 input channels, producer wave)
-    assert plan(128, 128, 64, 3, 1, torch.bfloat16) == 5007                # conv3x3_dma_kernel<false> (32x32x16; two channel chunks: no producer wave)
+    assert plan(256, 256, 32, 3, 1, torch.bfloat16) == 5057                # conv3x3_dma_stream_kernel<true> (LDS-DMA staged, 16x16x32 MFMA shape from 256 input channels, persistent + producer wave)
+    assert plan(128, 128, 64, 3, 1, torch.bfloat16) == 5047                # conv3x3_dma_stream_kernel<false> (32x32x16)
     assert plan(128, 256, 64, 1, 2, torch.bfloat16) == 1404                # 1x1 stride 2 (downsample): conv1x1_direct_kernel<4>
     assert plan(256, 512, 32, 1, 2, torch.bfloat16) == 1402                # ... 64-channel slabs from 256 input channels
     assert plan(256, 256, 32, 3, 1, torch.float32) == 722                  # f32: 4-wave 128x128 tile, 32-channel chunks
@@ -90,7 +90,7 @@ def test_conv_plan_reports_the_kernel_instantiation():
     assert plan(1536, 512, 1, 1, 1, torch.float32) == 722                  # ... in f32: generic 4-wave tile
     assert plan(512, 512, 14, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # B=1 inference layer4: tap-looping skinny kernel
     assert plan(128, 128, 56, 3, 1, torch.bfloat16, B=1, E=3) == 3000      # ... layer2 (3136 pixels per expert <= 3200)
-    assert plan(128, 128, 64, 3, 1, torch.bfloat16, B=1, E=3) == 5007      # 4096 pixels per expert: the LDS-DMA tile
+    assert plan(128, 128, 64, 3, 1, torch.bfloat16, B=1, E=3) == 5047      # 4096 pixels per expert: the LDS-DMA tile
     assert plan(128, 64, 64, 3, 1, torch.bfloat16, dilate=True, Hout=128) == 4741   # stride-2 dgrad, 64 gradient rows: 4 class launches <7,4,1>
     assert plan(256, 128, 32, 3, 1, torch.bfloat16, dilate=True, Hout=64) == 9207   # ... >= 128 rows: 4 class launches of conv3x3s2_dma_kernel<true>
     assert plan(64, 128, 128, 3, 2, torch.bfloat16) == 5207                # stride-2 forward: conv3x3s2_dma_kernel<false>
@@ -221,7 +221,7 @@ def test_vmcnt_counting_kernels_have_no_scratch_in_their_main_loops(tmp_path):
         for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
             yield m.group(1), m.group(2).split("\n")
     checked = 0
-    for src, pats in (("conv_dma", ("conv3x3_dma_kernel", "conv3x3s2_dma_kernel", "conv3x3_dma_f8_kernel")),
+    for src, pats in (("conv_dma", ("conv3x3_dma_kernel", "conv3x3_dma_stream_kernel", "conv3x3s2_dma_kernel", "conv3x3_dma_f8_kernel")),
                       ("conv_res", ("conv3x3_respipe_kernel",))):
         for sym, body in kernels(src):
             if any(p in sym for p in pats):

@@ -143,7 +143,7 @@ def _conv_case(case, dtype, plan=None):
     ops.conv2d(dyd, wd, dx, cin=r16(cout), cout=cinp, coutp=r64(cin), ipe=ipe, ks=ks, stride=1,
                pad=ks - 1 - pad, dilate=(stride == 2))
     close(from_nhwc(dx, cin), xr.grad, dtype, "conv dgrad")
-    if stride == 1 and ks == 3 and plan is not None and plan[1] in (5007, 5017, 5027, 5037, 1207):
+    if stride == 1 and ks == 3 and plan is not None and plan[1] in (5007, 5017, 5027, 5037, 5047, 5057, 1207):
         # a data gradient accumulating into the gradient another consumer left (BasicBlock `.1.conv1`: the identity branch's):
         # PMOE_RES_ADD with the residual prefetched under the MFMAs on both LDS-DMA kernels
         prev = rnd((N, cin, H, W), torch.Generator().manual_seed(9), dtype)
@@ -204,11 +204,11 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
 # parity test).  Codes: include/pmoe_hip.h pmoe_conv2d_plan; the third number = workgroups of the weight-gradient launch.
 BASELINE_CONV_CASES = [
     # (E, ipe, cin, cout, H, W, ks, stride), (fwd, dgrad, wgrad workgroups)
-    ((1, 4, 128, 128, 64, 64, 3, 1), (5007, 5007, 256)),       # layer2: conv3x3_dma_kernel<false> (LDS-DMA), 2 channel chunks: no producer wave
-    ((1, 8, 256, 256, 32, 32, 3, 1), (5037, 5037, 256)),       # layer3: 4 chunks, 32 x 8 pixel tiles; the 16x16x32 MFMA instantiation with the producer wave
-    ((2, 32, 512, 512, 16, 16, 3, 1), (5037, 5037, 256)),      # layer4: 8 chunks, one 16 x 16 image per tile (two patch rows per
+    ((1, 4, 128, 128, 64, 64, 3, 1), (5047, 5047, 256)),       # layer2: conv3x3_dma_stream_kernel<false> (LDS-DMA, persistent, producer wave), 2 channel chunks
+    ((1, 8, 256, 256, 32, 32, 3, 1), (5057, 5057, 256)),       # layer3: 4 chunks, 32 x 8 pixel tiles; the 16x16x32 MFMA instantiation of the persistent kernel
+    ((2, 32, 512, 512, 16, 16, 3, 1), (5057, 5057, 256)),      # layer4: 8 chunks, one 16 x 16 image per tile (two patch rows per
                                                                # 32-lane fragment: the column-keyed swizzle), 2 experts
-    ((1, 5, 128, 256, 40, 24, 3, 1), (5007, 5037, 200)),       # ragged: 24-wide rows in 32-wide tiles, 40 rows in strips of 8, 5 images
+    ((1, 5, 128, 256, 40, 24, 3, 1), (5047, 5057, 200)),       # ragged: 24-wide rows in 32-wide tiles, 40 rows in strips of 8, 5 images
     ((1, 1, 64, 64, 256, 256, 3, 1), (1207, 1207, 256)),       # stem conv2: conv3x3_respipe_kernel, 256 tiles of one image
     ((2, 2, 64, 64, 128, 128, 3, 1), (1207, 1207, 256)),       # layer1: resident kernel, persistent workgroups per expert
     ((1, 4, 64, 128, 128, 128, 3, 2), (5207, 4741, 256)),      # layer2.0.conv1: conv3x3s2_dma_kernel (parity planes by LDS-DMA); its data gradient (64 gradient rows) stays on the generic kernel's 4 parity-class launches
@@ -304,6 +304,7 @@ def test_conv_dma_mfma16_variant(monkeypatch, case):
     """PMOE_DMA_MF16=1 (read per launch): conv3x3_dma_kernel on v_mfma_f32_16x16x32_bf16 -- other fragment / accumulator layouts,
     same tile, same parity bar (forward with fused statistics, data gradient)."""
     monkeypatch.setenv("PMOE_DMA_MF16", "1")
+    monkeypatch.setenv("PMOE_DMA_STREAM", "0")
     monkeypatch.setenv("PMOE_DMA_PRODUCER", "2")            # (2: the producer-wave instantiation for every channel count)
     _conv_case(case, torch.bfloat16, (5037, 5037, None))
 
@@ -315,7 +316,39 @@ def test_conv_dma_without_producer_wave(monkeypatch, case, codes):
     which every wave issues its own LDS-DMA requests -- the A/B partner of the round-4 producer-wave instantiation, and the kernel
     the side-input epilogue modes (PMOE_RES_DBN / PMOE_RES_ADD) always run on."""
     monkeypatch.setenv("PMOE_DMA_PRODUCER", "0")
+    monkeypatch.setenv("PMOE_DMA_STREAM", "0")
     _conv_case(case, torch.bfloat16, codes)
+
+
+@pytest.mark.parametrize("case", [(1, 4, 128, 128, 64, 64, 3, 1), (2, 32, 512, 512, 16, 16, 3, 1), (1, 5, 128, 256, 40, 24, 3, 1),
+                                  (3, 70, 128, 128, 64, 64, 3, 1)])
+def test_conv_dma_persistent_stream(monkeypatch, case):
+    """conv3x3_dma_stream_kernel (round 4): persistent workgroups, the producer wave's request stream running across tile boundaries,
+    the epilogue staged in the patch buffer / ring slots the stream is not filling.  Same parity bar as the one-tile kernels, and --
+    same accumulation order, same rounding -- BIT-IDENTICAL forward output and BatchNorm partial sums; the last case gives every
+    workgroup several tiles incl. a ragged tail (3 experts x 70 images of 64 x 64: 3360 tiles on 256 workgroups)."""
+    E, ipe, cin, cout, H, W, ks, stride = case
+    if E * ipe <= 64:
+        _conv_case(case, torch.bfloat16, None)
+    g = torch.Generator().manual_seed(5)
+    BF = torch.bfloat16
+    N = E * ipe
+    x = nhwc(rnd((N, cin, H, W), g, BF), cin, BF)
+    ws = [rnd((cout, cin, 3, 3), g, BF, (2.0 / (cin * 9)) ** 0.5) for _ in range(E)]
+    wf, _, _keep = pack(ws, 3, BF)
+    outs = []
+    for stream in ("1", "0"):
+        monkeypatch.setenv("PMOE_DMA_STREAM", stream)
+        kw = dict(cin=cin, cout=cout, coutp=r64(cout), ipe=ipe, ks=3, stride=1, pad=1)
+        y = torch.full((N, H, W, cout), 7.0, dtype=BF, device=DEV)
+        code = ops.conv2d(x, wf, y, plan_only=True, **kw)
+        assert code in ((5047, 5057) if stream == "1" else (5007, 5017, 5027, 5037)), code
+        rows = ops.conv2d_stat_rows(N, H, W, H, W, cin, cout, r64(cout), ipe, 3, 1, 1, BF)
+        st = torch.full((rows, 2, r64(cout)), 3.0, device=DEV)
+        ops.conv2d(x, wf, y, stats=st, **kw)
+        outs.append((y, st))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
 
 
 @pytest.mark.parametrize("req", ["0", "2"])
