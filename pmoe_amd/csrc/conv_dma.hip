@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
 // and issues nothing between the last tap of a tile and the first barrier of the next one.
 // PMOE_DMA_STREAM=0: A/B switch back to the one-tile-per-workgroup kernels.
 template <bool MF16>
-__global__ void __launch_bounds__(NTHR + 64, 1) conv3x3_dma_stream_kernel(const ConvArgs a_in, const int pbuf_bytes, const int ntiles,
+__global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(const ConvArgs a_in, const int pbuf_bytes, const int ntiles,
                                                                           const int magic_pw, const int magic_ph) {
     ConvArgs a = a_in;
     a.res_mode = PMOE_RES_NONE; a.res = nullptr; a.bias = nullptr; a.act = PMOE_ACT_NONE; a.drop_p = 0.f; a.bn = nullptr;
@@ -455,10 +455,13 @@ __global__ void __launch_bounds__(NTHR + 64, 1) conv3x3_dma_stream_kernel(const 
     };
     constexpr int OOB = 0x7ff80000;
 
-    if (wave == 8) {
-        // ---------------- producer.  No per-lane offset tables: 112 registers of them (+ the compiler's hoisted per-tile copies) spilled
-        // at the 168-register budget of a 9-wave workgroup, and scratch traffic counts in this wave's vmcnt stream.  A piece's
-        // source offset is computed when it is requested (two magic-number divisions + ~10 VALU; 8 pieces per tap).
+    if (wave >= 8) {
+        // ---------------- producers: waves 8 and 9 share the weight tiles, waves 10 and 11 the patches (pieces of their parity).  ONE
+        // producer issuing the 24 requests of a tap needs about the tap's own 1400 cycles for them (60-100 per request): with the
+        // whole stream on one wave layer3 / layer4 ran 25 % / 40 % slower than the one-tile kernels (profiles/r04_kernel_ab.log, block 5).
+        // Every producer owns the in-order vmcnt bookkeeping of ITS requests: before barrier(tt) it waits until only the group it
+        // issued during the previous tap is outstanding.
+        const int pw = wave - 8;
         // one input descriptor per EXPERT (conv_dma_plan: an expert's images span < 2^31 bytes), the tile's image group in the offset
         auto rs_in_of = [&](const Tile& q) {
             const bf16* inb = (const bf16*)a.in + (size_t)q.e * a.ipe * a.H * a.W * a.in_ld + a.in_coff;
@@ -469,78 +472,111 @@ __global__ void __launch_bounds__(NTHR + 64, 1) conv3x3_dma_stream_kernel(const 
             const bf16* wb = (const bf16*)a.w + ((size_t)q.e * a.CoutP + q.cout0) * 9 * a.Cin;
             return __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, BN * 9 * a.Cin * 2, 0x00020000);
         };
-        const int lrow = lane >> 3, ljj = lane & 7;
-        auto req_patch = [&](const Tile& q, const __amdgpu_buffer_rsrc_t& rs, int i, int buf, int c0, int opaque) {
-            // (`opaque` is 0 at run time, unknown at compile time: keeps the offsets from being hoisted into per-tile tables)
-            const int pp = (i << 3) + lrow + opaque;
-            const int rowq = (pp * magic_pw) >> 16, px = pp - rowq * PW;
-            const int pn = (rowq * magic_ph) >> 16, prow = rowq - pn * PH;
-            const int n = q.n0 - q.e * a.ipe + pn, Y = q.oy0 - 1 + prow, X = q.ox0 - 1 + px;
-            const bool ok = pp < NPIX && n < a.ipe && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
-            const int off = ((((n * a.H + Y) * a.W + X) * a.in_ld) << 1) + ((ljj ^ cswz(px)) << 4);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + buf * pbuf_bytes + (i << 10)), 16, ok ? off : OOB, c0 << 1, 0, 0);
-        };
-        auto req_w = [&](const __amdgpu_buffer_rsrc_t& rs, int slot, int tap, int c0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (i << 3) + lrow;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(wring + slot * WSLOT + (i << 10)), 16,
-                                                         ((row * 9 * a.Cin) << 1) + ((ljj ^ cswz(row)) << 4), (tap * a.Cin + c0) << 1, 0, 0);
-            }
-        };
         int L = b0;
         if (L >= ntiles) return;
+        int gtt = 0, gch = 0;                            // stream position of the current tile's first tap / chunk
+        if (pw >= 2) {
+            // ---- patch producers (waves 10, 11): pieces of parity pp2 = pw - 2.  No per-lane offset tables: 96 registers of them plus
+            // the per-tile copies hipcc hoists out of the chunk loop spill at the 168-register budget of a 12-wave workgroup, and scratch
+            // traffic counts in the wave's vmcnt stream.  A piece's source offset is computed when it is requested (two magic-number
+            // divisions + ~10 VALU); two waves halve that cost per tap.  `opaque` (0 at run time, unknown at compile time) keeps the
+            // offsets from being hoisted into tables again.
+            const int pp2 = pw - 2;
+            const int lrow = lane >> 3, ljj = lane & 7;
+            auto req_patch = [&](const Tile& q, const __amdgpu_buffer_rsrc_t& rs, int i, int buf, int c0, int opaque) {
+                const int pp = (i << 3) + lrow + opaque;
+                const int rowq = (pp * magic_pw) >> 16, px = pp - rowq * PW;
+                const int pn = (rowq * magic_ph) >> 16, prow = rowq - pn * PH;
+                const int n = q.n0 - q.e * a.ipe + pn, Y = q.oy0 - 1 + prow, X = q.ox0 - 1 + px;
+                const bool ok = pp < NPIX && n < a.ipe && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+                const int off = ((((n * a.H + Y) * a.W + X) * a.in_ld) << 1) + ((ljj ^ cswz(px)) << 4);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + buf * pbuf_bytes + (i << 10)), 16, ok ? off : OOB, c0 << 1, 0, 0);
+            };
+            Tile cur = decode(L);
+            __amdgpu_buffer_rsrc_t rin = rs_in_of(cur);
+            for (int i = pp2; i < NPIECE; i += 2) req_patch(cur, rin, i, 0, 0, 0);
+            int after = 0;
+            for (;;) {
+                const bool has_next = L + G < ntiles;
+                const Tile nxt = decode(has_next ? L + G : L);
+                const __amdgpu_buffer_rsrc_t rin_n = rs_in_of(nxt);
+                for (int ch = 0; ch < nchunks; ++ch) {
+                    const int c0 = ch * CK;
+                    const bool more = ch + 1 < nchunks;
+                    int opaque = 0;
+                    asm volatile("" : "+s"(opaque));
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        vm_wait_prod(after);
+                        __builtin_amdgcn_s_barrier();
+                        int n = 0;
+                        if (tap >= 1 && tap <= 6 && (more || has_next)) {
+                            // the next chunk's patch: of this tile, or chunk 0 of the NEXT tile during this tile's last chunk
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int idx = (tap - 1) * 8 + 2 * j + pp2;
+                                if (idx < NPIECE) {
+                                    if (more) req_patch(cur, rin, idx, (gch + ch + 1) & 1, c0 + CK, opaque);
+                                    else req_patch(nxt, rin_n, idx, (gch + ch + 1) & 1, 0, opaque);
+                                    ++n;
+                                }
+                            }
+                        }
+                        after = n;
+                    }
+                }
+                for (int i = 0; i < nbar_epi; ++i) __builtin_amdgcn_s_barrier();      // the accumulating waves' epilogue
+                if (!has_next) return;
+                gch += nchunks;
+                L += G; cur = nxt; rin = rin_n;
+            }
+        }
+        // ---- weight producers: pieces of parity pw of every tap tile
+        int wv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = ((2 * i + pw) << 3) + (lane >> 3);
+            wv[i] = ((row * 9 * a.Cin) << 1) + (((lane & 7) ^ cswz(row)) << 4);
+        }
+        auto req_w = [&](const __amdgpu_buffer_rsrc_t& rs, int slot, int tap, int c0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(wring + slot * WSLOT + ((2 * i + pw) << 10)), 16, wv[i],
+                                                         (tap * a.Cin + c0) << 1, 0, 0);
+        };
         Tile cur = decode(L);
-        __amdgpu_buffer_rsrc_t rin = rs_in_of(cur), rw = rs_w_of(cur);
-        // prologue of the FIRST tile only
-        for (int i = 0; i < NPIECE; ++i) req_patch(cur, rin, i, 0, 0, 0);
+        __amdgpu_buffer_rsrc_t rw = rs_w_of(cur);
         req_w(rw, 0, 0, 0);
         req_w(rw, 1, 1, 0);
-        int after = 16;                                  // requests issued after W(stream tap): the group of the previous tap
-        int gtt = 0, gch = 0;                            // stream position of the current tile's first tap / chunk
+        int after = 8;                                   // own requests issued after this wave's share of W(stream tap)
         for (;;) {
             const bool has_next = L + G < ntiles;
             const Tile nxt = decode(has_next ? L + G : L);
-            const __amdgpu_buffer_rsrc_t rin_n = rs_in_of(nxt), rw_n = rs_w_of(nxt);
+            const __amdgpu_buffer_rsrc_t rw_n = rs_w_of(nxt);
             for (int ch = 0; ch < nchunks; ++ch) {
                 const int c0 = ch * CK;
-                const bool more = ch + 1 < nchunks;
-                int opaque = 0;
-                asm volatile("" : "+s"(opaque));
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int tt = ch * 9 + tap;
                     vm_wait_prod(after);
                     __builtin_amdgcn_s_barrier();
                     int n = 0;
-                    if (tap >= 1 && tap <= 6 && (more || has_next)) {
-                        // the next chunk's patch: of this tile, or chunk 0 of the NEXT tile during this tile's last chunk
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int idx = (tap - 1) * 8 + j;
-                            if (idx < NPIECE) {
-                                if (more) req_patch(cur, rin, idx, (gch + ch + 1) & 1, c0 + CK, opaque);
-                                else req_patch(nxt, rin_n, idx, (gch + ch + 1) & 1, 0, opaque);
-                                ++n;
-                            }
-                        }
-                    }
                     if (tt + 2 < T) {
                         int ntap = tap + 2, nc0 = c0;
                         if (ntap >= 9) { ntap -= 9; nc0 += CK; }
                         req_w(rw, (gtt + tt + 2) & (RING - 1), ntap, nc0);
-                        n += 16;
+                        n = 8;
                     } else if (has_next) {               // taps 0 / 1 of the next tile's first chunk
                         req_w(rw_n, (gtt + tt + 2) & (RING - 1), tt + 2 - T, 0);
-                        n += 16;
+                        n = 8;
                     }
                     after = n;
                 }
             }
-            for (int i = 0; i < nbar_epi; ++i) __builtin_amdgcn_s_barrier();      // the accumulating waves' epilogue
+            for (int i = 0; i < nbar_epi; ++i) __builtin_amdgcn_s_barrier();          // the accumulating waves' epilogue
             if (!has_next) return;
-            gtt += T; gch += nchunks;
-            L += G; cur = nxt; rin = rin_n; rw = rw_n;
+            gtt += T;
+            L += G; cur = nxt; rw = rw_n;
         }
     }
 
@@ -1153,6 +1189,9 @@ bool conv_dma_uses_stream(const ConvArgs& a0) {
     const char* ev = getenv("PMOE_DMA_STREAM");
     if (ev && !atoi(ev)) return false;
     if (!(a0.res_mode == PMOE_RES_NONE && !a0.bias && a0.act == PMOE_ACT_NONE && a0.drop_p == 0.f)) return false;
+    // two and four channel chunks (layer2: +24 %, layer3: +6 %); with eight (layer4: the prologue is 5 % of the tile) the 12-wave
+    // workgroup is 4 % slower than the 9-wave producer instantiation -- profiles/r04_kernel_ab.log, block 5.  PMOE_DMA_STREAM=2: always
+    if (a0.Cin > 256 && !(ev && atoi(ev) == 2)) return false;
     ConvArgs a = a0;
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
@@ -1191,10 +1230,10 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
         int grid = ntiles < 256 ? ntiles : 256;
         if (conv_dma_uses_mf16(a)) {
             HIP_RET((ensure_dyn_lds<conv3x3_dma_stream_kernel<true>>(160 * 1024)));
-            hipLaunchKernelGGL(conv3x3_dma_stream_kernel<true>, dim3(grid), dim3(NTHR + 64), smem, st, a, pbuf, ntiles, mpw, mph);
+            hipLaunchKernelGGL(conv3x3_dma_stream_kernel<true>, dim3(grid), dim3(NTHR + 4 * 64), smem, st, a, pbuf, ntiles, mpw, mph);
         } else {
             HIP_RET((ensure_dyn_lds<conv3x3_dma_stream_kernel<false>>(160 * 1024)));
-            hipLaunchKernelGGL(conv3x3_dma_stream_kernel<false>, dim3(grid), dim3(NTHR + 64), smem, st, a, pbuf, ntiles, mpw, mph);
+            hipLaunchKernelGGL(conv3x3_dma_stream_kernel<false>, dim3(grid), dim3(NTHR + 4 * 64), smem, st, a, pbuf, ntiles, mpw, mph);
         }
     } else if (conv_dma_uses_producer(a)) {
         if (conv_dma_uses_mf16(a)) {

@@ -206,7 +206,7 @@ BASELINE_CONV_CASES = [
     # (E, ipe, cin, cout, H, W, ks, stride), (fwd, dgrad, wgrad workgroups)
     ((1, 4, 128, 128, 64, 64, 3, 1), (5047, 5047, 256)),       # layer2: conv3x3_dma_stream_kernel<false> (LDS-DMA, persistent, producer wave), 2 channel chunks
     ((1, 8, 256, 256, 32, 32, 3, 1), (5057, 5057, 256)),       # layer3: 4 chunks, 32 x 8 pixel tiles; the 16x16x32 MFMA instantiation of the persistent kernel
-    ((2, 32, 512, 512, 16, 16, 3, 1), (5057, 5057, 256)),      # layer4: 8 chunks, one 16 x 16 image per tile (two patch rows per
+    ((2, 32, 512, 512, 16, 16, 3, 1), (5037, 5037, 256)),      # layer4 (eight chunks: the one-tile producer-wave kernel): 8 chunks, one 16 x 16 image per tile (two patch rows per
                                                                # 32-lane fragment: the column-keyed swizzle), 2 experts
     ((1, 5, 128, 256, 40, 24, 3, 1), (5047, 5057, 200)),       # ragged: 24-wide rows in 32-wide tiles, 40 rows in strips of 8, 5 images
     ((1, 1, 64, 64, 256, 256, 3, 1), (1207, 1207, 256)),       # stem conv2: conv3x3_respipe_kernel, 256 tiles of one image
@@ -328,6 +328,7 @@ def test_conv_dma_persistent_stream(monkeypatch, case):
     same accumulation order, same rounding -- BIT-IDENTICAL forward output and BatchNorm partial sums; the last case gives every
     workgroup several tiles incl. a ragged tail (3 experts x 70 images of 64 x 64: 3360 tiles on 256 workgroups)."""
     E, ipe, cin, cout, H, W, ks, stride = case
+    monkeypatch.setenv("PMOE_DMA_STREAM", "2")              # (2: also for more than four channel chunks)
     if E * ipe <= 64:
         _conv_case(case, torch.bfloat16, None)
     g = torch.Generator().manual_seed(5)
@@ -337,12 +338,12 @@ def test_conv_dma_persistent_stream(monkeypatch, case):
     ws = [rnd((cout, cin, 3, 3), g, BF, (2.0 / (cin * 9)) ** 0.5) for _ in range(E)]
     wf, _, _keep = pack(ws, 3, BF)
     outs = []
-    for stream in ("1", "0"):
+    for stream in ("2", "0"):
         monkeypatch.setenv("PMOE_DMA_STREAM", stream)
         kw = dict(cin=cin, cout=cout, coutp=r64(cout), ipe=ipe, ks=3, stride=1, pad=1)
         y = torch.full((N, H, W, cout), 7.0, dtype=BF, device=DEV)
         code = ops.conv2d(x, wf, y, plan_only=True, **kw)
-        assert code in ((5047, 5057) if stream == "1" else (5007, 5017, 5027, 5037)), code
+        assert code in ((5047, 5057) if stream == "2" else (5007, 5017, 5027, 5037)), code
         rows = ops.conv2d_stat_rows(N, H, W, H, W, cin, cout, r64(cout), ipe, 3, 1, 1, BF)
         st = torch.full((rows, 2, r64(cout)), 3.0, device=DEV)
         ops.conv2d(x, wf, y, stats=st, **kw)
