@@ -416,9 +416,16 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
 // nor W(1) of the next tile (rows 160..223, 224..255).  The producer joins the epilogue's barriers (s_barrier counts every live wave)
 // and issues nothing between the last tap of a tile and the first barrier of the next one.
 // PMOE_DMA_STREAM=0: A/B switch back to the one-tile-per-workgroup kernels.
-template <bool MF16>
+// NARROW (NT = 1; round 4, BASELINE config 4): tiles of 256 pixels x 64 output channels for the 64-output-channel layers with >= 128 input
+// channels -- the frozen U-Nets' 128 -> 64 decoder convolutions at full resolution (model/blocks/unet.py:57-63, 10 launches per
+// step that the generic register-staged kernel served at 610-630 TFLOP/s).  Same 4 x 2 wave grid, a wave's tile is 64 pixels x 32
+// couts (one A fragment, two B fragments, two MFMAs per 16 channels), weight tiles of 8 KiB, staging rows of 128 bytes.
+template <bool MF16, bool NARROW = false>
 __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(const ConvArgs a_in, const int pbuf_bytes, const int ntiles,
                                                                           const int magic_pw, const int magic_ph) {
+    constexpr int NT = NARROW ? 1 : 2, WPC = 4 * NT;     // WPC: pieces of a weight tile per producer wave
+    static_assert(!(NARROW && MF16), "the 64-cout tile exists on the 32x32x16 shape only");
+    constexpr int BN = 64 * NT, WSLOT = BN * RB;        // (shadow the 128-cout constants of this file)
     ConvArgs a = a_in;
     a.res_mode = PMOE_RES_NONE; a.res = nullptr; a.bias = nullptr; a.act = PMOE_ACT_NONE; a.drop_p = 0.f; a.bn = nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -532,15 +539,15 @@ __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(co
             }
         }
         // ---- weight producers: pieces of parity pw of every tap tile
-        int wv[8];
+        int wv[8];                                       // (WPC of them are used: a dependent array bound captured by the lambda below trips hipcc's host pass)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < WPC; ++i) {
             const int row = ((2 * i + pw) << 3) + (lane >> 3);
             wv[i] = ((row * 9 * a.Cin) << 1) + (((lane & 7) ^ cswz(row)) << 4);
         }
         auto req_w = [&](const __amdgpu_buffer_rsrc_t& rs, int slot, int tap, int c0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < WPC; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(wring + slot * WSLOT + ((2 * i + pw) << 10)), 16, wv[i],
                                                          (tap * a.Cin + c0) << 1, 0, 0);
         };
@@ -548,7 +555,7 @@ __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(co
         __amdgpu_buffer_rsrc_t rw = rs_w_of(cur);
         req_w(rw, 0, 0, 0);
         req_w(rw, 1, 1, 0);
-        int after = 8;                                   // own requests issued after this wave's share of W(stream tap)
+        int after = WPC;                                 // own requests issued after this wave's share of W(stream tap)
         for (;;) {
             const bool has_next = L + G < ntiles;
             const Tile nxt = decode(has_next ? L + G : L);
@@ -565,10 +572,10 @@ __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(co
                         int ntap = tap + 2, nc0 = c0;
                         if (ntap >= 9) { ntap -= 9; nc0 += CK; }
                         req_w(rw, (gtt + tt + 2) & (RING - 1), ntap, nc0);
-                        n = 8;
+                        n = WPC;
                     } else if (has_next) {               // taps 0 / 1 of the next tile's first chunk
                         req_w(rw_n, (gtt + tt + 2) & (RING - 1), tt + 2 - T, 0);
-                        n = 8;
+                        n = WPC;
                     }
                     after = n;
                 }
@@ -589,12 +596,12 @@ __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(co
         pbase[mt] = ((pn * PH + my) * PW + mx) << LOG_RB;
         pcol[mt] = mx;
     }
-    int aoff[2][4];
+    int aoff[NT][4];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int row = wn * 64 + nt * 32 + l31;
+            const int row = wn * (32 * NT) + nt * 32 + l31;
             aoff[nt][ks] = row * RB + (((ks * 2 + h) ^ cswz(row)) << 4);
         }
     int pbase16[4], pcol16[4], aoff16[4][2];
@@ -619,7 +626,7 @@ __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(co
         const Tile q = decode(L);
         const int e = q.e, n0 = q.n0, n_end = q.n_end, oy0 = q.oy0, ox0 = q.ox0, cout0 = q.cout0;
         const unsigned mb = q.mb;
-        f32x16 acc[2][2];
+        f32x16 acc[NT][2];
         f32x4 acc16[4][4];
         if constexpr (MF16) {
 #pragma unroll
@@ -628,7 +635,7 @@ __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(co
                 for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -676,14 +683,14 @@ __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(co
                     }
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
-                        v4i af[2], bfr[2];
+                        v4i af[NT], bfr[2];
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) af[nt] = *reinterpret_cast<const v4i*>(wt + aoff[nt][ks]);
+                        for (int nt = 0; nt < NT; ++nt) af[nt] = *reinterpret_cast<const v4i*>(wt + aoff[nt][ks]);
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt)
                             bfr[mt] = *reinterpret_cast<const v4i*>(bp[mt] + (((ks * 2 + h) ^ bsw[mt]) << 4));
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
+                        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                             for (int mt = 0; mt < 2; ++mt)
                                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[nt]),
@@ -699,13 +706,16 @@ __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(co
         char* stg_lo = smem + ((gch - 1) & 1) * pbuf_bytes;
         char* stg_s0 = wring + ((gtt + 2) & (RING - 1)) * WSLOT;
         char* stg_s1 = wring + ((gtt + 3) & (RING - 1)) * WSLOT;
-#define DMA_STG_ROW(p) ((p) < 160 ? stg_lo + (p) * 256 : (p) < 224 ? stg_s0 + ((p) - 160) * 256 : stg_s1 + ((p) - 224) * 256)
+        // (NT = 1: 256 rows of 128 bytes, all of them in the patch buffer)
+#define DMA_STG_ROW(p) (NT == 1 ? stg_lo + (p) * 128 : (p) < 160 ? stg_lo + (p) * 256 : (p) < 224 ? stg_s0 + ((p) - 160) * 256 : stg_s1 + ((p) - 224) * 256)
 #define DMA_RED_BASE stg_lo
 #define DMA_HAS_MF16
+#define DMA_NT NT
 #include "conv_dma_epilogue.inc"
 #undef DMA_STG_ROW
 #undef DMA_RED_BASE
 #undef DMA_HAS_MF16
+#undef DMA_NT
     }
 }
 
@@ -1145,6 +1155,26 @@ __global__ void __launch_bounds__(NTHR, 2) conv3x3_dma_f8_kernel(const ConvArgs 
 
 }  // namespace
 
+// the persistent kernel's piece decode: the magic-number divisions reproduce / and %, the packed fields fit, and rows 0..159 (NT = 2)
+// or all 256 half-rows (NT = 1) of the epilogue's staging fit the patch buffer.  Expects the tile geometry of conv_dma_plan in `a`.
+static bool stream_geometry_ok(const ConvArgs& a, int pbuf) {
+    if (pbuf < 160 * 256) return false;
+    const int PW = (1 << a.lTW) + 2, PH = (1 << a.lTH) + 2;
+    const int npiece = (a.TN * PH * PW + 7) / 8;
+    const int mpw = 65536 / PW + 1, mph = 65536 / PH + 1;
+    for (int pp = 0; pp < npiece * 8; ++pp)
+        if (((pp * mpw) >> 16) != pp / PW || ((((pp / PW) * mph) >> 16) != (pp / PW) / PH)) return false;
+    return a.TN * PH < 1024 && PW < 1024 && a.ipe < 2047;      // the packed (image, row, column) fields of a piece
+}
+
+// 64 output-channel rows over >= 128 input channels, nothing but the convolution (+ statistics): conv3x3_dma_stream_kernel<false, true>.
+// PMOE_DMA_NARROW=0: back to the generic kernel (A/B runs)
+bool conv_dma_is_narrow(const ConvArgs& a) {
+    const char* ev = getenv("PMOE_DMA_NARROW");
+    if (ev && !atoi(ev)) return false;
+    return a.CoutP == 64 && a.Cin >= 2 * CK && a.res_mode == PMOE_RES_NONE && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f;
+}
+
 // Which launches take this kernel: bf16, dense 3x3 stride 1 pad 1 (forward, or the flipped-filter data gradient), whole
 // 64-channel chunks, >= 128 output-channel rows, per-expert maps of >= 4096 pixels that tile into 16- or 32-pixel-wide
 // strips.  PMOE_CONV_DMA=0 sends them back to conv_igemm_lite_kernel (A/B runs; read per launch, so that tools/ab_conv.py can
@@ -1154,7 +1184,11 @@ bool conv_dma_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf
     if ((ev && !atoi(ev)) || dtype != PMOE_DT_BF16 || a.w_fp8) return false;
     if (a.ks != 3 || a.kh != 3 || a.kw != 3 || a.use_tapmap || a.stride != 1 || a.pad != 1 || a.dilate || a.in_shared) return false;
     if (a.out_step != 1 || a.Ho != a.H || a.Wo != a.W) return false;
-    if (a.Cin % CK || a.CoutP % BN || a.Cout % 8 || a.N % a.ipe) return false;
+    if (a.Cin % CK || a.Cout % 8 || a.N % a.ipe) return false;
+    // 64 output-channel rows: the NT = 1 instantiation of the persistent kernel only (forward launches, >= 2 channel chunks; the
+    // 64 -> 64 layers belong to conv_res.hip's resident-filter kernels, which conv_igemm_launch asks first)
+    const bool narrow = conv_dma_is_narrow(a);
+    if (a.CoutP % BN && !narrow) return false;
     if ((long long)a.ipe * a.Ho * a.Wo < 4096) return false;
     auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     int lTW = p2(a.Wo); if (lTW > 5) lTW = 5;
@@ -1173,6 +1207,7 @@ bool conv_dma_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf
     a.n_groups = (a.ipe + TN - 1) / TN;
     a.tiles_y = (a.Ho + (1 << lTH) - 1) >> lTH;
     a.tiles_x = (a.Wo + (1 << lTW) - 1) >> lTW;
+    if (narrow && !stream_geometry_ok(a, pb)) return false;
     *mblocks = (a.N / a.ipe) * a.n_groups * a.tiles_y * a.tiles_x;
     *smem = need < (size_t)BM / 2 * BN * 4 ? (size_t)BM / 2 * BN * 4 : need;
     *pbuf = pb;
@@ -1186,6 +1221,7 @@ bool conv_dma_uses_mf16(const ConvArgs& a) {
 
 // the persistent, streaming instantiation (round 4): forward launches whose piece decode the magic-number division reproduces
 bool conv_dma_uses_stream(const ConvArgs& a0) {
+    if (conv_dma_is_narrow(a0)) return true;             // (conv_dma_plan has checked the geometry)
     const char* ev = getenv("PMOE_DMA_STREAM");
     if (ev && !atoi(ev)) return false;
     if (!(a0.res_mode == PMOE_RES_NONE && !a0.bias && a0.act == PMOE_ACT_NONE && a0.drop_p == 0.f)) return false;
@@ -1196,13 +1232,7 @@ bool conv_dma_uses_stream(const ConvArgs& a0) {
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
     if (!conv_dma_plan(a, PMOE_DT_BF16, &mblocks, &smem, &pbuf)) return false;
-    if (pbuf < 160 * 256) return false;                  // rows 0..159 of the epilogue's staging live in a patch buffer
-    const int PW = (1 << a.lTW) + 2, PH = (1 << a.lTH) + 2;
-    const int npiece = (a.TN * PH * PW + 7) / 8;
-    const int mpw = 65536 / PW + 1, mph = 65536 / PH + 1;
-    for (int pp = 0; pp < npiece * 8; ++pp)
-        if (((pp * mpw) >> 16) != pp / PW || ((((pp / PW) * mph) >> 16) != (pp / PW) / PH)) return false;
-    return a.TN * PH < 1024 && PW < 1024 && a.ipe < 2047;      // the packed (image, row, column) fields of a piece
+    return stream_geometry_ok(a, pbuf);
 }
 
 // the producer-wave instantiation (round 4): forward launches -- nothing added to or derived from a side input in the epilogue
@@ -1215,6 +1245,13 @@ bool conv_dma_uses_producer(const ConvArgs& a) {
     return a.res_mode == PMOE_RES_NONE && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f;
 }
 
+// plan code of a launch conv_dma_plan accepts: 5007 / 5017 = conv3x3_dma_kernel<MF16>, + 20 with the producer wave, + 40 =
+// conv3x3_dma_stream_kernel<MF16>, 5067 = conv3x3_dma_stream_kernel<false, true> (64-cout tiles)
+int conv_dma_plan_code(const ConvArgs& a) {
+    if (conv_dma_is_narrow(a)) return 5067;
+    return (conv_dma_uses_mf16(a) ? 5017 : 5007) + (conv_dma_uses_stream(a) ? 40 : conv_dma_uses_producer(a) ? 20 : 0);
+}
+
 int conv_dma_launch(ConvArgs a, hipStream_t st) {
     int mblocks = 0, pbuf = 0;
     size_t smem = 0;
@@ -1224,16 +1261,20 @@ int conv_dma_launch(ConvArgs a, hipStream_t st) {
     // higher sustained clock buys).  PMOE_DMA_MF16=0 | 1 forces one shape (read per launch).
     if (conv_dma_uses_stream(a)) {
         // persistent workgroups, one per CU; the request stream of each runs across its tiles
-        const int ntiles = mblocks * (a.CoutP / BN);
+        const bool narrow = conv_dma_is_narrow(a);
+        const int ntiles = narrow ? mblocks : mblocks * (a.CoutP / BN);
         const int PWp = (1 << a.lTW) + 2, PHp = (1 << a.lTH) + 2;
         const int mpw = 65536 / PWp + 1, mph = 65536 / PHp + 1;
         int grid = ntiles < 256 ? ntiles : 256;
-        if (conv_dma_uses_mf16(a)) {
+        if (narrow) {
+            HIP_RET((ensure_dyn_lds<conv3x3_dma_stream_kernel<false, true>>(160 * 1024)));
+            hipLaunchKernelGGL((conv3x3_dma_stream_kernel<false, true>), dim3(grid), dim3(NTHR + 4 * 64), smem, st, a, pbuf, ntiles, mpw, mph);
+        } else if (conv_dma_uses_mf16(a)) {
             HIP_RET((ensure_dyn_lds<conv3x3_dma_stream_kernel<true>>(160 * 1024)));
-            hipLaunchKernelGGL(conv3x3_dma_stream_kernel<true>, dim3(grid), dim3(NTHR + 4 * 64), smem, st, a, pbuf, ntiles, mpw, mph);
+            hipLaunchKernelGGL((conv3x3_dma_stream_kernel<true>), dim3(grid), dim3(NTHR + 4 * 64), smem, st, a, pbuf, ntiles, mpw, mph);
         } else {
             HIP_RET((ensure_dyn_lds<conv3x3_dma_stream_kernel<false>>(160 * 1024)));
-            hipLaunchKernelGGL(conv3x3_dma_stream_kernel<false>, dim3(grid), dim3(NTHR + 4 * 64), smem, st, a, pbuf, ntiles, mpw, mph);
+            hipLaunchKernelGGL((conv3x3_dma_stream_kernel<false>), dim3(grid), dim3(NTHR + 4 * 64), smem, st, a, pbuf, ntiles, mpw, mph);
         }
     } else if (conv_dma_uses_producer(a)) {
         if (conv_dma_uses_mf16(a)) {

@@ -663,7 +663,7 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         size_t sm;
         if (conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm))
             return 1000 + plan.log_rb + (conv_res_pipe_ok(a) ? 240 : 100) + (a.bias ? 10 : 0);
-        if (!gemm_skinny_ok(a, dtype) && conv_dma_plan(c, dtype, &mb, &sm, &pb)) return (conv_dma_uses_mf16(a) ? 5017 : 5007) + (conv_dma_uses_stream(a) ? 40 : conv_dma_uses_producer(a) ? 20 : 0);
+        if (!gemm_skinny_ok(a, dtype) && conv_dma_plan(c, dtype, &mb, &sm, &pb)) return conv_dma_plan_code(a);
         return PMOE_ERR_UNSUPPORTED;
     }
     if (gemm_skinny_ok(a, dtype)) return 3000;           // gemm_skinny_kernel
@@ -694,7 +694,7 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         ConvArgs d = a;
         int mbd, pb;
         size_t sm;
-        if (conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return (conv_dma_uses_mf16(a) ? 5017 : 5007) + (conv_dma_uses_stream(a) ? 40 : conv_dma_uses_producer(d) ? 20 : 0);   // conv3x3_dma_kernel<MF16, PROD> | conv3x3_dma_stream_kernel<MF16>
+        if (conv_dma_plan(d, dtype, &mbd, &sm, &pb)) return conv_dma_plan_code(a);       // conv3x3_dma_kernel<MF16, PROD> | conv3x3_dma_stream_kernel<MF16, NT>
         d = a;
         if (conv_dma_s2_plan(d, dtype, &mbd, &sm, &pb)) return 5207;       // conv3x3s2_dma_kernel
     }

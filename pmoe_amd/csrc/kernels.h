@@ -68,6 +68,8 @@ int conv_dma_launch(ConvArgs a, hipStream_t st);
 bool conv_dma_uses_mf16(const ConvArgs& a);
 bool conv_dma_uses_producer(const ConvArgs& a);
 bool conv_dma_uses_stream(const ConvArgs& a);
+bool conv_dma_is_narrow(const ConvArgs& a);
+int conv_dma_plan_code(const ConvArgs& a);
 // ... on the block-scaled fp8 matrix instruction (e4m3 weights and activations)
 bool conv_dma_f8_plan(ConvArgs& a, int dtype, int* mblocks, size_t* smem, int* pbuf);
 int conv_dma_f8_launch(ConvArgs a, hipStream_t st);      // which instantiation: <true> = v_mfma_f32_16x16x32_bf16

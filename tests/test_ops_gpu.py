@@ -227,6 +227,22 @@ def test_conv_baseline_layer_shapes_bf16(case, plan):
     _conv_case(case, torch.bfloat16, plan)
 
 
+# BASELINE config 4: the 64-output-channel convolutions over >= 128 input channels (the U-Nets' `up_forw_4.0`, 128 -> 64 at full
+# resolution; model/blocks/unet.py:57-63) on conv3x3_dma_stream_kernel<false, true>: 256-pixel x 64-cout tiles
+NARROW_CONV_CASES = [
+    ((1, 2, 128, 64, 128, 128, 3, 1), (5067, None, None)),     # two chunks, 32 x 8 pixel tiles, 128 tiles for the persistent grid
+    ((2, 3, 192, 64, 40, 56, 3, 1), (5067, None, None)),       # three chunks, ragged tiles, 2 experts x 3 images
+    ((1, 17, 128, 56, 16, 16, 3, 1), (5067, None, None)),      # 56 of 64 output channels, one 16 x 16 image per tile, 17 images
+]
+
+
+@pytest.mark.parametrize("case,plan", NARROW_CONV_CASES)
+def test_conv_64_output_channel_tiles(case, plan, monkeypatch):
+    _conv_case(case, torch.bfloat16, plan)
+    monkeypatch.setenv("PMOE_DMA_NARROW", "0")              # the A/B partner: the generic register-staged kernel
+    _conv_case(case, torch.bfloat16, (741, None, None))
+
+
 # (E_bn, images per BN set, channels, H, W, conv runs per image?, bias?) -> kernel code
 DBN_CASES = [
     ((2, 2, 64, 128, 128, False, False), 1247),        # layer1 conv2 data gradient: conv3x3_respipe_kernel<false, 2>, persistent workgroups
