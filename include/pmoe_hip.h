@@ -48,12 +48,20 @@ extern "C" {
  * so the separate reduce pass over (dy, z) disappears (autograd of nn.BatchNorm2d + nn.ReLU in torchvision's BasicBlock
  * and model/blocks/basics.py:93-100).  bf16, 3x3 stride-1 layers on the LDS-DMA kernels only (pmoe_conv2d_plan says). */
 #define PMOE_RES_DBN 6
+/* round 4 (BASELINE config 4, the frozen U-Nets' conv -> BatchNorm -> ReLU -> conv pairs of model/blocks/unet.py:14-24 in train
+ * mode): no side input in the epilogue (`res` must be NULL) -- the convolution's INPUT is the pre-activation z of a BatchNorm +
+ * ReLU, `bn_coef` = that BatchNorm's [4][n/bn_ipe][cin] f32 coefficients, and the value the matrix cores see is
+ * bf16(max((in - mean) * gamma*invstd + beta, 0)): exactly what pmoe_bn_apply(relu = 1) would have written, evaluated in LDS on the
+ * halo patch, so that pass and the activation tensor between the two convolutions do not exist.  Forward launches without bias /
+ * activation / dropout; bf16, the 64 -> 64-channel 3x3 stride-1 resident-filter kernel only (pmoe_conv2d_plan returns 1267,
+ * anything else PMOE_ERR_UNSUPPORTED: the caller then runs pmoe_bn_apply + a plain launch). */
+#define PMOE_RES_INBN 7
 
 /* ABI revision of this header: bumped whenever a descriptor struct, an argument list or a buffer contract changes
  * (100: round 1; 200: round 2 -- pmoe_conv_desc 160 -> 176 bytes, pmoe_wgrad_desc.part_ws, pmoe_bn_bwd_reduce's gmask_out,
- * dw_ws overwritten instead of accumulated; 300: round 3; 400: round 4 -- pmoe_wgrad_desc.bn_*).  A binding compares pmoe_version() with the value it was
+ * dw_ws overwritten instead of accumulated; 300: round 3; 400: round 4 -- pmoe_wgrad_desc.bn_*; 401: PMOE_RES_INBN).  A binding compares pmoe_version() with the value it was
  * written against before its first launch (pmoe_amd/hip.py:load does). */
-#define PMOE_ABI_VERSION 400
+#define PMOE_ABI_VERSION 401
 int pmoe_version(void);
 const char* pmoe_error_string(int code);
 /* sizeof() of the descriptor structs as compiled (which: 0 = pmoe_conv_desc, 1 = pmoe_wgrad_desc);
@@ -115,7 +123,7 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
  *   1400 + MT                conv1x1_direct_kernel<MT>             (1x1, stride 1 | 2, >= 8192 pixels per expert, 64..512 input channels, conv_c1x1.hip)
  *   1316                     conv3x3_c16_kernel                    (16 input channels: direct MFMA form, no LDS staging, conv_c16.hip)
  *   1207 + 10 b + 20 m       conv3x3_respipe_kernel<b, m>          (resident filter bank, halo patches by LDS-DMA, read-out of tile t in registers under the MFMAs
- *                                                                   of tile t+1, conv_res.hip; b: per-expert bias row, m: 0 plain | 1 PMOE_RES_ADD | 2 PMOE_RES_DBN)
+ *                                                                   of tile t+1, conv_res.hip; b: per-expert bias row, m: 0 plain | 1 PMOE_RES_ADD | 2 PMOE_RES_DBN | 3 PMOE_RES_INBN)
  *   1107 | 1117              conv3x3_resdma_kernel<false | true>   (its LDS-staged predecessor, PMOE_RES_PIPE=0)
  *   2000 + LOG_RB            conv_igemm_lite_kernel<T, LOG_RB>     (8-wave 256 x 128 tile, two workgroups per CU)
  *   5007 | 5017              conv3x3_dma_kernel<false | true>      (LDS-DMA staged 3x3 stride-1 kernel, >= 128 channels, conv_dma.hip; <true>: 16x16x32 MFMA shape, >= 256 input channels)

@@ -11,7 +11,7 @@ static ConvArgs to_args(const pmoe_conv_desc* d) {
     a.res_ld = d->res_ld; a.res_coff = d->res_coff;
     a.ipe = d->ipe; a.in_shared = d->in_shared;
     a.ks = d->ks; a.stride = d->stride; a.pad = d->pad; a.dilate = d->dilate;
-    a.act = d->act; a.res_mode = d->res ? d->res_mode : PMOE_RES_NONE;
+    a.act = d->act; a.res_mode = (d->res || d->res_mode == PMOE_RES_INBN) ? d->res_mode : PMOE_RES_NONE;
     a.drop_p = d->drop_p; a.seed = d->seed;
     a.oscale = d->out_scale; a.in_scale = d->in_scale; a.w_fp8 = d->w_fp8; a.in_fp8 = d->in_fp8;
     a.bn = d->bn_coef; a.bn_ipe = d->bn_ipe > 0 ? d->bn_ipe : d->ipe;
@@ -35,6 +35,10 @@ static int check_conv(const pmoe_conv_desc* d) {
     if (d->drop_p < 0.f || d->drop_p >= 1.f) return PMOE_ERR_ARG;
     if (d->res && d->res_mode == PMOE_RES_DBN &&
         (!d->bn_coef || !d->stats || d->dtype != PMOE_DT_BF16 || (d->bn_ipe > 0 && (d->bn_ipe % d->ipe || d->n % d->bn_ipe))))
+        return PMOE_ERR_ARG;
+    if (d->res_mode == PMOE_RES_INBN &&
+        (d->res || !d->bn_coef || d->dtype != PMOE_DT_BF16 || d->bias || d->act != PMOE_ACT_NONE || d->drop_p != 0.f || d->in_shared ||
+         d->w_fp8 || d->dilate || (d->bn_ipe > 0 && (d->bn_ipe % d->ipe || d->n % d->bn_ipe))))
         return PMOE_ERR_ARG;
     // geometry: forward conv / transposed (dilate) relation between (h,w) and (ho,wo)
     if (!d->dilate) {

@@ -599,6 +599,14 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
         size_t sm;
         return conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &sm) ? conv_c1x1_launch(a, st) : PMOE_ERR_UNSUPPORTED;
     }
+    if (a.res_mode == PMOE_RES_INBN) {               // BatchNorm + ReLU of the INPUT on load: conv3x3_respipe_kernel<false, 3> only
+        ResPlan plan;
+        int pb, mpw, mph;
+        size_t sm;
+        if (!a.bias && conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) && conv_res_pipe_ok(a))
+            return conv_res_launch(a, plan, st);
+        return PMOE_ERR_UNSUPPORTED;
+    }
     if (a.res_mode == PMOE_RES_DBN) {                // BatchNorm-backward reductions in the epilogue: the two LDS-DMA kernels only
         ResPlan plan;
         int pb, mpw, mph, mb;
@@ -656,6 +664,13 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
         int wpe, tpe, slabs, mt;
         size_t smx;
         return conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &smx) ? 1450 + mt : PMOE_ERR_UNSUPPORTED;
+    }
+    if (a.res_mode == PMOE_RES_INBN) {
+        ResPlan plan;
+        int pb, mpw, mph;
+        size_t sm;
+        return (!a.bias && conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) && conv_res_pipe_ok(a))
+                   ? 1267 : PMOE_ERR_UNSUPPORTED;        // conv3x3_respipe_kernel<false, 3>
     }
     if (a.res_mode == PMOE_RES_DBN) {
         ResPlan plan;

@@ -605,7 +605,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
 //   * no LDS staging, ONE barrier per tile (patch t is free for the request of tile t+2);
 //   * the per-lane geometry of the 6 patch pieces and 2 output pixels is tile-invariant and computed once; the tile walk is
 //     incremental (no divisions in the loop).
-// MODE: 0 = plain (+ BatchNorm partial sums of the stored values when a.stats), 1 = PMOE_RES_ADD, 2 = PMOE_RES_DBN.
+// MODE: 0 = plain (+ BatchNorm partial sums of the stored values when a.stats), 1 = PMOE_RES_ADD, 2 = PMOE_RES_DBN,
+// 3 = PMOE_RES_INBN (round 4, BASELINE config 4): mode 0 whose INPUT is the pre-activation z of a BatchNorm + ReLU -- the frozen
+// U-Nets' `conv -> BatchNorm -> ReLU -> conv` pairs (model/blocks/unet.py:14-24) in train mode, where nothing is saved for a
+// backward pass and z has this one consumer: the pmoe_bn_apply pass between the two convolutions (read z, write a: 1.07 GB at
+// 256 x 256 x 64 channels x 64 images, 0.2 ms, 20 of them per step) disappears.  Each wave turns the patch pieces IT requested
+// into bf16(max((z - mean) * scale + shift, 0)) in place -- the arithmetic and rounding of bn_apply_kernel, so the MFMA operand
+// is bit-identical to the tensor that pass would have written -- between the MFMAs of the tile BEFORE the one that reads them
+// (steps 20..31: the requests were issued at the start of the tile, ahead of the read-out's stores in the wave's in-order
+// vmcnt stream, so `vmcnt(4)` = they have landed); a lane owns channel group lane & 7 of its pixel row, i.e. the physical 16-byte
+// slot (lane & 7) ^ swizzle(column), so its 24 coefficients are the same for every piece.  Pixels outside the image are not
+// touched: the DMA's zero fill stays zero (relu(bn(0)) is not 0).
 template <bool BIAS, int MODE>
 __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs a, const int tiles_per_expert,
                                                                  const int wgs_per_expert, const int pbuf_bytes,
@@ -640,6 +650,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
         const int nset = a.N / a.bn_ipe;
         lbn[tid] = (tid & 63) < a.Cout ? a.bn[((size_t)(tid >> 6) * nset + (e * a.ipe) / a.bn_ipe) * a.Cout + (tid & 63)] : 0.f;
     }
+    constexpr bool HASRES = MODE == 1 || MODE == 2, INBN = MODE == 3;
+    if (INBN && tid < 256) {                             // the INPUT's BatchNorm: same four rows over the 64 input channels
+        const int nset = a.N / a.bn_ipe;
+        lbn[tid] = a.bn[((size_t)(tid >> 6) * nset + (e * a.ipe) / a.bn_ipe) * a.Cin + (tid & 63)];
+    }
 
     constexpr int OOB = 0x7ff80000;
     const bf16* inb = (const bf16*)a.in + (size_t)e * a.ipe * a.H * a.W * a.in_ld + a.in_coff;
@@ -650,9 +665,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
     bf16* outb = (bf16*)a.out + (size_t)e * a.ipe * a.Ho * a.Wo * a.out_ld + a.out_coff;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
         (void*)outb, (short)0, (int)(((long long)a.ipe * a.Ho * a.Wo * a.out_ld - a.out_coff) * 2), 0x00020000);
-    const bf16* resb = MODE ? (const bf16*)a.res + (size_t)e * a.ipe * a.Ho * a.Wo * a.res_ld + a.res_coff : (const bf16*)a.in;
+    const bf16* resb = HASRES ? (const bf16*)a.res + (size_t)e * a.ipe * a.Ho * a.Wo * a.res_ld + a.res_coff : (const bf16*)a.in;
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)resb, (short)0, MODE ? (int)(((long long)a.ipe * a.Ho * a.Wo * a.res_ld - a.res_coff) * 2) : 0, 0x00020000);
+        (void*)resb, (short)0, HASRES ? (int)(((long long)a.ipe * a.Ho * a.Wo * a.res_ld - a.res_coff) * 2) : 0, 0x00020000);
 
     // resident filter bank: 72 pieces of 8 rows (piece = tap * 8 + row block), 9 per wave
 #pragma unroll
@@ -731,8 +746,53 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
 #pragma unroll
         for (int q = 0; q < 4; ++q) s1[k][q] = s2[k][q] = f32x2{0.f, 0.f};
 
+    // PMOE_RES_INBN: piece i of this wave's share of the patch of tile `w` in buffer `buf`, BatchNorm + ReLU in place
+    auto unpack2 = [](unsigned w) { return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)}; };
+    auto pack2 = [](f32x2 v) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, bf16x2{(bf16)v[0], (bf16)v[1]});
+    };
+    // (straight-line code, in two halves so that the scheduler can put MFMAs between the LDS read and its use: a branch here would
+    //  park the wave -- and its SIMD partner, which is in the same phase -- for the read's round trip)
+    f32x2 cmu[4], csc[4], csh[4];                        // this lane's channel group: 8 x (mean, gamma * invstd, beta)
+    auto xform_coef = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cmu[q] = *reinterpret_cast<const f32x2*>(lbn + (lane & 7) * 8 + 2 * q);
+            csc[q] = *reinterpret_cast<const f32x2*>(lbn + 128 + (lane & 7) * 8 + 2 * q);
+            csh[q] = *reinterpret_cast<const f32x2*>(lbn + 192 + (lane & 7) * 8 + 2 * q);
+        }
+    };
+    // (a wave without an i-th piece rewrites its piece 0 unchanged: no branch in the MFMA block)
+    auto xform_addr = [&](int buf, const int i) {
+        const int ii = i < my_pieces ? i : 0;
+        const int px = (i < my_pieces ? pgeo[i] : pgeo[0]) & 0x3ff;
+        return pbuf + buf * pbuf_bytes + ((wave + 8 * ii) << 10) + ((lane >> 3) << 7) + (((lane & 7) ^ ((px >> 1) & 7)) << 4);
+    };
+    auto xform_load = [&](int buf, const int i) { return *reinterpret_cast<const v4u*>(xform_addr(buf, i)); };
+    auto xform_store = [&](const Walk& w, int buf, const int i, const v4u z) {
+        const int n0 = w.q * a.TN, Y0 = w.py * TH - 1, X0 = w.px * TW - 1;
+        const int n = n0 + (pgeo[i] >> 20), Y = Y0 + ((pgeo[i] >> 10) & 0x3ff), X = X0 + (pgeo[i] & 0x3ff);
+        const bool ok = n < a.ipe && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+        v4u o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x2 v = __builtin_elementwise_fma(unpack2(z[q]) - cmu[q], csc[q], csh[q]);      // (bn_apply_kernel: centred, one fma)
+            v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+            o[q] = i < my_pieces ? (ok ? pack2(v) : 0u) : z[q];      // outside the image the DMA's zero fill stays zero
+        }
+        *reinterpret_cast<v4u*>(xform_addr(buf, i)) = o;
+    };
+
     if (ntile > 0) issue_patch(cur, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // filter bank + first patch (DMA), bias / coefficient rows
+    if (INBN && ntile > 0) {
+        __builtin_amdgcn_s_barrier();                    // (the coefficient rows of every wave are in LDS)
+        xform_coef();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xform_store(cur, 0, i, xform_load(0, i));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 
     // the tile whose read-out is pending: packed results, its residual / z vectors, validity and store offset
@@ -744,11 +804,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
 #pragma unroll
         for (int k = 0; k < 2; ++k) prev[mt][k] = rprev[mt][k] = v4u{0u, 0u, 0u, 0u};
 
-    auto unpack2 = [](unsigned w) { return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)}; };
-    auto pack2 = [](f32x2 v) {
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        return __builtin_bit_cast(unsigned, bf16x2{(bf16)v[0], (bf16)v[1]});
-    };
     // read-out of channel vector k of the pending tile (both pixels): straight-line, stores of invalid pixels go out of range
     auto readout = [&](const int k) {
         v4u pk[2];
@@ -805,7 +860,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             val[mt] = n0 + (ogeo[mt] >> 20) < a.ipe && oy0 + ((ogeo[mt] >> 10) & 0x3ff) < a.Ho && ox0 + (ogeo[mt] & 0x3ff) < a.Wo;
-            if (MODE) {
+            if (HASRES) {
                 // residual (a data gradient accumulating into the gradient another consumer left) / z of the BatchNorm whose
                 // backward reductions this launch carries: requested now, consumed one tile later
                 const unsigned rsoff = (unsigned)(((n0 * a.Ho + oy0) * a.Wo + ox0) * a.res_ld) * 2u;
@@ -834,6 +889,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
                 for (int k = 0; k < 16; ++k) acc[mt][k] = 0.f;
         }
         RLAP(0)                                          // patch requests, residual prefetch, accumulator init
+        v4u xz = v4u{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int st = 0; st < 36; ++st) {
             const int tap = st >> 2, ks = st & 3;
@@ -853,6 +909,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
             // ... in their first half (nothing is scheduled across this fence): the stores have the second half to be
             // acknowledged before the vmcnt(0) below has to wait for them
             if (st == 19) __builtin_amdgcn_sched_barrier(0);
+            if (INBN && t + 1 < ntile) {
+                // the next tile's patch: this wave's requests (issued before the read-out's four stores) have landed
+                if (st == 19) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); xform_coef(); }
+                if (st >= 20 && st < 32) {
+                    if (!(st & 1)) xz = xform_load(buf ^ 1, (st - 20) >> 1);
+                    else xform_store(nxt, buf ^ 1, (st - 20) >> 1, xz);
+                }
+            }
         }
         RLAP(1)                                          // 36 steps of fragment reads + MFMAs (+ the previous tile's read-out)
         // ---- this tile becomes the pending one: round to bf16, 8-byte pieces -> 16-byte channel vectors across the lane halves
@@ -869,7 +933,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
                     x[d] = r[0]; y[d] = r[1];
                 }
                 prev[mt][k] = v4u{x[0], x[1], y[0], y[1]};       // channels wn*32 + 16k + 8hh + 0..7 of pixel (mt, l31)
-                if (MODE) rprev[mt][k] = rz[mt][k];
+                if (HASRES) rprev[mt][k] = rz[mt][k];
             }
             pval[mt] = val[mt];
         }
@@ -931,8 +995,9 @@ bool conv_res_plan(const ConvArgs& a, int dtype, ResPlan* plan) {
     if (a.CoutP != 64 || a.Cout % 8 || (a.Cin != 64 && a.Cin != 16)) return false;
     if (a.act != PMOE_ACT_NONE || a.drop_p > 0.f) return false;
     if (a.bias && ((a.res_mode != PMOE_RES_NONE && a.res_mode != PMOE_RES_DBN) || a.Cin != 64)) return false;
-    if (a.res_mode != PMOE_RES_NONE && a.res_mode != PMOE_RES_ADD && a.res_mode != PMOE_RES_DBN) return false;
+    if (a.res_mode != PMOE_RES_NONE && a.res_mode != PMOE_RES_ADD && a.res_mode != PMOE_RES_DBN && a.res_mode != PMOE_RES_INBN) return false;
     if (a.res_mode == PMOE_RES_DBN && a.Cin != 64) return false;    // (conv3x3_resdma_kernel only: conv_igemm_launch)
+    if (a.res_mode == PMOE_RES_INBN && (a.Cin != 64 || a.in_shared || !a.bn)) return false;      // (conv3x3_respipe_kernel<false, 3> only)
     if (a.N % a.ipe || a.Ho != a.H || a.Wo != a.W) return false;
     auto p2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     int lTW = p2(a.Wo); if (lTW > 5) lTW = 5;
@@ -1013,6 +1078,7 @@ int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
     if (conv_res_dma_ok(a, p, &pb, &mpw, &mph, &sm)) {
         if (conv_res_pipe_ok(a)) {
             const int mode = a.res_mode == PMOE_RES_DBN ? 2 : a.res_mode == PMOE_RES_ADD ? 1 : 0;
+            if (a.res_mode == PMOE_RES_INBN) return launch_respipe<false, 3>(a, p, grid, sm, pb, mpw, mph, st);
             if (a.bias) return mode == 2 ? launch_respipe<true, 2>(a, p, grid, sm, pb, mpw, mph, st)
                              : mode == 1 ? launch_respipe<true, 1>(a, p, grid, sm, pb, mpw, mph, st)
                                          : launch_respipe<true, 0>(a, p, grid, sm, pb, mpw, mph, st);
@@ -1020,6 +1086,7 @@ int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
                  : mode == 1 ? launch_respipe<false, 1>(a, p, grid, sm, pb, mpw, mph, st)
                              : launch_respipe<false, 0>(a, p, grid, sm, pb, mpw, mph, st);
         }
+        if (a.res_mode == PMOE_RES_INBN) return PMOE_ERR_UNSUPPORTED;
         const char* evp = getenv("PMOE_RES_PREFETCH");
         a.prefetch = !(evp && !atoi(evp));
         if (a.bias) {
@@ -1031,6 +1098,7 @@ int conv_res_launch(ConvArgs a, const ResPlan& p, hipStream_t st) {
         }
         return (int)hipGetLastError();
     }
+    if (a.res_mode == PMOE_RES_INBN) return PMOE_ERR_UNSUPPORTED;
     if (p.log_rb == 7 && a.bias) {
         HIP_RET((ensure_dyn_lds<conv3x3_res_kernel<7, true>>(163840)));
         hipLaunchKernelGGL((conv3x3_res_kernel<7, true>), grid, block, p.smem + 256, st, a, p.tiles_per_expert,

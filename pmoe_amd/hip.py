@@ -15,10 +15,11 @@ import torch
 _LIB_PATH = Path(os.environ.get("PMOE_HIP_LIB") or Path(__file__).resolve().parent / "libpmoe_hip.so")
 _lib = None
 
-ABI_VERSION = 400            # include/pmoe_hip.h: PMOE_ABI_VERSION
+ABI_VERSION = 401            # include/pmoe_hip.h: PMOE_ABI_VERSION
 DT_BF16, DT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
-RES_NONE, RES_ADD, RES_DRELU, RES_DELU, RES_DTANH, RES_DSIGMOID, RES_DBN = 0, 1, 2, 3, 4, 5, 6
+RES_NONE, RES_ADD, RES_DRELU, RES_DELU, RES_DTANH, RES_DSIGMOID, RES_DBN, RES_INBN = 0, 1, 2, 3, 4, 5, 6, 7
+ERR_ARG, ERR_UNSUPPORTED = -1, -2      # include/pmoe_hip.h: PMOE_ERR_*
 # derivative mode that undoes each activation in the data-gradient epilogue (from the layer's saved output)
 RES_OF_ACT = {ACT_RELU: RES_DRELU, ACT_ELU: RES_DELU, ACT_TANH: RES_DTANH, ACT_SIGMOID: RES_DSIGMOID}
 ACT_BY_NAME = {"relu": ACT_RELU, "elu": ACT_ELU, "tanh": ACT_TANH, "sigmoid": ACT_SIGMOID}

@@ -58,7 +58,7 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
     d.res_coff = res_coff
     d.ipe, d.in_shared = ipe, int(in_shared)
     d.ks, d.stride, d.pad, d.dilate = ks, stride, pad, int(dilate)
-    d.act, d.res_mode = act, res_mode if res is not None else hip.RES_NONE
+    d.act, d.res_mode = act, res_mode if (res is not None or res_mode == hip.RES_INBN) else hip.RES_NONE
     d.drop_p, d.seed, d.dtype = float(drop_p), int(seed), dt(out)
     d.shuffle_c = int(shuffle2_c)
     if w_fp8:
@@ -72,6 +72,12 @@ def conv2d(x, w_packed, out, *, cin, cout, coutp, ipe, ks, stride, pad, dilate=F
             raise ValueError(f"conv2d: RES_DBN needs bn_coef [4, {nset}, {cout}] f32")
         if stats is None and not plan_only:
             raise ValueError("conv2d: RES_DBN writes the BatchNorm-backward reductions to `stats`")
+        d.bn_coef, d.bn_ipe = ptr(bn_coef, "bn_coef", torch.float32), int(bn_ipe or ipe)
+    if d.res_mode == hip.RES_INBN:
+        # the INPUT is the pre-activation z of a BatchNorm + ReLU: bn_coef = [4][n / bn_ipe][cin], applied on load
+        nset = n // (bn_ipe or ipe)
+        if res is not None or bn_coef is None or bn_coef.dtype != torch.float32 or tuple(bn_coef.shape) != (4, nset, cin):
+            raise ValueError(f"conv2d: RES_INBN takes no `res` and needs bn_coef [4, {nset}, {cin}] f32")
         d.bn_coef, d.bn_ipe = ptr(bn_coef, "bn_coef", torch.float32), int(bn_ipe or ipe)
     if in_shared and nin != ipe:
         raise ValueError("conv2d: shared input must hold exactly ipe images")

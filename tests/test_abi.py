@@ -42,7 +42,7 @@ def test_header_declares_the_bound_symbols():
 def test_library_exports_every_symbol(lib):
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.pmoe_version() == hip.ABI_VERSION == 400
+    assert lib.pmoe_version() == hip.ABI_VERSION == 401
     assert b"invalid" in lib.pmoe_error_string(-1)
 
 

@@ -253,6 +253,52 @@ DBN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [(2, 3, 64, 96), (1, 5, 40, 56), (3, 14, 16, 16)])
+def test_conv_applies_input_batchnorm_relu_on_load(case):
+    """PMOE_RES_INBN (round 4, the frozen U-Nets' conv -> BatchNorm -> ReLU -> conv pairs): the 64 -> 64 resident-filter kernel
+    evaluates relu(BatchNorm(z)) on its halo patch in LDS.  Against pmoe_bn_apply + the plain launch of the same kernel: output
+    and fused statistics BIT-identical (same arithmetic and rounding, same accumulation order); pixels outside the image must
+    stay zero (relu(bn(0)) is not), which the ragged cases and the shifted coefficients exercise."""
+    E, ipe, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    N, C_ = E * ipe, 64
+    BF = torch.bfloat16
+    z = nhwc(rnd((N, C_, H, W), g, BF, 2.0) + 0.3, C_, BF)
+    ws = [rnd((C_, C_, 3, 3), g, BF, (2.0 / (C_ * 9)) ** 0.5) for _ in range(E)]
+    wf, _, _ = pack(ws, 3, BF)
+    coef = torch.empty(4, E, C_, device=DEV)
+    coef[0] = rnd((E, C_), g, torch.float32, 0.5).to(DEV) + 0.3            # mean
+    coef[1] = 1.0                                                            # invstd (unused by the forward)
+    coef[2] = (rnd((E, C_), g, torch.float32, 0.3).abs() + 0.5).to(DEV)      # gamma * invstd
+    coef[3] = rnd((E, C_), g, torch.float32, 0.4).to(DEV) + 0.2              # beta: relu(bn(0)) > 0 for most channels
+    kw = dict(cin=C_, cout=C_, coutp=C_, ipe=ipe, ks=3, stride=1, pad=1)
+    rows = ops.conv2d_stat_rows(N, H, W, H, W, C_, C_, C_, ipe, 3, 1, 1, BF)
+    # the pair
+    a_ = torch.empty_like(z)
+    ops.bn_apply(z, None, a_, coef[2], coef[3], coef[0], ipe * H * W, E, C_, True)
+    ref, st_ref = torch.full_like(z, 7.0), torch.zeros(rows, 2, C_, device=DEV)
+    assert ops.conv2d(a_, wf, ref, plan_only=True, **kw) == 1207
+    ops.conv2d(a_, wf, ref, stats=st_ref, **kw)
+    # on load
+    out, st = torch.full_like(z, 5.0), torch.zeros(rows, 2, C_, device=DEV)
+    assert ops.conv2d(z, wf, out, res_mode=hip.RES_INBN, bn_coef=coef, plan_only=True, **kw) == 1267
+    ops.conv2d(z, wf, out, res_mode=hip.RES_INBN, bn_coef=coef, stats=st, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+    assert torch.equal(st, st_ref)
+    # and the pair itself against CPU fp32 (so that "identical" is not "identically wrong")
+    zc = z.float().cpu().permute(0, 3, 1, 2)
+    cc = coef.cpu()
+    yr = torch.cat([F.conv2d(torch.relu((zc[e * ipe:(e + 1) * ipe] - cc[0, e].view(1, -1, 1, 1)) * cc[2, e].view(1, -1, 1, 1)
+                                        + cc[3, e].view(1, -1, 1, 1)).to(BF).float(), ws[e].to(BF).float(), padding=1) for e in range(E)])
+    close(from_nhwc(out, C_), yr, BF, "conv over relu(bn(z)) applied on load")
+    # what the kernel does not serve says so (the caller then runs the pair)
+    w128, _, _ = pack([rnd((128, C_, 3, 3), g, BF, 0.1) for _ in range(E)], 3, BF)
+    o128 = torch.empty(N, H, W, 128, dtype=BF, device=DEV)
+    assert ops.conv2d(z, w128, o128, res_mode=hip.RES_INBN, bn_coef=coef, plan_only=True, cin=C_, cout=128, coutp=128, ipe=ipe,
+                      ks=3, stride=1, pad=1) == hip.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("case,plan", DBN_CASES)
 def test_conv_dgrad_with_batchnorm_reductions(case, plan):
     _dbn_case(case, plan)
