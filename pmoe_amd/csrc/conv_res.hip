@@ -616,6 +616,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
 // vmcnt stream, so `vmcnt(4)` = they have landed); a lane owns channel group lane & 7 of its pixel row, i.e. the physical 16-byte
 // slot (lane & 7) ^ swizzle(column), so its 24 coefficients are the same for every piece.  Pixels outside the image are not
 // touched: the DMA's zero fill stays zero (relu(bn(0)) is not 0).
+// Measured (tools/ab_inbn.py, 64 images of 256 x 256): plain launch 0.325 ms, this mode 0.396 ms, the pass it replaces 0.206 ms: a
+// pair costs 0.40 instead of 0.53 ms.  The +0.07 ms is not the vmcnt(4) wait (a build with the wait and no arithmetic: 0.328 ms),
+// not the coefficient reads (kept in registers for the kernel's lifetime: 0.390), not the VALU count (-25 %: 0.399) and not the
+// load -> use distance (three steps instead of one: 0.393); grouping the six stores in two bursts made it 0.57 ms -- the MFMA block
+// of this kernel has no idle issue slots to give (it runs at 93 % of the matrix pipe's time), so whatever is added to it is paid.
 template <bool BIAS, int MODE>
 __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs a, const int tiles_per_expert,
                                                                  const int wgs_per_expert, const int pbuf_bytes,
@@ -763,10 +768,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
             csh[q] = *reinterpret_cast<const f32x2*>(lbn + 192 + (lane & 7) * 8 + 2 * q);
         }
     };
-    // (a wave without an i-th piece rewrites its piece 0 unchanged: no branch in the MFMA block)
+    // (every wave has at least five pieces -- a 256-pixel tile's patch has >= 324 pixels = 41 pieces -- and a wave without a sixth
+    //  rewrites its piece 0 unchanged: no wave-level branch in the MFMA block; the lanes of pixels outside the image skip the store)
     auto xform_addr = [&](int buf, const int i) {
-        const int ii = i < my_pieces ? i : 0;
-        const int px = (i < my_pieces ? pgeo[i] : pgeo[0]) & 0x3ff;
+        const int ii = i < 5 || i < my_pieces ? i : 0;
+        const int px = (i < 5 || i < my_pieces ? pgeo[i] : pgeo[0]) & 0x3ff;
         return pbuf + buf * pbuf_bytes + ((wave + 8 * ii) << 10) + ((lane >> 3) << 7) + (((lane & 7) ^ ((px >> 1) & 7)) << 4);
     };
     auto xform_load = [&](int buf, const int i) { return *reinterpret_cast<const v4u*>(xform_addr(buf, i)); };
@@ -774,14 +780,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
         const int n0 = w.q * a.TN, Y0 = w.py * TH - 1, X0 = w.px * TW - 1;
         const int n = n0 + (pgeo[i] >> 20), Y = Y0 + ((pgeo[i] >> 10) & 0x3ff), X = X0 + (pgeo[i] & 0x3ff);
         const bool ok = n < a.ipe && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
         v4u o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x2 v = __builtin_elementwise_fma(unpack2(z[q]) - cmu[q], csc[q], csh[q]);      // (bn_apply_kernel: centred, one fma)
-            v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
-            o[q] = i < my_pieces ? (ok ? pack2(v) : 0u) : z[q];      // outside the image the DMA's zero fill stays zero
+            const f32x2 v = __builtin_elementwise_fma(unpack2(z[q]) - cmu[q], csc[q], csh[q]);      // (bn_apply_kernel: centred, one fma)
+            // ReLU on the rounded pair: a negative bf16 is a negative int16 (fmaxf on the f32 values gives the same bits except
+            // that -0 becomes +0 here)
+            const unsigned pk = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack2(v)), s16x2{0, 0}));
+            o[q] = i < 5 || i < my_pieces ? pk : z[q];
         }
-        *reinterpret_cast<v4u*>(xform_addr(buf, i)) = o;
+        if (ok || !(i < 5 || i < my_pieces)) *reinterpret_cast<v4u*>(xform_addr(buf, i)) = o;      // (the DMA's zero fill stays zero)
     };
 
     if (ntile > 0) issue_patch(cur, 0);
@@ -910,7 +919,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
             // acknowledged before the vmcnt(0) below has to wait for them
             if (st == 19) __builtin_amdgcn_sched_barrier(0);
             if (INBN && t + 1 < ntile) {
-                // the next tile's patch: this wave's requests (issued before the read-out's four stores) have landed
+                // the next tile's patch: this wave's requests (issued before the read-out's four stores) have landed.  One piece per
+                // two steps: its load at an even step, arithmetic and store at the next one
                 if (st == 19) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); xform_coef(); }
                 if (st >= 20 && st < 32) {
                     if (!(st & 1)) xz = xform_load(buf ^ 1, (st - 20) >> 1);

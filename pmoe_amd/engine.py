@@ -411,7 +411,9 @@ class ExpertGroupEngine:
         return torch.empty(n, h, w, c, dtype=dtype or self.dtype, device=self.dev)
 
     def _conv(self, x, layer, *, bias=True, act=hip.ACT_NONE, drop_p=0.0, out=None, out_coff=0, in_shared=False,
-              want_stats=False, tape=True):
+              want_stats=False, tape=True, in_bn=None):
+        """``in_bn``: x is the pre-activation z of a BatchNorm + ReLU and in_bn its [4, E, C] coefficient block -- the launch applies
+        them on load (PMOE_RES_INBN: untaped forward launches; the caller has asked pmoe_conv2d_plan)."""
         H, W = x.t.shape[1], x.t.shape[2]
         Ho = ops.conv_out_size(H, layer.ks, layer.stride, layer.pad)
         Wo = ops.conv_out_size(W, layer.ks, layer.stride, layer.pad)
@@ -442,7 +444,8 @@ class ExpertGroupEngine:
         ops.conv2d(xin, layer.w_f8 if f8 else layer.w_fwd, o.t, cin=layer.cinp, cout=layer.cout_st, coutp=layer.coutp,
                    ipe=self.B, ks=layer.ks, stride=layer.stride, pad=layer.pad, in_shared=in_shared, in_coff=x.coff,
                    out_coff=o.coff, bias=layer.bias_packed if bias else None, act=act, drop_p=drop_p, seed=seed,
-                   stats=stats, out_scale=layer.oscale if f8 else None, in_scale=self.fp8_in_scale)
+                   stats=stats, out_scale=layer.oscale if f8 else None, in_scale=self.fp8_in_scale,
+                   **(dict(res_mode=hip.RES_INBN, bn_coef=in_bn) if in_bn is not None else {}))
         o.act, o.drop_p = act, drop_p
         if self.debug_acts is not None and act == hip.ACT_RELU:
             self.debug_acts[layer.name] = (o.t, o.coff, layer.cout)
@@ -1263,12 +1266,12 @@ class ExpertGroupEngine:
         ops.nchw_to_nhwc(images.reshape(Bsz, cin, H, W).contiguous().float(), x0.t)
         return x0
 
-    def _conv_stats(self, x, layer, tape=True):
+    def _conv_stats(self, x, layer, tape=True, in_bn=None):
         # conv-epilogue statistics are plain sums (no sample to centre on before the conv has run): fine under
         # bf16 storage noise, not for the exact-f32 parity mode, which takes the centred colstats pass instead
         if self.training and self.fuse_conv_stats and self.dtype == torch.bfloat16:
-            return self._conv(x, layer, bias=False, want_stats=True, tape=tape)
-        return self._conv(x, layer, bias=False, tape=tape), None
+            return self._conv(x, layer, bias=False, want_stats=True, tape=tape, in_bn=in_bn)
+        return self._conv(x, layer, bias=False, tape=tape, in_bn=in_bn), None
 
     def _stem_in_bwd(self, x0, z1, gate, gapmean):
         dy = z1.grad

@@ -188,9 +188,32 @@ class PUNetEngine(ExpertGroupEngine):
     # ------------------------------------------------------------------ PU-Net forward
     fuse_bn_pool = True            # round 4: the down blocks' last BatchNorm + ReLU pass also writes MaxPool2d(2, 2) of its output
 
+    fuse_in_bn = True      # round 4: BatchNorm + ReLU between the two convolutions of a block applied ON LOAD by the second one
+
     def _conv3(self, x, blk, out=None, pool_to=None):
-        a = self._conv_bn(x, blk["c1"], blk["bn1"], relu=True)
-        return self._conv_bn(a, blk["c2"], blk["bn2"], relu=True, out=out, pool_to=pool_to)
+        """blocks/unet.py:14-24: (conv -> BatchNorm -> ReLU) x 2.  Untaped train-mode forward (the frozen U-Nets inside a training
+        step): the activation between the two convolutions has exactly one consumer and nothing is saved for a backward pass, so
+        where the second convolution's kernel can evaluate relu(bn1(z1)) on its halo patch (PMOE_RES_INBN: the 64-channel blocks)
+        the pass that would write it -- and the tensor -- do not exist."""
+        c1, bn1, c2 = blk["c1"], blk["bn1"], blk["c2"]
+        if (self.fuse_in_bn and not self.taping and self.training and self.dtype == torch.bfloat16 and self.fuse_conv_stats
+                and self.debug_acts is None and c2.w_f8 is None and c1.cout_st == c2.cinp == bn1.C):
+            n, h, w, _ = x.t.shape
+            ok = blk.get("_inbn")
+            if ok is None or ok[0] != (n, h, w):
+                probe = torch.empty(4, self.E, bn1.C, dtype=torch.float32, device=self.dev)
+                zz = torch.empty(n, h, w, c1.cout_st, dtype=self.dtype, device=self.dev)
+                oo = torch.empty(n, h, w, c2.cout_st, dtype=self.dtype, device=self.dev)
+                code = ops.conv2d(zz, c2.w_fwd, oo, cin=c2.cinp, cout=c2.cout_st, coutp=c2.coutp, ipe=self.B, ks=c2.ks,
+                                  stride=c2.stride, pad=c2.pad, res_mode=hip.RES_INBN, bn_coef=probe, plan_only=True)
+                ok = blk["_inbn"] = ((n, h, w), code == 1267)
+            if ok[1]:
+                z1, st1 = self._conv_stats(x, c1)
+                self._bn_coeffs(bn1, self.B * h * w, st1, st1.shape[0] // self.E, z1)
+                z2, st2 = self._conv_stats(z1, c2, in_bn=self._last_coef)
+                return self._bn(z2, blk["bn2"], relu=True, stats=st2, out=out, pool_to=pool_to)
+        a = self._conv_bn(x, c1, bn1, relu=True)
+        return self._conv_bn(a, c2, blk["bn2"], relu=True, out=out, pool_to=pool_to)
 
     def _maxpool2(self, x, cat=None, fused=None):
         """``fused``: the pooled tensor was already written by the pass that produced x (_bn, pool_to): only the tape entry is added."""

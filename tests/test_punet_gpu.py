@@ -121,3 +121,42 @@ def test_punet_contract(tmp_path):
     model.punet.unet.out.bias.requires_grad_(True)
     with pytest.raises(NotImplementedError, match="frozen"):
         model(dev["images"], dev["speed"], dev["command"])
+
+
+def test_punet_fused_forward_paths_match_the_unfused_ones(tmp_path):
+    """Round 4's fused forward paths of the frozen U-Nets -- BatchNorm + ReLU applied on load by the second convolution of a
+    64-channel block (PMOE_RES_INBN), MaxPool2d written by the BatchNorm pass, ConvTranspose2d scattering its own 2x2 blocks --
+    against the engine with each switch off: same kernels' arithmetic, so actions, speed and every BatchNorm running buffer of a
+    train-mode step are BIT-identical (bf16, batch 4, 128 x 128, T = 4 past + F = 2 predicted frames)."""
+    from oracle import weights as W
+    g = torch.load(GOLDEN / "p6_punet_b8_96_f2.pt", weights_only=False)
+    _, _, model, _ = build_pair(tmp_path, g, torch.bfloat16)
+    inp = W.make_inputs(4, 128, 128, seed=11)            # (power-of-two sides: the fused ConvTranspose2d store serves those)
+    eng = model._engine()
+    args = [inp[k].cuda() for k in ("images", "speed", "command")]
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(**switches):
+        model.load_state_dict(state0)
+        for k, v in switches.items():
+            assert hasattr(type(eng), k), k
+            setattr(eng, k, v)
+        try:
+            with torch.no_grad():
+                act, sp = model(*args)
+            torch.cuda.synchronize()
+            return act.clone(), sp.clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k}
+        finally:
+            for k in switches:
+                delattr(eng, k)                      # back to the class default
+
+    ref = run()
+    import pmoe_amd.ops as ops
+    ops.profile_begin()
+    run()
+    names = [meta.get("kernel") for name, meta, _ in ops.profile_end() if name == "conv2d"]
+    assert 1267 in names and (1452 in names or 1454 in names), sorted(set(map(str, names)))      # the fused kernels really ran
+    for sw in ("fuse_in_bn", "fuse_bn_pool", "fuse_upconv_shuffle"):
+        got = run(**{sw: False})
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), sw
+        assert got[2].keys() == ref[2].keys() and all(torch.equal(got[2][k], ref[2][k]) for k in ref[2]), sw
