@@ -426,6 +426,7 @@ __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(co
     constexpr int NT = NARROW ? 1 : 2, WPC = 4 * NT;     // WPC: pieces of a weight tile per producer wave
     static_assert(!(NARROW && MF16), "the 64-cout tile exists on the 32x32x16 shape only");
     constexpr int BN = 64 * NT, WSLOT = BN * RB;        // (shadow the 128-cout constants of this file)
+    STAMP_INIT                                           // (the -DPMOE_STAMP tools build never launches this kernel: conv_dma_uses_stream)
     ConvArgs a = a_in;
     a.res_mode = PMOE_RES_NONE; a.res = nullptr; a.bias = nullptr; a.act = PMOE_ACT_NONE; a.drop_p = 0.f; a.bn = nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1170,6 +1171,9 @@ static bool stream_geometry_ok(const ConvArgs& a, int pbuf) {
 // 64 output-channel rows over >= 128 input channels, nothing but the convolution (+ statistics): conv3x3_dma_stream_kernel<false, true>.
 // PMOE_DMA_NARROW=0: back to the generic kernel (A/B runs)
 bool conv_dma_is_narrow(const ConvArgs& a) {
+#ifdef PMOE_STAMP
+    return false;                                        // (the stamped epilogue ends the workgroup after its first tile)
+#endif
     const char* ev = getenv("PMOE_DMA_NARROW");
     if (ev && !atoi(ev)) return false;
     return a.CoutP == 64 && a.Cin >= 2 * CK && a.res_mode == PMOE_RES_NONE && !a.bias && a.act == PMOE_ACT_NONE && a.drop_p == 0.f;
@@ -1221,6 +1225,9 @@ bool conv_dma_uses_mf16(const ConvArgs& a) {
 
 // the persistent, streaming instantiation (round 4): forward launches whose piece decode the magic-number division reproduces
 bool conv_dma_uses_stream(const ConvArgs& a0) {
+#ifdef PMOE_STAMP
+    return false;                                        // (the stamped epilogue ends the workgroup after its first tile)
+#endif
     if (conv_dma_is_narrow(a0)) return true;             // (conv_dma_plan has checked the geometry)
     const char* ev = getenv("PMOE_DMA_STREAM");
     if (ev && !atoi(ev)) return false;
