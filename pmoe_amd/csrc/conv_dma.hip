@@ -420,6 +420,13 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
 // channels -- the frozen U-Nets' 128 -> 64 decoder convolutions at full resolution (model/blocks/unet.py:57-63, 10 launches per
 // step that the generic register-staged kernel served at 610-630 TFLOP/s).  Same 4 x 2 wave grid, a wave's tile is 64 pixels x 32
 // couts (one A fragment, two B fragments, two MFMAs per 16 channels), weight tiles of 8 KiB, staging rows of 128 bytes.
+// Measured and REMOVED (round 4, tools/ab_inbn.py): PMOE_RES_INBN on this kernel -- the producer waves turning every halo patch into
+// relu(BatchNorm(z)) in LDS between its landing (requests moved to taps 0..2, counted wait at barrier 4) and its first use, bit-identical
+// to pmoe_bn_apply + the plain launch.  With a quarter of the pieces on each of the four producers (three per tap at taps 4..7) a
+// 128-channel launch went 0.325 -> 0.404 ms against the 0.101 ms pass it replaces (pair 0.426 -> 0.404) and a 256-channel one 0.267 ->
+// 0.331 against 0.042 (a loss); with the two patch producers alone (six pieces per tap, reads grouped) 0.431 / 0.373 ms.  A piece costs
+// a producer ~300 cycles (two magic-number divisions, 28 VALU, an LDS round trip) on a SIMD it shares with two accumulating waves, and
+// every producer that arrives late holds the per-tap barrier for all twelve waves.  The 64-channel kernel keeps its variant (conv_res.hip).
 template <bool MF16, bool NARROW = false>
 __global__ void __launch_bounds__(NTHR + 4 * 64, 1) conv3x3_dma_stream_kernel(const ConvArgs a_in, const int pbuf_bytes, const int ntiles,
                                                                           const int magic_pw, const int magic_ph) {
