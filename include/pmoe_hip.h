@@ -129,6 +129,7 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
  *   5007 | 5017              conv3x3_dma_kernel<false | true>      (LDS-DMA staged 3x3 stride-1 kernel, >= 128 channels, conv_dma.hip; <true>: 16x16x32 MFMA shape, >= 256 input channels)
  *   5027 | 5037              conv3x3_dma_kernel<false | true, true> (round 4: the same with a ninth, request-only producer wave; launches without a side input / bias / activation)
  *   5047 | 5057              conv3x3_dma_stream_kernel<false | true> (round 4: those launches on persistent workgroups whose request stream runs across tile boundaries)
+ *   5067                     conv3x3_dma_stream_kernel<false, true>  (round 4: its 256-pixel x 64-output-channel tiles for 64 output channels over >= 128 input channels)
  *   5207                     conv3x3s2_dma_kernel                  (its stride-2 forward sibling: parity planes gathered by the DMA, conv_dma.hip)
  *   8000 + one of the above  the same tile with e4m3 operands (w_fp8)
  *   8507                     conv3x3_dma_f8_kernel                 (w_fp8 + in_fp8: LDS-DMA kernel on the block-scaled fp8 MFMA, conv_dma.hip)
