@@ -420,6 +420,11 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
 // channels -- the frozen U-Nets' 128 -> 64 decoder convolutions at full resolution (model/blocks/unet.py:57-63, 10 launches per
 // step that the generic register-staged kernel served at 610-630 TFLOP/s).  Same 4 x 2 wave grid, a wave's tile is 64 pixels x 32
 // couts (one A fragment, two B fragments, two MFMAs per 16 channels), weight tiles of 8 KiB, staging rows of 128 bytes.
+// Measured and REMOVED (round 4, tools/ab_ops.py): the data-gradient modes with a side input (PMOE_RES_DBN / PMOE_RES_ADD) on this kernel.
+// The 8-wave kernel prefetches the read-out's z / residual vectors under the last chunk in 32 registers; a 12-wave workgroup has 168 per
+// wave and the loop needs 156-162, so they were requested after the accumulators had been staged, flying across an LDS-only staging
+// barrier.  layer2.1.conv1's data gradient (PMOE_RES_ADD): 0.377 ms on the 8-wave kernel, 0.491 ms here (the plain data gradient of the
+// same shape: 0.287) -- the instantiation spills ~50 registers around the epilogue and the exposed round trip is paid per tile.
 // Measured and REMOVED (round 4, tools/ab_inbn.py): PMOE_RES_INBN on this kernel -- the producer waves turning every halo patch into
 // relu(BatchNorm(z)) in LDS between its landing (requests moved to taps 0..2, counted wait at barrier 4) and its first use, bit-identical
 // to pmoe_bn_apply + the plain launch.  With a quarter of the pieces on each of the four producers (three per tap at taps 4..7) a
