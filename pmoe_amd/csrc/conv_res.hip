@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_resdma_kernel(const ConvArgs a
 // not the coefficient reads (kept in registers for the kernel's lifetime: 0.390), not the VALU count (-25 %: 0.399) and not the
 // load -> use distance (three steps instead of one: 0.393); grouping the six stores in two bursts made it 0.57 ms -- the MFMA block
 // of this kernel has no idle issue slots to give (it runs at 93 % of the matrix pipe's time), so whatever is added to it is paid.
-template <bool BIAS, int MODE>
+template <bool BIAS, int MODE, bool RZ_LATE = true>
 __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs a, const int tiles_per_expert,
                                                                  const int wgs_per_expert, const int pbuf_bytes,
                                                                  const int magic_pw, const int magic_ph) {
@@ -869,16 +869,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             val[mt] = n0 + (ogeo[mt] >> 20) < a.ipe && oy0 + ((ogeo[mt] >> 10) & 0x3ff) < a.Ho && ox0 + (ogeo[mt] & 0x3ff) < a.Wo;
-            if (HASRES) {
-                // residual (a data gradient accumulating into the gradient another consumer left) / z of the BatchNorm whose
-                // backward reductions this launch carries: requested now, consumed one tile later
-                const unsigned rsoff = (unsigned)(((n0 * a.Ho + oy0) * a.Wo + ox0) * a.res_ld) * 2u;
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    rz[mt][k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(val[mt] && cval[k] ? rvo[mt] : (unsigned)OOB),
-                                                                      (int)(rsoff + 32u * k), 0);
-            }
         }
+        // residual (a data gradient accumulating into the gradient another consumer left) / z of the BatchNorm whose backward
+        // reductions this launch carries: consumed one tile later.  RZ_LATE (round 4, cycle stamps profiles/r04_respipe_dbn_stamps.log):
+        // requested at the start of the tile, the four loads made the MFMA-idle phase before the first MFMA 3240-3470 cycles long
+        // instead of 1525 (80 instead of 48 vector-memory instructions of the workgroup queue at the texture path's port while nothing
+        // else runs); requested between the MFMAs of steps 22 / 26, behind the read-out's stores, they queue there under the other
+        // waves' MFMAs, and the tile-end wait leaves them in flight (the youngest four of the wave's in-order stream).
+        const unsigned rsoff = HASRES ? (unsigned)(((n0 * a.Ho + oy0) * a.Wo + ox0) * a.res_ld) * 2u : 0u;
+        auto load_rz = [&](const int mt) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                rz[mt][k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)(val[mt] && cval[k] ? rvo[mt] : (unsigned)OOB),
+                                                                  (int)(rsoff + 32u * k), 0);
+        };
+        if (HASRES && !RZ_LATE) { load_rz(0); load_rz(1); }
         const char* patch = pbuf + buf * pbuf_bytes;
         f32x16 acc[2];
         if (BIAS) {
@@ -918,6 +923,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
             // ... in their first half (nothing is scheduled across this fence): the stores have the second half to be
             // acknowledged before the vmcnt(0) below has to wait for them
             if (st == 19) __builtin_amdgcn_sched_barrier(0);
+            if (HASRES && RZ_LATE && st == 22) load_rz(0);
+            if (HASRES && RZ_LATE && st == 26) load_rz(1);
             if (INBN && t + 1 < ntile) {
                 // the next tile's patch: this wave's requests (issued before the read-out's four stores) have landed.  One piece per
                 // two steps: its load at an even step, arithmetic and store at the next one
@@ -949,6 +956,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_respipe_kernel(const ConvArgs 
         }
         psoff = osoff;
         cur = nxt;
+        if (HASRES && RZ_LATE) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // (all but this tile's four side-input loads)
+        else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next tile's patch has landed (+ residual vectors, earlier stores)
         __builtin_amdgcn_s_barrier();                    // ... for every wave, and every wave is done reading this tile's patch
         RLAP(2)
@@ -1073,6 +1082,15 @@ bool conv_res_pipe_ok(const ConvArgs& a) {
 
 template <bool BIAS, int MODE>
 static int launch_respipe(const ConvArgs& a, const ResPlan& p, dim3 grid, size_t sm, int pb, int mpw, int mph, hipStream_t st) {
+    if constexpr (MODE == 1 || MODE == 2) {              // PMOE_RES_RZ_LATE=0: the side-input loads back at the start of the tile (A/B)
+        const char* ev = getenv("PMOE_RES_RZ_LATE");
+        if (ev && !atoi(ev)) {
+            HIP_RET((ensure_dyn_lds<conv3x3_respipe_kernel<BIAS, MODE, false>>(163840)));
+            hipLaunchKernelGGL((conv3x3_respipe_kernel<BIAS, MODE, false>), grid, dim3(512), sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb,
+                               mpw, mph);
+            return (int)hipGetLastError();
+        }
+    }
     HIP_RET((ensure_dyn_lds<conv3x3_respipe_kernel<BIAS, MODE>>(163840)));
     hipLaunchKernelGGL((conv3x3_respipe_kernel<BIAS, MODE>), grid, dim3(512), sm, st, a, p.tiles_per_expert, p.wgs_per_expert, pb, mpw, mph);
     return (int)hipGetLastError();

@@ -55,13 +55,19 @@ def main():
         y = torch.empty(N, H, H, cout, dtype=dt, device="cuda")
         rows = ops.conv2d_stat_rows(N, H, H, H, H, cin, cout, cout, B, 3, 1, 1, dt)
         plan = ops.conv2d_plan(N, H, H, H, H, cin, cout, cout, B, 3, 1, 1, dt) if hasattr(ops, "conv2d_plan") else None
-        for what, (src, w) in {"forward": (x, wf), "data gradient": (y, wd)}.items():
+        runs = {"forward": (x, wf), "data gradient": (y, wd)}
+        if "--dbn" in sys.argv and cin == cout:      # + the data gradient with the BatchNorm-backward epilogue (PMOE_RES_DBN)
+            runs["data gradient + BatchNorm reductions"] = (y, wd)
+        zz = torch.randn(N, H, H, cin, device="cuda").to(dt)
+        coef = torch.rand(4, E, cin, device="cuda") + 0.5
+        for what, (src, w) in runs.items():
             stats = torch.full((rows, 2, cout), -1.0, device="cuda")
+            extra = dict(res=zz, res_mode=hip.RES_DBN, bn_coef=coef) if what.endswith("reductions") else {}
             for _ in range(3):          # warm caches / clocks, keep the last
                 stats.fill_(-1.0)
                 ops.conv2d(src, w, y if what == "forward" else x, cin=cin if what == "forward" else cout,
                            cout=cout if what == "forward" else cin, coutp=cout if what == "forward" else cin, ipe=B, ks=3,
-                           stride=1, pad=1, stats=stats)
+                           stride=1, pad=1, stats=stats, **extra)
             torch.cuda.synchronize()
             v = stats.flatten().cpu()
             if cout == 64:                                        # conv3x3_resdma_kernel: 5 laps per tile, summed over the workgroup's tiles
