@@ -420,6 +420,15 @@ __global__ void __launch_bounds__(PROD ? NTHR + 64 : NTHR, PROD ? 1 : 2) conv3x3
 // channels -- the frozen U-Nets' 128 -> 64 decoder convolutions at full resolution (model/blocks/unet.py:57-63, 10 launches per
 // step that the generic register-staged kernel served at 610-630 TFLOP/s).  Same 4 x 2 wave grid, a wave's tile is 64 pixels x 32
 // couts (one A fragment, two B fragments, two MFMAs per 16 channels), weight tiles of 8 KiB, staging rows of 128 bytes.
+// Measured and REMOVED (round 4, late; profiles/r04_dma_stamps.log): ONE workgroup barrier per TWO taps.  The one-tile kernel's stamps show
+// 1510-1690 cycles per tap in the main loop against 1024 of MFMA time per SIMD, so the barrier of every odd stream tap was dropped (tiles
+// with whole pairs of channel chunks: the producers publish W(t), W(t+1) at barrier t and request W(t+2), W(t+3) into the two slots the
+// previous step read; a chunk's patch lands one tap earlier where its first tap is odd; both copies of the tap loop unrolled so that the
+// scheduler may carry fragment reads across the unsynchronised boundary).  Bit-identical, and worth +1.8 % on layer2, +3.5 % on layer3
+// (in-process A/B) -- but the paired 16x16x32 instantiation needs 178 registers of a 12-wave workgroup's 168, the 32x32x16 one it falls back
+// to is slower on the 256-channel levels, and config 4 as a whole went 109.1 -> 110.4 ms.  The per-tap overhead is not the barrier: at
+// 0.6-0.65 MFMA utilisation these kernels run at 1.9-2.0 GHz, a bare stream of the same MFMAs at ~1.45 (1481 TFLOP/s): the part is
+// power-limited, and cycles saved come back as clock lost.
 // Measured and REMOVED (round 4, tools/ab_ops.py): the data-gradient modes with a side input (PMOE_RES_DBN / PMOE_RES_ADD) on this kernel.
 // The 8-wave kernel prefetches the read-out's z / residual vectors under the last chunk in 32 registers; a 12-wave workgroup has 168 per
 // wave and the loop needs 156-162, so they were requested after the accumulators had been staged, flying across an LDS-only staging
