@@ -151,13 +151,17 @@ class PUNetEngine(ExpertGroupEngine):
         self.head = conv("action_pred.1", [e.action_pred[1]])
 
     def _ensure_built(self, dev, dtype):
+        # (its own key: the base class stores a longer tuple in _built_for -- compared against that one, this branch ran on EVERY
+        #  call, the fresh shadow tensors changed the pointer table, and all 79 weight packs of a PUNetExpert were redone every step:
+        #  1.2 ms of pack launches + the derived ConvTranspose2d packs per step until round 4)
         key = (str(dev), dtype)
-        if self._built_for != key:
+        if self.__dict__.get("_punet_built_for") != key:
             for up in self.up_layers:
                 up.alloc(dtype, dev)
                 up._derived_version = None
             for l in self.shadow_bns:
                 l.shadow = {k: torch.zeros(l.C, dtype=F32, device=dev) for k in ("gamma", "beta", "rm", "rv")}
+            self._punet_built_for = key
         super()._ensure_built(dev, dtype)
 
     def _extra_tables(self):

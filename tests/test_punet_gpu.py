@@ -160,3 +160,29 @@ def test_punet_fused_forward_paths_match_the_unfused_ones(tmp_path):
         got = run(**{sw: False})
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), sw
         assert got[2].keys() == ref[2].keys() and all(torch.equal(got[2][k], ref[2][k]) for k in ref[2]), sw
+
+
+def test_punet_engine_packs_its_weights_once(tmp_path):
+    """The packed bf16 weight layouts are cached on the parameters' version counters: a second step over unchanged weights must not
+    launch a single pack kernel (until round 4 the PU-Net engine rebuilt its pointer tables, and with them all 79 packs, every step)."""
+    import pmoe_amd.ops as ops
+    from pmoe_amd.loss import punet_loss
+    g = torch.load(GOLDEN / "p1_punet_b2_64_f2.pt", weights_only=False)
+    _, _, model, inp = build_pair(tmp_path, g, torch.bfloat16)
+    args = [inp[k].cuda() for k in ("images", "speed", "command")]
+    counts = []
+    for _ in range(3):
+        model.zero_grad(set_to_none=True)
+        ops.profile_begin()
+        act, sp = model(*args)
+        punet_loss(act, sp, inp["control"].cuda(), inp["target_speed"].cuda(), [0.7, 0.3]).backward()
+        counts.append(sum(1 for n, _, _ in ops.profile_end() if n.startswith("pack_conv_weights") and "gated" not in n))
+    assert counts[0] > 0 and counts[1] == 0 and counts[2] == 0, counts
+    # ... and an optimizer step invalidates them
+    with torch.no_grad():
+        for p_ in model.parameters():
+            if p_.requires_grad:
+                p_.add_(0.0)
+    ops.profile_begin()
+    model(*args)
+    assert sum(1 for n, _, _ in ops.profile_end() if n.startswith("pack_conv_weights") and "gated" not in n) > 0
