@@ -302,9 +302,20 @@ class PUNetEngine(ExpertGroupEngine):
         ops.conv2d(h.t, up.w_fwd, cat.t, **kw)
         return True
 
+    fold_entry_eca = True  # round 4: the entry block's two ECA gates folded into per-image weights of the convolutions they feed
+
     def _entry_fwd(self, masks):
         eb = self.entry
         self.training = self.pu.entry_block.training
+        n, h, w, _ = masks.t.shape
+        if self.fold_entry_eca and self.fold_eca_gate and self.training and not self.taping and h * w >= 256:
+            # untaped train-mode forward (the frozen PU-Net inside a training step): conv(x * g[n]) = conv(x, W * g[n]) -- the two
+            # gated activations (92 and 64 channels at full resolution) are never written, and the second gate's average pool comes
+            # from the BatchNorm pass that writes its input (basics.py:79-134 via model/punet.py:60-68)
+            z1, st1 = self._eca_conv_folded(masks, eb["eca1"], eb["conv1"])
+            a = self._bn(z1, eb["bn1"], relu=True, stats=st1, want_gap=True)
+            z, _ = self._eca_conv_folded(a, eb["eca2"], eb["conv2"])
+            return self._bn(z, eb["bn2"], relu=True)        # 3 real channels: centred colstats pass (no fused epilogue stats)
         a = self._eca(masks, eb["eca1"], shared=False)
         a = self._conv_bn(a, eb["conv1"], eb["bn1"], relu=True)
         a = self._eca(a, eb["eca2"], shared=False)

@@ -361,21 +361,46 @@ def run_punet_per_pass(tmp, name, dtype=torch.float32, verbose=True):
             if k.startswith("punet.") and (k.endswith("running_mean") or k.endswith("running_var")):
                 worst = max(worst, (((sd[k].double().cpu() - v).abs() / (1e-3 + v.abs())).max().item(), k))
         return worst
+
+    def bn_err_std(sd):
+        """the bf16 yardstick for the running statistics: a mean's error in units of its channel's reference standard deviation,
+        a variance's relative to the reference variance.  (The ratio to |mean| above is what the f32 run is held to at 1e-4; in
+        bf16 it is a ratio to channels whose mean is ~0 -- 1024 channels of 288 samples each at the bottleneck -- and its maximum
+        moved between 0.43 and 0.67 from one rounding realisation of the SAME arithmetic to the next: explicit ECA gates 0.43, the
+        three CPU emulation variants 0.43-0.51, gates folded into the weights 0.67, all on `pred_unet.dwn_5.1.running_mean`.)"""
+        ref = o64.state_dict()
+        worst = (0.0, "")
+        for k, v in ref.items():
+            if not k.startswith("punet."):
+                continue
+            if k.endswith("running_mean"):
+                var = ref[k[:-len("running_mean")] + "running_var"]
+                worst = max(worst, (((sd[k].double().cpu() - v).abs() / (var + 1e-5).sqrt()).max().item(), k))
+            elif k.endswith("running_var"):
+                worst = max(worst, (((sd[k].double().cpu() - v).abs() / (v + 1e-5)).max().item(), k))
+        return worst
     emul = None
     if dtype == torch.bfloat16:
         # the yardstick: the same passes through the CPU oracle with bf16 storage emulated, each on the float64 pass inputs
-        ob = copy.deepcopy(oracle)
-        EM.emulate_bf16(ob, "fused")
-        emul = []
-        with torch.no_grad():
-            for k, (xin, ref) in enumerate(passes):
-                if k < T:
-                    out = ob.punet.unet(xin.float().to(torch.bfloat16).float())
-                else:                                       # a roll-out "pass" = entry_block + pred_unet on the 4 previous (forced) masks
-                    cat = torch.cat([p[1].float() for p in passes[k - T:k]], dim=1).to(torch.bfloat16).float()
-                    out = ob.punet.pred_unet(ob.punet.entry_block(cat))
-                emul.append((EM.metric(out, ref), EM.rms_metric(out, ref)))
-        emul_bn = bn_err(ob.state_dict())
+        # (the three storage variants of oracle/bf16_emulation.py, the larger figure per pass: the product fuses some of the passes the
+        #  "all" variant stores, and folds the entry block's ECA gates into per-image weights as the "folded" one does, so its rounding
+        #  points lie among them -- the convention of tests/golden/bf16_bounds.pt, which takes the worst of its draws over the variants)
+        emul, emul_bn, emul_bn_std = None, (0.0, ""), (0.0, "")
+        for variant in ("fused", "all", "folded"):
+            ob = copy.deepcopy(oracle)
+            EM.emulate_bf16(ob, variant)
+            cur = []
+            with torch.no_grad():
+                for k, (xin, ref) in enumerate(passes):
+                    if k < T:
+                        out = ob.punet.unet(xin.float().to(torch.bfloat16).float())
+                    else:                                   # a roll-out "pass" = entry_block + pred_unet on the 4 previous (forced) masks
+                        cat = torch.cat([p[1].float() for p in passes[k - T:k]], dim=1).to(torch.bfloat16).float()
+                        out = ob.punet.pred_unet(ob.punet.entry_block(cat))
+                    cur.append((EM.metric(out, ref), EM.rms_metric(out, ref)))
+            emul = cur if emul is None else [(max(a_[0], b_[0]), max(a_[1], b_[1])) for a_, b_ in zip(emul, cur)]
+            emul_bn = max(emul_bn, bn_err(ob.state_dict()))
+            emul_bn_std = max(emul_bn_std, bn_err_std(ob.state_dict()))
     tol = PASS_TOL[dtype]
     report = {"per_pass": [], "per_pass_rms": []}
     for k, (t, (_, ref)) in enumerate(zip(got, passes)):
@@ -400,7 +425,12 @@ def run_punet_per_pass(tmp, name, dtype=torch.float32, verbose=True):
         assert worst[0] <= 1e-4, worst
     else:
         report["emulation"], report["emulation_bn"] = emul, emul_bn
-        assert worst[0] <= max(1e-2, 1.25 * emul_bn[0]), (worst, emul_bn)
+        worst_std = report["bn_running_worst_std"] = bn_err_std(sd)
+        report["emulation_bn_std"] = emul_bn_std
+        if verbose:
+            print(name, "BN running statistics, bf16: in units of the reference std / variance %.3e %s (emulation %.3e); ratio to |mean| "
+                  "%.3e (emulation %.3e)" % (worst_std + (emul_bn_std[0], worst[0], emul_bn[0])))
+        assert worst_std[0] <= max(1e-2, 1.25 * emul_bn_std[0]), (worst_std, emul_bn_std, worst, emul_bn)
     if verbose:
         print(name, "per-pass teacher-forced", dtype, "max", ["%.2e" % e for e in report["per_pass"]],
               "rms", ["%.2e" % e for e in report["per_pass_rms"]], "BN buffers %.2e %s" % worst,

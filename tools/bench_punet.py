@@ -59,7 +59,7 @@ def main():
             d = by.setdefault(name, [0.0, 0])
             d[0] += ms_
             d[1] += 1
-        for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:14]:
+        for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:32]:
             print(f"  {k:22s} {t:8.2f} ms  {n:4d} launches")
         # conv launches grouped by (layer name, kernel plan code): where the 300 conv launches spend their time
         conv = {}
