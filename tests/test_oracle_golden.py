@@ -236,3 +236,42 @@ def test_segmentation_criterion_matches_reference(golden_dir):
             torch.testing.assert_close(x.grad, c[lt]["dlogits"], rtol=1e-4, atol=1e-9)
     with pytest.raises(ValueError):
         O.AutoregressiveCriterion(1, "huber")
+
+
+def test_bf16_storage_emulation_variants():
+    """oracle/bf16_emulation.py, the yardstick of the bf16 parity tests: each variant changes WHERE values are rounded to bf16, never
+    the arithmetic -- all three stay within bf16 noise of the float64 block, the "folded" one (ECA gates multiplied into per-image
+    weights, rounded once) reproduces the gate algebra exactly when nothing is rounded, and it leaves the convolution's master
+    weights in f32."""
+    import copy
+
+    from oracle import bf16_emulation as EM
+    from oracle import pmoe_oracle as O
+    torch.manual_seed(0)
+    blk = O.EfficientConvBlock(23, 3)
+    blk.train()
+    x = torch.randn(3, 23, 32, 32)
+    ref = copy.deepcopy(blk).double()(x.double())
+    errs = {}
+    for v in ("fused", "all", "folded"):
+        b = copy.deepcopy(blk)
+        EM.emulate_bf16(b, v)
+        with torch.no_grad():
+            errs[v] = EM.metric(b(x.to(torch.bfloat16).float()), ref)
+    assert all(1e-4 < e < 5e-2 for e in errs.values()), errs           # bf16 noise: neither exact nor broken
+    assert max(errs.values()) < 3 * min(errs.values()), errs           # the variants are the same order of magnitude
+    # the fold itself is exact algebra: with the rounding switched off it equals the plain block to f32 accuracy
+    b = copy.deepcopy(blk)
+    orig = EM._round
+    EM._round = lambda t: t
+    try:
+        EM._fold_gates(b)
+        with torch.no_grad():
+            out = b(x)
+    finally:
+        EM._round = orig
+    assert EM.metric(out, ref) < 1e-5
+    b = copy.deepcopy(blk)
+    w0 = b.layer1.conv1[0].weight.detach().clone()
+    EM.emulate_bf16(b, "folded")
+    assert torch.equal(b.layer1.conv1[0].weight, w0)                    # master weights stay f32: W * g[n] is what gets rounded
