@@ -431,6 +431,9 @@ def run_punet_per_pass(tmp, name, dtype=torch.float32, verbose=True):
             print(name, "BN running statistics, bf16: in units of the reference std / variance %.3e %s (emulation %.3e); ratio to |mean| "
                   "%.3e (emulation %.3e)" % (worst_std + (emul_bn_std[0], worst[0], emul_bn[0])))
         assert worst_std[0] <= max(1e-2, 1.25 * emul_bn_std[0]), (worst_std, emul_bn_std, worst, emul_bn)
+        # the ill-conditioned ratio to |mean| stays as a coarse net (it was THE bound until the ECA fold moved its realisation: 0.43
+        # explicit, 0.67 folded, emulations 0.43-0.51 -- see bn_err_std): twice the emulation's worst
+        assert worst[0] <= max(1e-2, 2.0 * emul_bn[0]), (worst, emul_bn)
     if verbose:
         print(name, "per-pass teacher-forced", dtype, "max", ["%.2e" % e for e in report["per_pass"]],
               "rms", ["%.2e" % e for e in report["per_pass_rms"]], "BN buffers %.2e %s" % worst,
