@@ -141,6 +141,18 @@ class PUNetEngine(ExpertGroupEngine):
             self.conv1 = self.eca1 = None
             return
         super()._collect_backbone(bbs)
+        c1 = self.conv1
+        if self.pad_stem_input and c1.ks == 3 and c1.stride == 1 and c1.coutp == 64 and c1.cin > 64 and c1.cinp % 64:
+            # round 4: the 138-channel stem input (F predicted masks x 23 classes) stored in rows of 192 channels instead of 144, zero
+            # filled -- whole 64-channel chunks, so the convolution (667 GFLOP at the C4 shape) runs on the persistent LDS-DMA kernel's
+            # 64-output-channel tiles (plan 5067) instead of the generic register-staged kernel's 16-channel chunks (273 TFLOP/s)
+            c1.cinp = (c1.cin + 63) // 64 * 64
+
+    pad_stem_input = True
+
+    def _x0_width(self, channels):
+        """row width of the backbone's input tensor: the stem convolution's (possibly 64-padded) input-channel count"""
+        return self.conv1.cinp if self.conv1 is not None and self.conv1.cin == channels else r16(channels)
 
     def _collect_heads(self, ex):
         conv, mlp = self._mk["conv"], self._mk["mlp"]
@@ -390,7 +402,7 @@ class PUNetEngine(ExpertGroupEngine):
             masks.append(m)
         x0 = None
         if not self.return_inter:                  # torch.stack(outs,1).view(B,-1,H,W)  (punet.py:120, moe.py:311)
-            x0 = Var(self._new(Bsz, H, W, r16(F_ * nc)))
+            x0 = Var(self._new(Bsz, H, W, self._x0_width(F_ * nc)))
             self._cat_masks([m.t for m in masks[T:]], x0.t, nc)
         self._pred_masks = masks[T:] if self.taping else None
         return x0, inter
@@ -417,7 +429,7 @@ class PUNetEngine(ExpertGroupEngine):
             # the chained train-mode U-Nets' sensitivity in the loop
             mk = self.debug_x0
             Hm, Wm = mk.shape[-2:]
-            x0 = Var(self._new(Bsz, Hm, Wm, r16(mk.shape[1] * mk.shape[2])))
+            x0 = Var(self._new(Bsz, Hm, Wm, self._x0_width(mk.shape[1] * mk.shape[2])))
             ops.nchw_to_nhwc(mk.reshape(Bsz, -1, Hm, Wm).contiguous().float(), x0.t)
             inter = None
         else:
