@@ -80,13 +80,31 @@ def rel_l2(got, ref):
     return ((got - ref).norm() / (ref.norm() + 1e-20)).item()
 
 
+_ORACLES = {}      # (type, experts, weight seed, dropout) -> the filled CPU oracle: building + filling one costs ~2 s, a deepcopy 0.1 s
+
+
+def cached_oracle(key, make):
+    """a private deepcopy of the oracle `make()` builds for `key` (built once per test process: the suite constructs the same
+    handful of configurations about a hundred times)"""
+    import copy
+    if key not in _ORACLES:
+        _ORACLES[key] = make()
+    return copy.deepcopy(_ORACLES[key])
+
+
 def build_pair(g, dtype, dropout=0.0):
     m = g["meta"]
     ocfg = O.stage2_cfg(m["type"], m["n_experts"], dropout=dropout)
-    oracle = O.get_model(ocfg)
-    W.fill_state_dict(oracle, seed=m["weight_seed"])
+
+    def make():
+        o = O.get_model(ocfg)
+        W.fill_state_dict(o, seed=m["weight_seed"])
+        return o
+    oracle = cached_oracle((m["type"], m["n_experts"], m["weight_seed"], dropout), make)
     oracle.train(m["train"])
-    model = get_model(stage2_model_cfg(m["type"], m["n_experts"], dropout=dropout))
+    # (the product module before its first forward is parameter containers only: a pristine instance per configuration, deep-copied)
+    model = cached_oracle(("product", m["type"], m["n_experts"], dropout),
+                          lambda: get_model(stage2_model_cfg(m["type"], m["n_experts"], dropout=dropout)))
     model.load_state_dict(oracle.state_dict(), strict=True)
     model = model.to("cuda")
     model.compute_dtype = dtype

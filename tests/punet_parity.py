@@ -26,8 +26,12 @@ def build_pair(tmp, g, dtype, exclude_freeze=()):
     m = g["meta"]
     ocfg = O.stage2_cfg(m["type"], m["n_experts"], dropout=0.0, future_frames=m["future_frames"],
                         exclude_freeze=exclude_freeze)
-    oracle = O.get_model(ocfg)
-    W.fill_state_dict(oracle, seed=m["weight_seed"])
+    def make():
+        o = O.get_model(ocfg)
+        W.fill_state_dict(o, seed=m["weight_seed"])
+        return o
+    from tests.parity_util import cached_oracle
+    oracle = cached_oracle((m["type"], m["n_experts"], m["weight_seed"], m["future_frames"], tuple(exclude_freeze)), make)
     oracle.train(m["train"])
     model = build_product(tmp, m, exclude_freeze=exclude_freeze)
     model.load_state_dict(oracle.state_dict(), strict=True)
