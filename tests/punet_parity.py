@@ -33,7 +33,9 @@ def build_pair(tmp, g, dtype, exclude_freeze=()):
     from tests.parity_util import cached_oracle
     oracle = cached_oracle((m["type"], m["n_experts"], m["weight_seed"], m["future_frames"], tuple(exclude_freeze)), make)
     oracle.train(m["train"])
-    model = build_product(tmp, m, exclude_freeze=exclude_freeze)
+    # (the product module before its first forward: checkpoint files written + read once per configuration, then deep-copied)
+    model = cached_oracle(("product", m["type"], m["n_experts"], m["future_frames"], tuple(exclude_freeze)),
+                          lambda: build_product(tmp, m, exclude_freeze=exclude_freeze))
     model.load_state_dict(oracle.state_dict(), strict=True)
     model = model.to("cuda")
     model.compute_dtype = dtype
