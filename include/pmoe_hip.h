@@ -52,9 +52,10 @@ extern "C" {
  * mode): no side input in the epilogue (`res` must be NULL) -- the convolution's INPUT is the pre-activation z of a BatchNorm +
  * ReLU, `bn_coef` = that BatchNorm's [4][n/bn_ipe][cin] f32 coefficients, and the value the matrix cores see is
  * bf16(max((in - mean) * gamma*invstd + beta, 0)): exactly what pmoe_bn_apply(relu = 1) would have written, evaluated in LDS on the
- * halo patch, so that pass and the activation tensor between the two convolutions do not exist.  Forward launches without bias /
- * activation / dropout; bf16, the 64 -> 64-channel 3x3 stride-1 resident-filter kernel only (pmoe_conv2d_plan returns 1267,
- * anything else PMOE_ERR_UNSUPPORTED: the caller then runs pmoe_bn_apply + a plain launch). */
+ * halo patch, so that pass and the activation tensor between the two convolutions do not exist.  Forward launches without
+ * activation / dropout; bf16; the 64 -> 64-channel 3x3 stride-1 resident-filter kernel (no bias; pmoe_conv2d_plan returns 1267) and
+ * the 1x1 direct kernel (bias allowed, with or without shuffle_c: 1412 | 1414 | 1462 | 1464 -- the U-Nets' ConvTranspose2d layers and
+ * final classifier behind a frozen block); anything else PMOE_ERR_UNSUPPORTED: the caller then runs pmoe_bn_apply + a plain launch. */
 #define PMOE_RES_INBN 7
 
 /* ABI revision of this header: bumped whenever a descriptor struct, an argument list or a buffer contract changes

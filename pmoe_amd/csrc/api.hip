@@ -37,7 +37,7 @@ static int check_conv(const pmoe_conv_desc* d) {
         (!d->bn_coef || !d->stats || d->dtype != PMOE_DT_BF16 || (d->bn_ipe > 0 && (d->bn_ipe % d->ipe || d->n % d->bn_ipe))))
         return PMOE_ERR_ARG;
     if (d->res_mode == PMOE_RES_INBN &&
-        (d->res || !d->bn_coef || d->dtype != PMOE_DT_BF16 || d->bias || d->act != PMOE_ACT_NONE || d->drop_p != 0.f || d->in_shared ||
+        (d->res || !d->bn_coef || d->dtype != PMOE_DT_BF16 || (d->bias && d->ks != 1) || d->act != PMOE_ACT_NONE || d->drop_p != 0.f || d->in_shared ||
          d->w_fp8 || d->dilate || (d->bn_ipe > 0 && (d->bn_ipe % d->ipe || d->n % d->bn_ipe))))
         return PMOE_ERR_ARG;
     // geometry: forward conv / transposed (dilate) relation between (h,w) and (ho,wo)

@@ -605,6 +605,11 @@ int conv_igemm_launch(const ConvArgs& a, int dtype, hipStream_t st) {
         size_t sm;
         if (!a.bias && conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) && conv_res_pipe_ok(a))
             return conv_res_launch(a, plan, st);
+        {
+            int wpe, tpe, slabs, mt;                    // 1x1 layers: conv1x1_direct_kernel<MT, true>
+            size_t smx;
+            if (conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &smx)) return conv_c1x1_launch(a, st);
+        }
         return PMOE_ERR_UNSUPPORTED;
     }
     if (a.res_mode == PMOE_RES_DBN) {                // BatchNorm-backward reductions in the epilogue: the two LDS-DMA kernels only
@@ -663,14 +668,18 @@ int conv_igemm_plan(const ConvArgs& a, int dtype) {
     if (a.shuf_c) {
         int wpe, tpe, slabs, mt;
         size_t smx;
-        return conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &smx) ? 1450 + mt : PMOE_ERR_UNSUPPORTED;
+        return conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &smx) ? 1450 + mt + (a.res_mode == PMOE_RES_INBN ? 10 : 0)
+                                                                       : PMOE_ERR_UNSUPPORTED;
     }
     if (a.res_mode == PMOE_RES_INBN) {
         ResPlan plan;
         int pb, mpw, mph;
         size_t sm;
-        return (!a.bias && conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) && conv_res_pipe_ok(a))
-                   ? 1267 : PMOE_ERR_UNSUPPORTED;        // conv3x3_respipe_kernel<false, 3>
+        if (!a.bias && conv_res_plan(a, dtype, &plan) && conv_res_dma_ok(a, plan, &pb, &mpw, &mph, &sm) && conv_res_pipe_ok(a))
+            return 1267;                                 // conv3x3_respipe_kernel<false, 3>
+        int wpe, tpe, slabs, mt;
+        size_t smx;
+        return conv_c1x1_plan(a, dtype, &wpe, &tpe, &slabs, &mt, &smx) ? 1410 + mt : PMOE_ERR_UNSUPPORTED;      // conv1x1_direct_kernel<MT, true>
     }
     if (a.res_mode == PMOE_RES_DBN) {
         ResPlan plan;

@@ -1331,6 +1331,62 @@ def test_upconv_with_fused_pixel_shuffle(E, ipe, cin, c_up, H, W):
         close(from_nhwc(cat_a[e * ipe:(e + 1) * ipe, :, :, c_up:], c_up), ref, BF, f"fused transposed conv e{e}")
 
 
+@pytest.mark.parametrize("E,ipe,cin,cout,H,W,shuf", [(1, 4, 64, 24, 64, 64, 0), (2, 3, 128, 64, 64, 64, 64), (1, 2, 256, 128, 64, 128, 128),
+                                                     (1, 5, 64, 23 + 1, 40, 56, 0)])
+def test_conv1x1_applies_input_batchnorm_relu_on_load(E, ipe, cin, cout, H, W, shuf):
+    """PMOE_RES_INBN on conv1x1_direct_kernel (the U-Nets' final classifier and ConvTranspose2d layers behind a frozen train-mode
+    block): relu(BatchNorm(z)) evaluated in registers on the B operand.  Bit-identical to pmoe_bn_apply + the plain launch, with a
+    bias, with and without the fused 2x2 scatter, several BatchNorm parameter sets per launch (E > 1), ragged pixel counts."""
+    g = torch.Generator().manual_seed(cin + cout + H + shuf)
+    BF = torch.bfloat16
+    N = E * ipe
+    z = nhwc(rnd((N, cin, H, W), g, BF, 2.0) + 0.3, cin, BF)
+    co = 4 * shuf if shuf else cout
+    ws = [rnd((co, cin, 1, 1), g, BF, (1.0 / cin) ** 0.5) for _ in range(E)]
+    wf, _, _keep = pack(ws, 1, BF)
+    bp = (torch.randn(E, r64(co), generator=g) * 0.1).to(DEV).contiguous()
+    coef = torch.empty(4, E, cin, device=DEV)
+    coef[0] = rnd((E, cin), g, torch.float32, 0.5).to(DEV) + 0.3
+    coef[1] = 1.0
+    coef[2] = (rnd((E, cin), g, torch.float32, 0.3).abs() + 0.5).to(DEV)
+    coef[3] = rnd((E, cin), g, torch.float32, 0.4).to(DEV) + 0.2
+    kw = dict(cin=cin, cout=co, coutp=r64(co), ipe=ipe, ks=1, stride=1, pad=0, bias=bp)
+    a_ = torch.empty_like(z)
+    ops.bn_apply(z, None, a_, coef[2], coef[3], coef[0], ipe * H * W, E, cin, True)
+    if shuf:
+        ref = torch.full((N, 2 * H, 2 * W, 2 * shuf), 3.0, dtype=BF, device=DEV)
+        out = torch.full_like(ref, 3.0)
+        extra = dict(out_coff=shuf, shuffle2_c=shuf)
+        codes = (1452, 1454), (1462, 1464)
+    else:
+        ref = torch.full((N, H, W, r16(co)), 7.0, dtype=BF, device=DEV)
+        out = torch.full_like(ref, 5.0)
+        extra = {}
+        codes = (1402, 1404), (1412, 1414)
+    assert ops.conv2d(a_, wf, ref, plan_only=True, **extra, **kw) in codes[0]
+    ops.conv2d(a_, wf, ref, **extra, **kw)
+    assert ops.conv2d(z, wf, out, res_mode=hip.RES_INBN, bn_coef=coef, plan_only=True, **extra, **kw) in codes[1]
+    ops.conv2d(z, wf, out, res_mode=hip.RES_INBN, bn_coef=coef, **extra, **kw)
+    torch.cuda.synchronize()
+    if shuf:
+        assert torch.equal(out, ref)
+    else:
+        assert torch.equal(out[..., :co], ref[..., :co])
+    # and against the CPU (so that "identical" is not "identically wrong")
+    zc = z.float().cpu().permute(0, 3, 1, 2)
+    cc = coef.cpu()
+    for e in range(E):
+        act = torch.relu((zc[e * ipe:(e + 1) * ipe] - cc[0, e].view(1, -1, 1, 1)) * cc[2, e].view(1, -1, 1, 1)
+                         + cc[3, e].view(1, -1, 1, 1)).to(BF).float()
+        yr = F.conv2d(act, ws[e].to(BF).float(), bp[e, :co].cpu())
+        if shuf:
+            got = out[e * ipe:(e + 1) * ipe, :, :, shuf:].float().cpu()                      # [ipe, 2H, 2W, shuf]
+            yr = yr.view(ipe, 2, 2, shuf, H, W).permute(0, 4, 1, 5, 2, 3).reshape(ipe, 2 * H, 2 * W, shuf)
+            close(got.permute(0, 3, 1, 2), yr.permute(0, 3, 1, 2), BF, f"1x1 + scatter over relu(bn(z)) e{e}")
+        else:
+            close(from_nhwc(out[e * ipe:(e + 1) * ipe], co), yr, BF, f"1x1 over relu(bn(z)) e{e}")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("E,ipe,C,H,W,coff,ld", [(1, 3, 64, 32, 48, 0, 128), (2, 2, 128, 16, 16, 0, 256), (1, 2, 512, 8, 8, 0, 512)])
 def test_bn_apply_with_fused_maxpool2(dtype, E, ipe, C, H, W, coff, ld):
