@@ -37,7 +37,7 @@ def r64(c):
 class Var:
     """A device activation [N,H,W,ld] (+ channel window) with its gradient slot."""
     __slots__ = ("t", "coff", "c", "g", "needs_grad", "act", "drop_p", "base", "gap_part", "bn_src", "bn_part", "f8", "bn_defer",
-                 "bn_fused")
+                 "bn_fused", "pending_bn")
 
     def __init__(self, t, c=None, coff=0, needs_grad=False, base=None):
         self.t, self.coff, self.c = t, coff, (c if c is not None else t.shape[-1])
@@ -48,6 +48,8 @@ class Var:
         self.f8 = None                       # the same activation as e4m3(t * in_scale) bytes (fp8 policy: _bn, want_f8)
         self.bn_defer = False                # t feeds a BatchNorm and the ONLY consumer of dL/dt applies that BatchNorm's backward on load
         self.bn_fused = None                 # (g, coef, c1, c2) left by _bn_bwd for that consumer instead of dL/dt (round 4: _stem_in_bwd)
+        self.pending_bn = None               # (coef [4,E,C], rpe): t is the PRE-activation z of a BatchNorm + ReLU that its one consumer
+                                             # applies on load (PMOE_RES_INBN) or engine_punet._materialize writes out (untaped PU-Net forward)
 
     @property
     def grad(self):

@@ -11,6 +11,8 @@ Built from the same primitive launches as :class:`pmoe_amd.engine.ExpertGroupEng
 * ``ConvTranspose2d(k=2,s=2)`` is one 1x1 GEMM with 4*Cout rows + ``pmoe_pixel_shuffle2`` into the second half of
   the skip-concatenation buffer; ``torch.cat`` / ``view`` of 23-class masks are ``pmoe_copy_window`` launches.
 """
+import os
+
 import torch
 
 from . import hip, ops
@@ -206,7 +208,7 @@ class PUNetEngine(ExpertGroupEngine):
 
     fuse_in_bn = True      # round 4: BatchNorm + ReLU between the two convolutions of a block applied ON LOAD by the second one
 
-    def _conv3(self, x, blk, out=None, pool_to=None):
+    def _conv3(self, x, blk, out=None, pool_to=None, defer=False):
         """blocks/unet.py:14-24: (conv -> BatchNorm -> ReLU) x 2.  Untaped train-mode forward (the frozen U-Nets inside a training
         step): the activation between the two convolutions has exactly one consumer and nothing is saved for a backward pass, so
         where the second convolution's kernel can evaluate relu(bn1(z1)) on its halo patch (PMOE_RES_INBN: the 64-channel blocks)
@@ -227,9 +229,47 @@ class PUNetEngine(ExpertGroupEngine):
                 z1, st1 = self._conv_stats(x, c1)
                 self._bn_coeffs(bn1, self.B * h * w, st1, st1.shape[0] // self.E, z1)
                 z2, st2 = self._conv_stats(z1, c2, in_bn=self._last_coef)
-                return self._bn(z2, blk["bn2"], relu=True, stats=st2, out=out, pool_to=pool_to)
+                return self._last_bn(z2, st2, blk["bn2"], out, pool_to, defer)
         a = self._conv_bn(x, c1, bn1, relu=True)
+        if (defer and self.fuse_in_bn and not self.taping and self.training and self.dtype == torch.bfloat16 and self.fuse_conv_stats
+                and self.debug_acts is None and c2.w_f8 is None):
+            z2, st2 = self._conv_stats(a, c2)
+            return self._last_bn(z2, st2, blk["bn2"], out, pool_to, defer)
         return self._conv_bn(a, c2, blk["bn2"], relu=True, out=out, pool_to=pool_to)
+
+    def _last_bn(self, z2, st2, bn2, out, pool_to, defer):
+        """the block's second BatchNorm + ReLU: written out (`_bn`), or -- `defer`, untaped: the caller promises ONE consumer that is a
+        1x1 layer -- finalized only: the statistics and running buffers are updated, the activation stays pending on z2 and the
+        consumer applies it on load (conv1x1_direct_kernel<MT, true>) or `_materialize` writes it after all."""
+        if not defer or out is not None or pool_to is not None:
+            return self._bn(z2, bn2, relu=True, stats=st2, out=out, pool_to=pool_to)
+        n, h, w, _ = z2.t.shape
+        rpe = self.B * h * w
+        self._bn_coeffs(bn2, rpe, st2, st2.shape[0] // self.E, z2)
+        z2.pending_bn = (self._last_coef, rpe)
+        return z2
+
+    def _materialize(self, v):
+        """v with a pending BatchNorm + ReLU (see _last_bn) -> the activation tensor, written by the pass the fused consumer avoids"""
+        if v.pending_bn is None:
+            return v
+        coef, rpe = v.pending_bn
+        y = Var(torch.empty_like(v.t))
+        ops.bn_apply(v.t, None, y.t, coef[2], coef[3], coef[0], rpe, self.E, v.t.shape[-1], True)
+        return y
+
+    def _conv1x1_after_bn(self, h, layer, out=None):
+        """1x1 layer (+ bias) over h: where h carries a pending BatchNorm + ReLU and the direct kernel serves the shape, applied on load"""
+        if h.pending_bn is not None:
+            n, hh, ww, _ = h.t.shape
+            o = torch.empty(n, hh, ww, layer.cout_st, dtype=self.dtype, device=self.dev)
+            kw = dict(cin=layer.cinp, cout=layer.cout_st, coutp=layer.coutp, ipe=self.B, ks=1, stride=1, pad=0, bias=layer.bias_packed)
+            if ops.conv2d(h.t, layer.w_fwd, o, res_mode=hip.RES_INBN, bn_coef=h.pending_bn[0], plan_only=True, **kw) in (1412, 1414):
+                ops.set_meta(flop=2.0 * n * hh * ww * layer.cout * layer.cin, name=layer.name + "+bn")
+                ops.conv2d(h.t, layer.w_fwd, o, res_mode=hip.RES_INBN, bn_coef=h.pending_bn[0], **kw)
+                return Var(o, layer.cout_st, 0)
+            h = self._materialize(h)
+        return self._conv(h, layer, bias=True)
 
     def _maxpool2(self, x, cat=None, fused=None):
         """``fused``: the pooled tensor was already written by the pass that produced x (_bn, pool_to): only the tape entry is added."""
@@ -284,20 +324,25 @@ class PUNetEngine(ExpertGroupEngine):
             cats.append(cat)
             h = self._maxpool2(a, cat, fused=fused)
             hh, ww = hh // 2, ww // 2
-        x5 = h = self._conv3(h, U["dwn"][4])
+        # round 4 (late): the last BatchNorm + ReLU of a block whose one consumer is a 1x1 layer (the transposed convolutions, the
+        # final classifier) stays pending on its pre-activation and is applied on load by that launch (untaped forward: _last_bn)
+        lazy = self.fuse_in_bn_1x1 and not self.taping and not getattr(self, "return_inter", False)
+        x5 = h = self._conv3(h, U["dwn"][4], defer=lazy)
         for j in range(4):
             cat, up = cats[3 - j], U["up"][j]
             if not self.taping and self.fuse_upconv_shuffle and self._upconv_fused(h, up, cat):
-                h = self._conv3(cat, U["up_forw"][j])
+                h = self._conv3(cat, U["up_forw"][j], defer=lazy)
                 continue
+            h = self._materialize(h)
             t = self._conv(h, up, bias=True)                                  # [n, h, w, 4*Cout]
             ops.pixel_shuffle2(t.t, cat.t, up.c_up, dst_coff=up.c_up)
             if self.taping and t.needs_grad:
                 cat.needs_grad = True
                 self.tape.append(lambda t=t, up=up, cat=cat: self._up_bwd(t, up, cat))
-            h = self._conv3(cat, U["up_forw"][j])
-        return self._conv(h, U["out"], bias=True), x5
+            h = self._conv3(cat, U["up_forw"][j], defer=lazy)
+        return self._conv1x1_after_bn(h, U["out"]), (None if x5.pending_bn is not None else x5)
 
+    fuse_in_bn_1x1 = os.environ.get("PMOE_PUNET_BN_1X1", "1") != "0"      # round 4 (late): see _unet_fwd (the variable: A/B runs)
     fuse_upconv_shuffle = True     # round 4: ConvTranspose2d = 1x1 GEMM whose store scatters the 2x2 blocks itself (frozen / untaped path)
 
     def _upconv_fused(self, h, up, cat):
@@ -308,7 +353,11 @@ class PUNetEngine(ExpertGroupEngine):
                   out_coff=up.c_up, bias=up.bias_packed, shuffle2_c=up.c_up)
         if h.t.dtype != torch.bfloat16 or up.cout_st != 4 * up.c_up:
             return False
-        if ops.conv2d(h.t, up.w_fwd, cat.t, plan_only=True, **kw) not in (1452, 1454):
+        if h.pending_bn is not None:                      # (its BatchNorm + ReLU applied on load: conv1x1_direct_kernel<MT, true>)
+            kw.update(res_mode=hip.RES_INBN, bn_coef=h.pending_bn[0])
+            if ops.conv2d(h.t, up.w_fwd, cat.t, plan_only=True, **kw) not in (1462, 1464):
+                return False
+        elif ops.conv2d(h.t, up.w_fwd, cat.t, plan_only=True, **kw) not in (1452, 1454):
             return False
         ops.set_meta(flop=2.0 * h.t.shape[0] * h.t.shape[1] * h.t.shape[2] * up.cout * up.cin, name=up.name + "+shuffle")
         ops.conv2d(h.t, up.w_fwd, cat.t, **kw)
