@@ -122,6 +122,7 @@ int pmoe_conv2d_stat_rows(const pmoe_conv_desc* d);
  *   3000                     gemm_skinny_kernel<4|8>               (expert MLP layers / <= 2048 output pixels per expert, bf16)
  *   1000 + LOG_RB            conv3x3_res_kernel<LOG_RB>            (resident-filter kernel, conv_res.hip)
  *   1400 + MT                conv1x1_direct_kernel<MT>             (1x1, stride 1 | 2, >= 8192 pixels per expert, 64..512 input channels, conv_c1x1.hip)
+ *   1410 + MT | 1460 + MT    conv1x1_direct_kernel<MT, true>       (the same with PMOE_RES_INBN: BatchNorm + ReLU of the input applied to the operand registers; 1450 + MT / 1460 + MT: with shuffle_c)
  *   1316                     conv3x3_c16_kernel                    (16 input channels: direct MFMA form, no LDS staging, conv_c16.hip)
  *   1207 + 10 b + 20 m       conv3x3_respipe_kernel<b, m>          (resident filter bank, halo patches by LDS-DMA, read-out of tile t in registers under the MFMAs
  *                                                                   of tile t+1, conv_res.hip; b: per-expert bias row, m: 0 plain | 1 PMOE_RES_ADD | 2 PMOE_RES_DBN | 3 PMOE_RES_INBN)
